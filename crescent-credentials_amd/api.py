@@ -1,0 +1,461 @@
+"""ctypes bindings for libcrescent_gpu.so + a host-side mirror of the reference's Groth16 interface.
+
+Names follow `forks/groth16` (Groth16::create_proof_with_reduction_and_matrices, ProvingKey,
+VerifyingKey, Proof, LibsnarkReduction::witness_map_from_matrices, generate_parameters_with_qap) so
+the parity tests read like the reference's own tests.  All data crossing into the library are packed
+little-endian byte arrays (numpy uint8), exactly the C ABI of include/crescent_gpu.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libcrescent_gpu.so")
+
+FR_MODULUS = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+CG_FORM_CANONICAL, CG_FORM_MONTGOMERY = 0, 1
+
+
+class CrescentGpuError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("libcrescent_gpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+class _CgProvingKey(C.Structure):
+    _fields_ = [
+        ("coord_form", C.c_uint32),
+        ("alpha_g1", C.c_void_p), ("beta_g1", C.c_void_p), ("delta_g1", C.c_void_p),
+        ("beta_g2", C.c_void_p), ("delta_g2", C.c_void_p),
+        ("a_query", C.c_void_p), ("a_len", C.c_uint64),
+        ("b_g1_query", C.c_void_p), ("b_g1_len", C.c_uint64),
+        ("b_g2_query", C.c_void_p), ("b_g2_len", C.c_uint64),
+        ("h_query", C.c_void_p), ("h_len", C.c_uint64),
+        ("l_query", C.c_void_p), ("l_len", C.c_uint64),
+    ]
+
+
+class _CgCsr(C.Structure):
+    _fields_ = [("row_ptr", C.c_void_p), ("col", C.c_void_p), ("coeff", C.c_void_p), ("nnz", C.c_uint64)]
+
+
+class _CgOptions(C.Structure):
+    _fields_ = [("device", C.c_int32), ("window_bits", C.c_int32), ("shard_rank", C.c_int32),
+                ("shard_count", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
+class CgTimings(C.Structure):
+    _fields_ = [("upload_ms", C.c_float), ("witness_map_ms", C.c_float), ("msm_h_ms", C.c_float),
+                ("msm_l_ms", C.c_float), ("msm_a_ms", C.c_float), ("msm_b1_ms", C.c_float),
+                ("msm_b2_ms", C.c_float), ("finish_ms", C.c_float), ("total_ms", C.c_float),
+                ("msm_g1_pairs", C.c_uint64), ("msm_g2_pairs", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class _CgR1csHeader(C.Structure):
+    _fields_ = [("field_size", C.c_uint32), ("n_wires", C.c_uint32), ("n_pub_out", C.c_uint32),
+                ("n_pub_in", C.c_uint32), ("n_prv_in", C.c_uint32), ("n_constraints", C.c_uint32),
+                ("n_labels", C.c_uint64), ("num_inputs", C.c_uint64), ("num_variables", C.c_uint64)]
+
+
+# every symbol include/crescent_gpu.h declares, with its signature
+_SIGNATURES = {
+    "cg_init": (C.c_int, [C.c_int, C.c_void_p]),
+    "cg_last_error": (C.c_char_p, []),
+    "cg_version": (C.c_char_p, []),
+    "cg_circuit_load": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(_CgProvingKey), C.POINTER(_CgCsr), C.c_uint64,
+                                  C.c_uint64, C.c_uint64, C.POINTER(_CgOptions)]),
+    "cg_circuit_free": (None, [C.c_void_p]),
+    "cg_prove": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(CgTimings)]),
+    "cg_prove_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(CgTimings)]),
+    "cg_prove_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(CgTimings)]),
+    "cg_assemble": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cg_witness_map": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cg_domain_size": (C.c_uint64, [C.c_void_p]),
+    "cg_msm_g1": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p]),
+    "cg_msm_g2": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p]),
+    "cg_ntt": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_int]),
+    "cg_setup": (C.c_int, [C.POINTER(_CgCsr), C.c_uint64, C.c_uint64, C.c_uint64] + [C.c_void_p] * 11),
+    "cg_r1cs_parse": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "cg_r1cs_get": (C.c_int, [C.c_void_p, C.POINTER(_CgR1csHeader), C.POINTER(_CgCsr), C.POINTER(C.c_void_p)]),
+    "cg_r1cs_free": (None, [C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """The HIP library.  Raises if it has not been built: there is deliberately no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise CrescentGpuError(-2, "%s not found; run `python -c 'import __graft_entry__ as g; g.build()'`" % _LIB_PATH)
+        L = C.CDLL(_LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise CrescentGpuError(rc, lib().cg_last_error().decode("utf-8", "replace"))
+
+
+def _u8(a, nbytes: Optional[int] = None) -> np.ndarray:
+    if isinstance(a, (bytes, bytearray, memoryview)):
+        a = np.frombuffer(bytes(a), dtype=np.uint8)
+    a = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1)
+    if nbytes is not None and a.size != nbytes:
+        raise ValueError("expected %d bytes, got %d" % (nbytes, a.size))
+    return a
+
+
+def fr_to_bytes(x: int) -> bytes:
+    return int(x % FR_MODULUS).to_bytes(32, "little")
+
+
+def scalars_to_array(vals: Sequence[int]) -> np.ndarray:
+    return np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in vals), dtype=np.uint8).copy()
+
+
+def _ptr(a: np.ndarray) -> int:
+    return a.ctypes.data
+
+
+# ------------------------------------------------------------------------------------------------
+# data structures (forks/groth16/src/data_structures.rs)
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class VerifyingKey:
+    """data_structures.rs:31-44 (fork adds delta_g1).  Packed canonical bytes."""
+    alpha_g1: np.ndarray
+    beta_g2: np.ndarray
+    gamma_g2: np.ndarray
+    delta_g1: np.ndarray
+    delta_g2: np.ndarray
+    gamma_abc_g1: np.ndarray      # num_inputs x 64
+
+
+@dataclass
+class ProvingKey:
+    """data_structures.rs:101-118.  Queries are packed arrays: G1 64 B, G2 128 B per point, identity = zeros."""
+    vk: VerifyingKey
+    beta_g1: np.ndarray
+    delta_g1: np.ndarray
+    a_query: np.ndarray
+    b_g1_query: np.ndarray
+    b_g2_query: np.ndarray
+    h_query: np.ndarray
+    l_query: np.ndarray
+    coord_form: int = CG_FORM_CANONICAL
+
+    def _c(self) -> _CgProvingKey:
+        k = _CgProvingKey()
+        k.coord_form = self.coord_form
+        k.alpha_g1 = _ptr(self.vk.alpha_g1); k.beta_g1 = _ptr(self.beta_g1); k.delta_g1 = _ptr(self.delta_g1)
+        k.beta_g2 = _ptr(self.vk.beta_g2); k.delta_g2 = _ptr(self.vk.delta_g2)
+        k.a_query = _ptr(self.a_query); k.a_len = self.a_query.size // 64
+        k.b_g1_query = _ptr(self.b_g1_query); k.b_g1_len = self.b_g1_query.size // 64
+        k.b_g2_query = _ptr(self.b_g2_query); k.b_g2_len = self.b_g2_query.size // 128
+        k.h_query = _ptr(self.h_query); k.h_len = self.h_query.size // 64
+        k.l_query = _ptr(self.l_query); k.l_len = self.l_query.size // 64
+        return k
+
+
+@dataclass
+class Proof:
+    """data_structures.rs:7-14; `data` is the 256-byte ark-serialize uncompressed a ‖ b ‖ c."""
+    data: bytes
+
+    def serialize_uncompressed(self) -> bytes:
+        return self.data
+
+    @property
+    def a(self) -> bytes:
+        return self.data[:64]
+
+    @property
+    def b(self) -> bytes:
+        return self.data[64:192]
+
+    @property
+    def c(self) -> bytes:
+        return self.data[192:]
+
+
+@dataclass
+class _Csr:
+    row_ptr: np.ndarray   # uint64, rows + 1
+    col: np.ndarray       # uint32
+    coeff: np.ndarray     # uint8, nnz * 32 canonical
+
+    @property
+    def nnz(self) -> int:
+        return int(self.col.size)
+
+
+class ConstraintMatrices:
+    """ark-relations ConstraintMatrices<F> (fields visible at forks/circom-compat/src/zkey.rs:181-193),
+    held as three CSR matrices."""
+
+    def __init__(self, a: _Csr, b: _Csr, c: _Csr, num_instance_variables: int, num_witness_variables: int,
+                 num_constraints: int, _keepalive=None):
+        self.a, self.b, self.c = a, b, c
+        self.num_instance_variables = num_instance_variables
+        self.num_witness_variables = num_witness_variables
+        self.num_constraints = num_constraints
+        self._keepalive = _keepalive
+
+    @staticmethod
+    def from_rows(A, B, Cm, num_instance_variables: int, num_variables: int) -> "ConstraintMatrices":
+        """rows: list of list of (coeff:int, column:int) — the Vec<Vec<(F, usize)>> form."""
+        def conv(rows):
+            rp = np.zeros(len(rows) + 1, dtype=np.uint64)
+            cols, coefs = [], []
+            for i, row in enumerate(rows):
+                for coeff, col in row:
+                    cols.append(col)
+                    coefs.append(int(coeff % FR_MODULUS).to_bytes(32, "little"))
+                rp[i + 1] = len(cols)
+            return _Csr(rp, np.asarray(cols, dtype=np.uint32), np.frombuffer(b"".join(coefs), dtype=np.uint8).copy()
+                        if coefs else np.zeros(0, dtype=np.uint8))
+        return ConstraintMatrices(conv(A), conv(B), conv(Cm), num_instance_variables,
+                                  num_variables - num_instance_variables, len(A))
+
+    @property
+    def num_variables(self) -> int:
+        return self.num_instance_variables + self.num_witness_variables
+
+    def _c(self):
+        arr = (_CgCsr * 3)()
+        keep = []
+        for i, m in enumerate((self.a, self.b, self.c)):
+            col = m.col if m.col.size else np.zeros(1, dtype=np.uint32)
+            coeff = m.coeff if m.coeff.size else np.zeros(32, dtype=np.uint8)
+            keep += [col, coeff]
+            arr[i].row_ptr = _ptr(m.row_ptr); arr[i].col = _ptr(col); arr[i].coeff = _ptr(coeff); arr[i].nnz = m.nnz
+        return arr, keep
+
+
+# ------------------------------------------------------------------------------------------------
+# prover
+# ------------------------------------------------------------------------------------------------
+class Prover:
+    """A circuit loaded on one GPU (cg_ctx): proving key tables + matrices resident in HBM."""
+
+    def __init__(self, pk: ProvingKey, matrices: ConstraintMatrices, device: int = -1, window_bits: int = 0,
+                 shard_rank: int = 0, shard_count: int = 1):
+        L = lib()
+        self.num_inputs = matrices.num_instance_variables
+        self.num_constraints = matrices.num_constraints
+        self.num_variables = matrices.num_variables
+        opt = _CgOptions(device=device, window_bits=window_bits, shard_rank=shard_rank, shard_count=shard_count)
+        cpk = pk._c()
+        abc, _keep = matrices._c()
+        h = C.c_void_p()
+        _check(L.cg_circuit_load(C.byref(h), C.byref(cpk), abc, self.num_inputs, self.num_constraints,
+                                 self.num_variables, C.byref(opt)))
+        self._h = h
+        self.domain_size = int(L.cg_domain_size(h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().cg_circuit_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def prove(self, full_assignment, r: int, s: int, timings: bool = False):
+        w = _u8(full_assignment, self.num_variables * 32)
+        out = np.zeros(256, dtype=np.uint8)
+        rb, sb = _u8(fr_to_bytes(r)), _u8(fr_to_bytes(s))
+        tm = CgTimings()
+        _check(lib().cg_prove(self._h, _ptr(w), _ptr(rb), _ptr(sb), _ptr(out), C.byref(tm) if timings else None))
+        p = Proof(out.tobytes())
+        return (p, tm.as_dict()) if timings else p
+
+    def prove_dev(self, d_ptr: int, r: int, s: int, timings: bool = False):
+        """assignment already in this GPU's memory (e.g. a torch uint8 tensor's data_ptr())."""
+        out = np.zeros(256, dtype=np.uint8)
+        rb, sb = _u8(fr_to_bytes(r)), _u8(fr_to_bytes(s))
+        tm = CgTimings()
+        _check(lib().cg_prove_dev(self._h, C.c_void_p(d_ptr), _ptr(rb), _ptr(sb), _ptr(out), C.byref(tm) if timings else None))
+        p = Proof(out.tobytes())
+        return (p, tm.as_dict()) if timings else p
+
+    def prove_partial(self, assignment, r: int, on_device: bool = False) -> bytes:
+        out = np.zeros(384, dtype=np.uint8)
+        rb = _u8(fr_to_bytes(r))
+        if on_device:
+            ptr = C.c_void_p(int(assignment))
+        else:
+            w = _u8(assignment, self.num_variables * 32)
+            ptr = C.c_void_p(_ptr(w))
+        _check(lib().cg_prove_partial(self._h, ptr, 1 if on_device else 0, _ptr(rb), _ptr(out), None))
+        return out.tobytes()
+
+    def assemble(self, partials: bytes, n_shards: int, r: int, s: int) -> Proof:
+        pb = _u8(partials, 384 * n_shards)
+        out = np.zeros(256, dtype=np.uint8)
+        rb, sb = _u8(fr_to_bytes(r)), _u8(fr_to_bytes(s))
+        _check(lib().cg_assemble(self._h, _ptr(pb), n_shards, _ptr(rb), _ptr(sb), _ptr(out)))
+        return Proof(out.tobytes())
+
+    def witness_map(self, full_assignment) -> np.ndarray:
+        w = _u8(full_assignment, self.num_variables * 32)
+        h = np.zeros(self.domain_size * 32, dtype=np.uint8)
+        _check(lib().cg_witness_map(self._h, _ptr(w), _ptr(h)))
+        return h
+
+
+class LibsnarkReduction:
+    """forks/groth16/src/r1cs_to_qap.rs:100-226 (the default QAP type, lib.rs:55)."""
+
+    @staticmethod
+    def witness_map_from_matrices(prover: Prover, full_assignment) -> np.ndarray:
+        """r1cs_to_qap.rs:150-213 on a loaded circuit -> h coefficients (domain_size x 32 B canonical)."""
+        return prover.witness_map(full_assignment)
+
+
+class Groth16:
+    """forks/groth16/src/lib.rs:55-57 / prover.rs.  Loaded circuits are cached per (pk, matrices) object pair,
+    since the reference's stateless call shape would otherwise re-upload the key for every proof."""
+    _cache = {}
+
+    @classmethod
+    def create_proof_with_reduction_and_matrices(cls, pk: ProvingKey, r: int, s: int, matrices: ConstraintMatrices,
+                                                 num_inputs: int, num_constraints: int, full_assignment) -> Proof:
+        """prover.rs:26-51."""
+        if num_inputs != matrices.num_instance_variables or num_constraints != matrices.num_constraints:
+            raise ValueError("num_inputs/num_constraints disagree with the matrices")
+        key = (id(pk), id(matrices))
+        pr = cls._cache.get(key)
+        if pr is None:
+            pr = Prover(pk, matrices)
+            cls._cache[key] = pr
+        return pr.prove(full_assignment, r, s)
+
+    @classmethod
+    def clear_cache(cls):
+        for p in cls._cache.values():
+            p.close()
+        cls._cache.clear()
+
+
+def generate_parameters_with_qap(matrices: ConstraintMatrices, alpha: int, beta: int, delta: int, tau: int) -> ProvingKey:
+    """forks/groth16/src/generator.rs:50-228 with gamma = 1 and the standard generators (:28,:34-35), on the GPU."""
+    l, m, M = matrices.num_instance_variables, matrices.num_constraints, matrices.num_variables
+    D = 1
+    while D < m + l:
+        D <<= 1
+    a = np.zeros(M * 64, np.uint8); b1 = np.zeros(M * 64, np.uint8); b2 = np.zeros(M * 128, np.uint8)
+    h = np.zeros((D - 1) * 64, np.uint8); lq = np.zeros(max(M - l, 0) * 64, np.uint8) if M > l else np.zeros(0, np.uint8)
+    gabc = np.zeros(l * 64, np.uint8); vkp = np.zeros(576, np.uint8)
+    abc, _keep = matrices._c()
+    tb, ab, bb, db = (_u8(fr_to_bytes(x)) for x in (tau, alpha, beta, delta))
+    lq_buf = lq if lq.size else np.zeros(64, np.uint8)
+    _check(lib().cg_setup(abc, l, m, M, _ptr(tb), _ptr(ab), _ptr(bb), _ptr(db), _ptr(a), _ptr(b1), _ptr(b2), _ptr(h),
+                          _ptr(lq_buf), _ptr(gabc), _ptr(vkp)))
+    vk = VerifyingKey(alpha_g1=vkp[0:64].copy(), beta_g2=vkp[192:320].copy(), gamma_g2=vkp[320:448].copy(),
+                      delta_g1=vkp[128:192].copy(), delta_g2=vkp[448:576].copy(), gamma_abc_g1=gabc)
+    return ProvingKey(vk=vk, beta_g1=vkp[64:128].copy(), delta_g1=vkp[128:192].copy(), a_query=a, b_g1_query=b1,
+                      b_g2_query=b2, h_query=h, l_query=lq, coord_form=CG_FORM_CANONICAL)
+
+
+# ------------------------------------------------------------------------------------------------
+# unit-level operators
+# ------------------------------------------------------------------------------------------------
+def msm_bigint_g1(bases, scalars, coord_form: int = CG_FORM_CANONICAL, window_bits: int = 0) -> bytes:
+    """<G1 as VariableBaseMSM>::msm_bigint (call sites prover.rs:66,74,266) -> affine canonical 64 B."""
+    b, s = _u8(bases), _u8(scalars)
+    out = np.zeros(64, np.uint8)
+    _check(lib().cg_msm_g1(_ptr(b) if b.size else None, coord_form, b.size // 64, _ptr(s) if s.size else None,
+                           s.size // 32, window_bits, _ptr(out)))
+    return out.tobytes()
+
+
+def msm_bigint_g2(bases, scalars, coord_form: int = CG_FORM_CANONICAL, window_bits: int = 0) -> bytes:
+    b, s = _u8(bases), _u8(scalars)
+    out = np.zeros(128, np.uint8)
+    _check(lib().cg_msm_g2(_ptr(b) if b.size else None, coord_form, b.size // 128, _ptr(s) if s.size else None,
+                           s.size // 32, window_bits, _ptr(out)))
+    return out.tobytes()
+
+
+def _ntt(data, inverse: bool, coset: bool) -> np.ndarray:
+    a = _u8(data).copy()
+    n = a.size // 32
+    if n == 0 or n & (n - 1):
+        raise ValueError("length must be a power of two")
+    _check(lib().cg_ntt(_ptr(a), n.bit_length() - 1, 1 if inverse else 0, 1 if coset else 0))
+    return a
+
+
+def fft_in_place(data, coset: bool = False) -> np.ndarray:
+    """EvaluationDomain::fft_in_place (coset=True: the `get_coset(F::GENERATOR)` domain, r1cs_to_qap.rs:182-185)."""
+    return _ntt(data, False, coset)
+
+
+def ifft_in_place(data, coset: bool = False) -> np.ndarray:
+    """EvaluationDomain::ifft_in_place (r1cs_to_qap.rs:179-180,210)."""
+    return _ntt(data, True, coset)
+
+
+class R1CSFile:
+    """forks/circom-compat/src/circom/r1cs_reader.rs:40-148 + R1CS::from (:26-38)."""
+
+    def __init__(self, data: bytes):
+        L = lib()
+        buf = _u8(data)
+        h = C.c_void_p()
+        _check(L.cg_r1cs_parse(_ptr(buf), buf.size, C.byref(h)))
+        try:
+            hdr = _CgR1csHeader()
+            abc = (_CgCsr * 3)()
+            wm = C.c_void_p()
+            _check(L.cg_r1cs_get(h, C.byref(hdr), abc, C.byref(wm)))
+            self.header = {k: getattr(hdr, k) for k, _ in hdr._fields_}
+            n_c = hdr.n_constraints
+            mats = []
+            for k in range(3):
+                nnz = abc[k].nnz
+                rp = np.ctypeslib.as_array(C.cast(abc[k].row_ptr, C.POINTER(C.c_uint64)), shape=(n_c + 1,)).copy()
+                if nnz:
+                    col = np.ctypeslib.as_array(C.cast(abc[k].col, C.POINTER(C.c_uint32)), shape=(nnz,)).copy()
+                    coeff = np.ctypeslib.as_array(C.cast(abc[k].coeff, C.POINTER(C.c_uint8)), shape=(nnz * 32,)).copy()
+                else:
+                    col = np.zeros(0, np.uint32); coeff = np.zeros(0, np.uint8)
+                mats.append(_Csr(rp, col, coeff))
+            self.wire_mapping = np.ctypeslib.as_array(C.cast(wm, C.POINTER(C.c_uint64)), shape=(hdr.n_wires,)).copy()
+            self.num_inputs = int(hdr.num_inputs)
+            self.num_variables = int(hdr.num_variables)
+            self.num_aux = self.num_variables - self.num_inputs
+            self.matrices = ConstraintMatrices(mats[0], mats[1], mats[2], self.num_inputs, self.num_aux, n_c)
+        finally:
+            L.cg_r1cs_free(h)
+
+    def constraint(self, i: int):
+        """(A_i, B_i, C_i) as lists of (wire, coeff:int) — the reference's `Constraints<E>` tuple."""
+        out = []
+        for m in (self.matrices.a, self.matrices.b, self.matrices.c):
+            lo, hi = int(m.row_ptr[i]), int(m.row_ptr[i + 1])
+            out.append([(int(m.col[t]), int.from_bytes(m.coeff[32 * t:32 * t + 32].tobytes(), "little")) for t in range(lo, hi)])
+        return tuple(out)

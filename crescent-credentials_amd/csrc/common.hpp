@@ -1,0 +1,106 @@
+// Shared host-side plumbing for libcrescent_gpu: error reporting, HIP checks, device buffers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/crescent_gpu.h"
+#include "curve.cuh"
+
+namespace cg {
+
+// thread-local last error (cg_last_error)
+std::string& last_error();
+int fail(int code, const char* fmt, ...);
+
+struct HipError : std::runtime_error {
+    int code;
+    HipError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define CG_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            char _b[512];                                                                         \
+            snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),       \
+                     __FILE__, __LINE__);                                                         \
+            throw ::cg::HipError(_e == hipErrorOutOfMemory ? CG_ERR_OUT_OF_MEMORY : CG_ERR_HIP, _b); \
+        }                                                                                         \
+    } while (0)
+
+#define CG_KERNEL_CHECK() CG_HIP(hipGetLastError())
+
+// RAII device buffer
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t count) { alloc(count); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void alloc(size_t count) {
+        release();
+        if (count) CG_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+        n = count;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+    }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+template <class T>
+struct PinnedBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    PinnedBuf() = default;
+    explicit PinnedBuf(size_t count) { alloc(count); }
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    void alloc(size_t count) {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        if (count) CG_HIP(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault));
+        n = count;
+    }
+};
+
+inline uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+inline int ilog2_ceil(uint64_t n) { int l = 0; while ((1ull << l) < n) ++l; return l; }
+
+// ---- host-side byte <-> field conversions --------------------------------------------------------
+template <class F>
+inline F fp_from_bytes(const uint8_t* b) {  // raw 32 LE bytes -> limbs (no form change)
+    F r;
+    memcpy(r.l, b, 32);
+    return r;
+}
+template <class F>
+inline void fp_to_bytes(const F& a, uint8_t* b) { memcpy(b, a.l, 32); }
+
+template <class P>
+inline bool fp_is_canonical(const Fp<P>& a) {  // a < N
+    for (int i = 7; i >= 0; --i) {
+        if (a.l[i] < P::N[i]) return true;
+        if (a.l[i] > P::N[i]) return false;
+    }
+    return false;
+}
+
+}  // namespace cg

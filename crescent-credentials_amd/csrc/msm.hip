@@ -1,0 +1,503 @@
+// Pippenger MSM over BN254 G1/G2 for gfx950.
+//
+// Computes Σ s_i·P_i, the value of ark-ec's `VariableBaseMSM::msm_bigint` at the call sites
+// forks/groth16/src/prover.rs:66,74,266.  The sum is a unique group element, so the window size,
+// the signed-digit recoding and the order of additions are free design choices; only the final
+// affine point is observable (prover.rs:131-135).
+//
+// Pipeline (all on one stream):
+//   digits   : every canonical scalar -> W signed c-bit digits; zero digits and identity bases are
+//              dropped; survivors become (bucket, table index | sign) entries, compacted with a
+//              deterministic prefix sum.
+//   sort     : rocPRIM radix sort of the entries by bucket (c-1 key bits).
+//   accumulate: the sorted list is cut into equal segments, one per lane, so every lane of every
+//              wave performs the same number of mixed additions regardless of how skewed the
+//              buckets are (circom witnesses are dominated by 0/1 wires).  A lane flushes runs that
+//              lie wholly inside its segment straight to the bucket array and hands the first/last
+//              run up as a partial; partials are reduced by the same kernel recursively.
+//   reduce   : Σ (b+1)·S_b by chunked running sums, a small scalar multiple per chunk, and a tree
+//              sum.
+#include "msm.hpp"
+
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+namespace cg {
+
+static constexpr int SCALAR_BITS = 255;  // c*W must reach bit 254 plus the recoding carry
+
+// ---------------------------------------------------------------------------------------------
+// window choice
+// ---------------------------------------------------------------------------------------------
+int msm_default_window(uint64_t n, bool precomputed) {
+    double best = 1e300;
+    int best_c = 4;
+    for (int c = 4; c <= 22; ++c) {
+        int W = (SCALAR_BITS + c - 1) / c;
+        if ((double)W * (double)n >= 2147483648.0) continue;
+        double buckets = (double)(1u << (c - 1)) * (precomputed ? 1 : W);
+        if (buckets > (double)(1u << 24)) continue;
+        // mixed add ~ 10 field products, bucket-reduction add ~ 14, two per bucket
+        double cost = (double)n * W * 10.0 + buckets * 2.0 * 14.0;
+        if (cost < best) { best = cost; best_c = c; }
+    }
+    return best_c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// base import / window tables
+// ---------------------------------------------------------------------------------------------
+template <class F> struct Coords;
+template <> struct Coords<Fq> { static constexpr int N = 2; };
+template <> struct Coords<Fq2> { static constexpr int N = 4; };
+
+// raw[i] holds 2 (G1) or 4 (G2) 32-byte field elements; identity = all zero
+template <class F>
+__global__ void __launch_bounds__(256) k_import(const Fq* __restrict__ raw, Affine<F>* __restrict__ out, uint64_t n, int to_mont_form) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    constexpr int NC = Coords<F>::N;
+    Fq c[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        c[k] = raw[i * NC + k];
+        if (to_mont_form) c[k] = to_mont(c[k]);
+    }
+    Affine<F> p;
+    if constexpr (NC == 2) { p.x = c[0]; p.y = c[1]; }
+    else { p.x = {c[0], c[1]}; p.y = {c[2], c[3]}; }
+    out[i] = p;
+}
+
+template <class F>
+void import_bases(const uint8_t* host_bytes, uint32_t coord_form, uint64_t n, Affine<F>* out_dev, hipStream_t st) {
+    if (!n) return;
+    constexpr int NC = Coords<F>::N;
+    DevBuf<Fq> raw(n * NC);
+    CG_HIP(hipMemcpyAsync(raw.p, host_bytes, n * NC * 32, hipMemcpyHostToDevice, st));
+    k_import<F><<<ceil_div(n, 256), 256, 0, st>>>(raw.p, out_dev, n, coord_form == CG_FORM_CANONICAL ? 1 : 0);
+    CG_KERNEL_CHECK();
+    CG_HIP(hipStreamSynchronize(st));  // raw is freed on return
+}
+template void import_bases<Fq>(const uint8_t*, uint32_t, uint64_t, Affine<Fq>*, hipStream_t);
+template void import_bases<Fq2>(const uint8_t*, uint32_t, uint64_t, Affine<Fq2>*, hipStream_t);
+
+template <class F>
+__global__ void __launch_bounds__(256) k_table_first(const Affine<F>* __restrict__ bases, Affine<F>* __restrict__ table,
+                                                     uint8_t* __restrict__ valid, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> p = bases[i];
+    table[i] = p;
+    valid[i] = p.is_inf() ? 0 : 1;
+}
+
+// table[j*n + i] = 2^c * table[(j-1)*n + i]
+template <class F>
+__global__ void __launch_bounds__(256) k_table_next(Affine<F>* __restrict__ table, const uint8_t* __restrict__ valid,
+                                                    uint64_t n, int j, int c) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (!valid[i]) {
+        table[(uint64_t)j * n + i] = Affine<F>::inf();
+        return;
+    }
+    Affine<F> p = table[(uint64_t)(j - 1) * n + i];
+    XYZZ<F> a = dbl_affine(p);
+    for (int k = 1; k < c; ++k) a = dbl(a);
+    table[(uint64_t)j * n + i] = to_affine(a);  // a point of odd prime order never doubles to infinity
+}
+
+template <class F>
+void MsmBases<F>::build(const Affine<F>* bases_dev, uint64_t n_, int c_, bool precompute, hipStream_t st) {
+    n = n_;
+    c = c_;
+    W = (SCALAR_BITS + c - 1) / c;
+    precomputed = precompute;
+    if ((uint64_t)W * n >= (1ull << 31)) throw HipError(CG_ERR_INVALID_ARGUMENT, "MSM too large for 31-bit table indices");
+    const uint64_t rows = precompute ? (uint64_t)W : 1;
+    table.alloc(n ? rows * n : 1);
+    valid.alloc(n ? n : 1);
+    if (!n) return;
+    k_table_first<F><<<ceil_div(n, 256), 256, 0, st>>>(bases_dev, table.p, valid.p, n);
+    CG_KERNEL_CHECK();
+    if (precompute)
+        for (int j = 1; j < W; ++j) {
+            k_table_next<F><<<ceil_div(n, 256), 256, 0, st>>>(table.p, valid.p, n, j, c);
+            CG_KERNEL_CHECK();
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// signed-digit extraction
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t limb_at(const uint32_t s[8], int idx) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r = (idx == i) ? s[i] : r;
+    return r;
+}
+// bits [pos, pos+c) of the 256-bit little-endian integer s (c <= 22)
+__device__ __forceinline__ uint32_t bits_at(const uint32_t s[8], int pos, int c) {
+    int w = pos >> 5, sh = pos & 31;
+    uint64_t lo = limb_at(s, w);
+    uint64_t hi = (w + 1 < 8) ? limb_at(s, w + 1) : 0u;
+    uint64_t v = (lo | (hi << 32)) >> sh;
+    return (uint32_t)v & ((1u << c) - 1u);
+}
+
+// Calls f(j, digit) for every window; digit in [-2^(c-1), 2^(c-1)].
+template <class Fn>
+__device__ __forceinline__ void for_each_digit(const uint32_t s[8], int c, int W, Fn f) {
+    uint32_t carry = 0;
+    const uint32_t half = 1u << (c - 1);
+    for (int j = 0; j < W; ++j) {
+        int pos = j * c;
+        uint32_t raw = (pos < 256 ? bits_at(s, pos, c) : 0u) + carry;
+        int32_t d;
+        if (raw > half) { d = (int32_t)raw - (int32_t)(1u << c); carry = 1; }
+        else { d = (int32_t)raw; carry = 0; }
+        f(j, d);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_digit_count(const Fr* __restrict__ scalars, const uint8_t* __restrict__ valid,
+                                                     uint64_t n, int c, int W, uint32_t* __restrict__ counts) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t cnt = 0;
+    if (valid[i]) {
+        Fr s = scalars[i];
+        for_each_digit(s.l, c, W, [&](int, int32_t d) { cnt += (d != 0); });
+    }
+    counts[i] = cnt;
+}
+
+__global__ void __launch_bounds__(256) k_digit_emit(const Fr* __restrict__ scalars, const uint8_t* __restrict__ valid,
+                                                    uint64_t n, int c, int W, const uint32_t* __restrict__ incl,
+                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                    int precomputed) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (!valid[i]) return;
+    uint32_t pos = i ? incl[i - 1] : 0u;
+    Fr s = scalars[i];
+    const uint32_t nb = 1u << (c - 1);
+    for_each_digit(s.l, c, W, [&](int j, int32_t d) {
+        if (d != 0) {
+            uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+            uint32_t sign = d < 0 ? 0x80000000u : 0u;
+            if (precomputed) {
+                keys[pos] = mag - 1u;
+                vals[pos] = (uint32_t)((uint64_t)j * n + i) | sign;
+            } else {
+                keys[pos] = (uint32_t)j * nb + (mag - 1u);
+                vals[pos] = (uint32_t)i | sign;
+            }
+            ++pos;
+        }
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// bucket accumulation over equal segments of the sorted entry list
+// ---------------------------------------------------------------------------------------------
+template <class F>
+__device__ __forceinline__ void flush_run(uint32_t key, const XYZZ<F>& acc, bool first, bool final_level, uint32_t t,
+                                          XYZZ<F>* __restrict__ bucket_sums, uint32_t* __restrict__ part_keys,
+                                          XYZZ<F>* __restrict__ part_pts) {
+    if (first && !final_level) {
+        part_keys[2 * t] = key;
+        part_pts[2 * t] = acc;
+    } else {
+        bucket_sums[key] = acc;
+    }
+}
+
+template <class F>
+__global__ void __launch_bounds__(256) k_accum_affine(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                      uint32_t N, uint32_t L, uint32_t T, const Affine<F>* __restrict__ table,
+                                                      XYZZ<F>* __restrict__ bucket_sums, uint32_t* __restrict__ part_keys,
+                                                      XYZZ<F>* __restrict__ part_pts) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const bool final_level = (T == 1);
+    uint32_t beg = t * L;
+    uint32_t end = beg + L < N ? beg + L : N;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    uint32_t cur = keys[beg];
+    bool first = true;
+    for (uint32_t k = beg; k < end; ++k) {
+        uint32_t key = keys[k];
+        uint32_t v = vals[k];
+        if (key != cur) {
+            flush_run(cur, acc, first, final_level, t, bucket_sums, part_keys, part_pts);
+            first = false;
+            acc = XYZZ<F>::inf();
+            cur = key;
+        }
+        Affine<F> p = table[v & 0x7fffffffu];
+        if (v >> 31) p.y = neg(p.y);
+        madd(acc, p);
+    }
+    if (final_level) {
+        bucket_sums[cur] = acc;
+    } else if (first) {  // the whole segment is one run
+        part_keys[2 * t] = cur;
+        part_pts[2 * t] = acc;
+        part_keys[2 * t + 1] = cur;
+        part_pts[2 * t + 1] = XYZZ<F>::inf();
+    } else {
+        part_keys[2 * t + 1] = cur;
+        part_pts[2 * t + 1] = acc;
+    }
+}
+
+template <class F>
+__global__ void __launch_bounds__(256) k_accum_xyzz(const uint32_t* __restrict__ keys, const XYZZ<F>* __restrict__ pts,
+                                                    uint32_t N, uint32_t L, uint32_t T, XYZZ<F>* __restrict__ bucket_sums,
+                                                    uint32_t* __restrict__ part_keys, XYZZ<F>* __restrict__ part_pts) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const bool final_level = (T == 1);
+    uint32_t beg = t * L;
+    uint32_t end = beg + L < N ? beg + L : N;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    uint32_t cur = keys[beg];
+    bool first = true;
+    for (uint32_t k = beg; k < end; ++k) {
+        uint32_t key = keys[k];
+        if (key != cur) {
+            flush_run(cur, acc, first, final_level, t, bucket_sums, part_keys, part_pts);
+            first = false;
+            acc = XYZZ<F>::inf();
+            cur = key;
+        }
+        add(acc, pts[k]);
+    }
+    if (final_level) {
+        bucket_sums[cur] = acc;
+    } else if (first) {
+        part_keys[2 * t] = cur;
+        part_pts[2 * t] = acc;
+        part_keys[2 * t + 1] = cur;
+        part_pts[2 * t + 1] = XYZZ<F>::inf();
+    } else {
+        part_keys[2 * t + 1] = cur;
+        part_pts[2 * t + 1] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bucket reduction: per window, Σ_b (b+1)·S_b
+// ---------------------------------------------------------------------------------------------
+// thread t of window w covers buckets [t*K, t*K+K) of that window:
+//   out = Σ (b - tK + 1)·S_b + (tK)·Σ S_b
+template <class F>
+__global__ void __launch_bounds__(256) k_reduce_chunks(const XYZZ<F>* __restrict__ bucket_sums, uint32_t nb_per_window,
+                                                       uint32_t K, uint32_t chunks_per_window, uint32_t total_chunks,
+                                                       XYZZ<F>* __restrict__ out) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total_chunks) return;
+    uint32_t w = g / chunks_per_window, t = g % chunks_per_window;
+    const XYZZ<F>* S = bucket_sums + (uint64_t)w * nb_per_window;
+    uint32_t lo = t * K;
+    uint32_t hi = lo + K < nb_per_window ? lo + K : nb_per_window;
+    XYZZ<F> run = XYZZ<F>::inf(), acc = XYZZ<F>::inf();
+    for (uint32_t b = hi; b-- > lo;) {
+        add(run, S[b]);
+        add(acc, run);
+    }
+    if (lo != 0 && !run.is_inf()) {
+        // (lo)·run by MSB-first double-and-add; lo < 2^22
+        XYZZ<F> m = run;
+        int top = 31 - __clz(lo);
+        for (int bit = top - 1; bit >= 0; --bit) {
+            m = dbl(m);
+            if ((lo >> bit) & 1u) add(m, run);
+        }
+        add(acc, m);
+    }
+    out[g] = acc;
+}
+
+// out[w*out_per_window + blk] = Σ of this block's slice of in[w*in_per_window ...]
+template <class F>
+__global__ void __launch_bounds__(256) k_sum_points(const XYZZ<F>* __restrict__ in, uint32_t in_per_window,
+                                                    XYZZ<F>* __restrict__ out, uint32_t out_per_window) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    XYZZ<F>* sm = reinterpret_cast<XYZZ<F>*>(smem_raw);
+    const uint32_t w = blockIdx.y;
+    const uint32_t blk = blockIdx.x;
+    const XYZZ<F>* src = in + (uint64_t)w * in_per_window;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t i = blk * blockDim.x + threadIdx.x; i < in_per_window; i += gridDim.x * blockDim.x) add(acc, src[i]);
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            XYZZ<F> a = sm[threadIdx.x];
+            add(a, sm[threadIdx.x + s]);
+            sm[threadIdx.x] = a;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(uint64_t)w * out_per_window + blk] = sm[0];
+}
+
+// ---------------------------------------------------------------------------------------------
+// engine
+// ---------------------------------------------------------------------------------------------
+static constexpr uint32_t ACC_TARGET_THREADS = 256u * 4u * 4u * 64u * 2u;  // CUs x SIMDs x waves x lanes x rounds
+static constexpr uint32_t ACC_MIN_L = 8;
+static constexpr uint32_t ACC_LEVEL_L = 8;   // segment length of the partial-combining levels
+static constexpr uint32_t RED_K = 16;        // buckets per thread in the running-sum reduction
+
+static uint32_t level1_L(uint64_t N) {
+    uint64_t L = (N + ACC_TARGET_THREADS - 1) / ACC_TARGET_THREADS;
+    if (L < ACC_MIN_L) L = ACC_MIN_L;
+    return (uint32_t)L;
+}
+
+template <class F>
+void MsmEngine<F>::init(const MsmBases<F>* b) {
+    bases = b;
+    const uint64_t n = b->n;
+    const int W = b->W;
+    cap_entries = n * (uint64_t)W;
+    if (cap_entries == 0) cap_entries = 1;
+    const uint32_t nb = 1u << (b->c - 1);
+    nbuckets_total = b->precomputed ? nb : nb * (uint32_t)W;
+    keys_a.alloc(cap_entries); keys_b.alloc(cap_entries);
+    vals_a.alloc(cap_entries); vals_b.alloc(cap_entries);
+    thread_counts.alloc(n ? n : 1);
+    // rocPRIM temp sizes for the worst case
+    size_t scan_bytes = 0, sort_bytes = 0;
+    (void)rocprim::inclusive_scan(nullptr, scan_bytes, thread_counts.p, thread_counts.p, (size_t)(n ? n : 1), rocprim::plus<uint32_t>());
+    (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, keys_a.p, keys_b.p, vals_a.p, vals_b.p, (size_t)cap_entries, 0u, 32u);
+    sort_tmp_bytes = scan_bytes > sort_bytes ? scan_bytes : sort_bytes;
+    sort_tmp.alloc(sort_tmp_bytes ? sort_tmp_bytes : 1);
+    bucket_sums.alloc(nbuckets_total);
+    // partial buffers: level 1 emits 2*T1 partials with T1 <= cap/ACC_MIN_L ... but L grows with N,
+    // so T1 <= max(ACC_TARGET_THREADS, cap/ACC_MIN_L) capped by cap.
+    uint64_t t1 = (cap_entries + ACC_MIN_L - 1) / ACC_MIN_L;
+    if (t1 > ACC_TARGET_THREADS) t1 = ACC_TARGET_THREADS;
+    uint64_t pa = 2 * t1;
+    uint64_t t2 = (pa + ACC_LEVEL_L - 1) / ACC_LEVEL_L;
+    uint64_t pb = 2 * t2;
+    part_keys_a.alloc(pa); part_pts_a.alloc(pa);
+    part_keys_b.alloc(pb); part_pts_b.alloc(pb);
+    const uint32_t wins = b->precomputed ? 1u : (uint32_t)W;
+    uint32_t chunks = ceil_div(nb, RED_K);
+    red_a.alloc((uint64_t)chunks * wins);
+    red_b.alloc((uint64_t)ceil_div(chunks, 256) * wins + wins);
+    result.alloc(wins);
+    h_count.alloc(1);
+    h_result.alloc(wins);
+    CG_HIP(hipEventCreateWithFlags(&ev_count, hipEventDisableTiming));
+}
+
+template <class F>
+MsmEngine<F>::~MsmEngine() {
+    if (ev_count) (void)hipEventDestroy(ev_count);
+}
+
+template <class F>
+void MsmEngine<F>::digits(const Fr* scalars_dev, uint64_t n, hipStream_t st) {
+    if (n > bases->n) n = bases->n;  // msm_bigint zips and truncates to the shorter operand
+    n_scalars = n;
+    h_count.p[0] = 0;
+    if (!n) return;
+    const int c = bases->c, W = bases->W;
+    k_digit_count<<<ceil_div(n, 256), 256, 0, st>>>(scalars_dev, bases->valid.p, n, c, W, thread_counts.p);
+    CG_KERNEL_CHECK();
+    size_t tmp = sort_tmp_bytes;
+    CG_HIP(rocprim::inclusive_scan(sort_tmp.p, tmp, thread_counts.p, thread_counts.p, (size_t)n, rocprim::plus<uint32_t>(), st));
+    CG_HIP(hipMemcpyAsync(h_count.p, thread_counts.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    CG_HIP(hipEventRecord(ev_count, st));
+    k_digit_emit<<<ceil_div(n, 256), 256, 0, st>>>(scalars_dev, bases->valid.p, n, c, W, thread_counts.p, keys_a.p, vals_a.p,
+                                                  bases->precomputed ? 1 : 0);
+    CG_KERNEL_CHECK();
+}
+
+template <class F>
+void MsmEngine<F>::accumulate(hipStream_t st) {
+    const uint32_t wins = bases->precomputed ? 1u : (uint32_t)bases->W;
+    const uint32_t nb = 1u << (bases->c - 1);
+    n_entries = 0;
+    if (n_scalars) {
+        CG_HIP(hipEventSynchronize(ev_count));
+        n_entries = h_count.p[0];
+    }
+    CG_HIP(hipMemsetAsync(bucket_sums.p, 0, bucket_sums.bytes(), st));
+    if (n_entries) {
+        const uint32_t N = n_entries;
+        int key_bits = bases->c - 1;
+        if (!bases->precomputed) key_bits += ilog2_ceil((uint64_t)bases->W);
+        if (key_bits < 1) key_bits = 1;
+        size_t tmp = sort_tmp_bytes;
+        CG_HIP(rocprim::radix_sort_pairs(sort_tmp.p, tmp, keys_a.p, keys_b.p, vals_a.p, vals_b.p, (size_t)N, 0u,
+                                         (unsigned)key_bits, st));
+        // level 1
+        uint32_t L = level1_L(N);
+        uint32_t T = ceil_div(N, L);
+        k_accum_affine<F><<<ceil_div(T, 256), 256, 0, st>>>(keys_b.p, vals_b.p, N, L, T, bases->table.p, bucket_sums.p,
+                                                            part_keys_a.p, part_pts_a.p);
+        CG_KERNEL_CHECK();
+        // combine partials until one lane covers everything
+        bool from_a = true;
+        uint32_t count = (T == 1) ? 0 : 2 * T;
+        while (count) {
+            uint32_t Lk = ACC_LEVEL_L;
+            uint32_t Tk = ceil_div(count, Lk);
+            const uint32_t* ik = from_a ? part_keys_a.p : part_keys_b.p;
+            const XYZZ<F>* ip = from_a ? part_pts_a.p : part_pts_b.p;
+            uint32_t* ok = from_a ? part_keys_b.p : part_keys_a.p;
+            XYZZ<F>* op = from_a ? part_pts_b.p : part_pts_a.p;
+            k_accum_xyzz<F><<<ceil_div(Tk, 256), 256, 0, st>>>(ik, ip, count, Lk, Tk, bucket_sums.p, ok, op);
+            CG_KERNEL_CHECK();
+            count = (Tk == 1) ? 0 : 2 * Tk;
+            from_a = !from_a;
+        }
+    }
+    // bucket reduction
+    const uint32_t chunks = ceil_div(nb, RED_K);
+    const uint32_t total_chunks = chunks * wins;
+    k_reduce_chunks<F><<<ceil_div(total_chunks, 256), 256, 0, st>>>(bucket_sums.p, nb, RED_K, chunks, total_chunks, red_a.p);
+    CG_KERNEL_CHECK();
+    uint32_t per_win = chunks;
+    XYZZ<F>* src = red_a.p;
+    XYZZ<F>* dst = red_b.p;
+    while (true) {
+        uint32_t blocks = ceil_div(per_win, 256);
+        uint32_t threads = per_win < 256 ? 64u : 256u;
+        if (per_win < 256) { threads = 64; while (threads < per_win) threads <<= 1; }
+        XYZZ<F>* out = (blocks == 1) ? result.p : dst;
+        k_sum_points<F><<<dim3(blocks, wins), threads, threads * sizeof(XYZZ<F>), st>>>(src, per_win, out, blocks == 1 ? 1 : blocks);
+        CG_KERNEL_CHECK();
+        if (blocks == 1) break;
+        per_win = blocks;
+        XYZZ<F>* tswap = src; src = dst; dst = tswap;
+    }
+    CG_HIP(hipMemcpyAsync(h_result.p, result.p, wins * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+}
+
+template <class F>
+XYZZ<F> MsmEngine<F>::value() const {
+    if (bases->precomputed) return h_result.p[0];
+    // Horner over the windows: Σ_j 2^(c j) S_j
+    const int W = bases->W, c = bases->c;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int j = W - 1; j >= 0; --j) {
+        for (int k = 0; k < c; ++k) acc = dbl(acc);
+        add(acc, h_result.p[j]);
+    }
+    return acc;
+}
+
+template struct MsmBases<Fq>;
+template struct MsmBases<Fq2>;
+template struct MsmEngine<Fq>;
+template struct MsmEngine<Fq2>;
+
+}  // namespace cg

@@ -1,0 +1,69 @@
+// Pippenger multi-scalar multiplication over BN254 G1/G2 on the GPU (internal C++ interface).
+// Computes the same group element as ark-ec's `VariableBaseMSM::msm_bigint`
+// (call sites forks/groth16/src/prover.rs:66,74,266).
+#pragma once
+#include "common.hpp"
+
+namespace cg {
+
+// Fixed bases of one query, expanded for every window: table[j*n + i] = 2^(c*j) * P_i (affine,
+// Montgomery).  With all windows pre-shifted, every signed digit of every scalar lands in ONE
+// shared set of 2^(c-1) buckets, so a whole MSM is a single bucket accumulation plus a single
+// bucket reduction — the layout 288 GB of HBM makes affordable (13x the key size at c = 20).
+template <class F>
+struct MsmBases {
+    uint64_t n = 0;
+    int c = 0;          // window bits
+    int W = 0;          // number of windows = ceil(255 / c)
+    bool precomputed = true;   // false: table holds only window 0 and keys carry the window index
+    DevBuf<Affine<F>> table;
+    DevBuf<uint8_t> valid;     // 1 = base is not the identity
+    // bases_dev: n affine points already in Montgomery form on the device (identity = all zero)
+    void build(const Affine<F>* bases_dev, uint64_t n, int c, bool precompute, hipStream_t st);
+};
+
+int msm_default_window(uint64_t n, bool precomputed);
+
+// Per-MSM working set; reusable across proofs.
+template <class F>
+struct MsmEngine {
+    const MsmBases<F>* bases = nullptr;
+    uint64_t cap_entries = 0;
+    uint32_t nbuckets_total = 0;  // buckets per window * windows-in-key-space
+    DevBuf<uint32_t> keys_a, keys_b, vals_a, vals_b;
+    DevBuf<uint32_t> thread_counts;   // per-scalar non-zero digit count, then exclusive offsets
+    DevBuf<uint32_t> block_sums;
+    DevBuf<uint8_t> sort_tmp;
+    size_t sort_tmp_bytes = 0;
+    DevBuf<XYZZ<F>> bucket_sums;
+    DevBuf<uint32_t> part_keys_a, part_keys_b;
+    DevBuf<XYZZ<F>> part_pts_a, part_pts_b;
+    DevBuf<XYZZ<F>> red_a, red_b;
+    DevBuf<XYZZ<F>> result;           // W_keyspace points (1 when precomputed)
+    PinnedBuf<uint32_t> h_count;
+    PinnedBuf<XYZZ<F>> h_result;
+    uint64_t n_scalars = 0;
+    uint32_t n_entries = 0;
+    hipEvent_t ev_count = nullptr;
+
+    void init(const MsmBases<F>* b);
+    ~MsmEngine();
+    // phase 1: signed-digit extraction of `n` canonical scalars -> compacted (bucket, index) entries;
+    // the entry count is copied to pinned host memory asynchronously.
+    void digits(const Fr* scalars_dev, uint64_t n, hipStream_t st);
+    // phase 2 (waits for the count): sort by bucket, accumulate, reduce; result copied to h_result.
+    void accumulate(hipStream_t st);
+    // after the stream has been synchronised: the MSM value
+    XYZZ<F> value() const;
+};
+
+// import packed affine points (64 B / 128 B each, `coord_form`) into Montgomery Affine<F> on the device
+template <class F>
+void import_bases(const uint8_t* host_bytes, uint32_t coord_form, uint64_t n, Affine<F>* out_dev, hipStream_t st);
+
+extern template struct MsmBases<Fq>;
+extern template struct MsmBases<Fq2>;
+extern template struct MsmEngine<Fq>;
+extern template struct MsmEngine<Fq2>;
+
+}  // namespace cg

@@ -1,0 +1,589 @@
+// libcrescent_gpu: the C ABI of include/crescent_gpu.h.
+//
+// Host orchestration of the Groth16 prove path: the structure follows
+// forks/groth16/src/prover.rs:26-136,256-274 and r1cs_to_qap.rs:150-213 (what is computed and in
+// which algebraic order), re-laid-out for one MI355X: the proving key lives in HBM as per-window
+// base tables, the five MSMs and the witness map run on separate HIP streams, and only the few
+// scalar multiplications by r, s and the final additions run on the host.
+#include <memory>
+#include <mutex>
+#include <chrono>
+
+#include "msm.hpp"
+#include "ntt.hpp"
+
+namespace cg {
+
+std::string& last_error() {
+    static thread_local std::string e;
+    return e;
+}
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    last_error() = buf;
+    return code;
+}
+
+// ---- canonical byte <-> Montgomery point conversions (host) ----------------------------------------
+static Fq fq_import(const uint8_t* b, uint32_t form) {
+    Fq a = fp_from_bytes<Fq>(b);
+    return form == CG_FORM_CANONICAL ? to_mont(a) : a;
+}
+static G1Affine g1_import(const uint8_t* b, uint32_t form) { return {fq_import(b, form), fq_import(b + 32, form)}; }
+static G2Affine g2_import(const uint8_t* b, uint32_t form) {
+    return {{fq_import(b, form), fq_import(b + 32, form)}, {fq_import(b + 64, form), fq_import(b + 96, form)}};
+}
+static void g1_export_canonical(const G1Affine& p, uint8_t* out) {  // identity -> zeros
+    fp_to_bytes(from_mont(p.x), out);
+    fp_to_bytes(from_mont(p.y), out + 32);
+}
+static void g2_export_canonical(const G2Affine& p, uint8_t* out) {
+    fp_to_bytes(from_mont(p.x.c0), out);
+    fp_to_bytes(from_mont(p.x.c1), out + 32);
+    fp_to_bytes(from_mont(p.y.c0), out + 64);
+    fp_to_bytes(from_mont(p.y.c1), out + 96);
+}
+
+// a > b as 256-bit integers (canonical limbs)
+static bool limbs_gt(const uint32_t a[8], const uint32_t b[8]) {
+    for (int i = 7; i >= 0; --i) {
+        if (a[i] > b[i]) return true;
+        if (a[i] < b[i]) return false;
+    }
+    return false;
+}
+// ark-serialize SWFlags for the uncompressed form [ark-mem; SURVEY Appendix B]: bit 7 of the last byte
+// is set when y is the larger of {y, -y}; bit 6 marks infinity (all-zero coordinates).  Isolated here.
+static void g1_serialize_uncompressed(const G1Affine& p, uint8_t out[64]) {
+    if (p.is_inf()) { memset(out, 0, 64); out[63] |= 0x40; return; }
+    Fq y = from_mont(p.y), ny = from_mont(neg(p.y));
+    g1_export_canonical(p, out);
+    if (limbs_gt(y.l, ny.l)) out[63] |= 0x80;
+}
+static void g2_serialize_uncompressed(const G2Affine& p, uint8_t out[128]) {
+    if (p.is_inf()) { memset(out, 0, 128); out[127] |= 0x40; return; }
+    g2_export_canonical(p, out);
+    Fq2 n = neg(p.y);
+    Fq y1 = from_mont(p.y.c1), n1 = from_mont(n.c1), y0 = from_mont(p.y.c0), n0 = from_mont(n.c0);
+    // QuadExtField ordering compares c1 first, then c0 [ark-mem]
+    bool gt = limbs_gt(y1.l, n1.l) || (y1 == n1 && limbs_gt(y0.l, n0.l));
+    if (gt) out[127] |= 0x80;
+}
+
+static bool scalar_is_zero(const uint8_t s[32]) {
+    for (int i = 0; i < 32; ++i) if (s[i]) return false;
+    return true;
+}
+static bool scalar_is_canonical(const uint8_t s[32]) { return fp_is_canonical(fp_from_bytes<Fr>(s)); }
+
+template <class F>
+static XYZZ<F> scalar_mul_bytes(const Affine<F>& p, const uint8_t k[32]) {
+    uint32_t e[8];
+    memcpy(e, k, 32);
+    return scalar_mul(XYZZ<F>::from_affine(p), e);
+}
+template <class F>
+static XYZZ<F> scalar_mul_bytes(const XYZZ<F>& p, const uint8_t k[32]) {
+    uint32_t e[8];
+    memcpy(e, k, 32);
+    return scalar_mul(p, e);
+}
+
+struct Range { uint64_t lo, hi; };
+static Range shard_range(uint64_t n, int rank, int count) {
+    if (count <= 1) return {0, n};
+    return {n * (uint64_t)rank / (uint64_t)count, n * (uint64_t)(rank + 1) / (uint64_t)count};
+}
+
+}  // namespace cg
+
+using namespace cg;
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+struct cg_ctx {
+    int device = 0;
+    std::mutex mu;
+    uint64_t l = 0, m = 0, M = 0, D = 0;
+    int logD = 0;
+    int shard_rank = 0, shard_count = 1;
+    // host copies of the single points the finishing step needs (Montgomery)
+    G1Affine alpha_g1, beta_g1, delta_g1, a0, b1_0;
+    G2Affine beta_g2, delta_g2, b2_0;
+    // scalar ranges (into the MSM operand numbering) owned by this shard
+    Range rh, rl, ra;   // h: [0, D-1), l: [0, M-l), a/b: [0, M-1)
+    MsmBases<Fq> bh, bl, ba, bb1;
+    MsmBases<Fq2> bb2;
+    MsmEngine<Fq> eh, el, ea, eb1;
+    MsmEngine<Fq2> eb2;
+    DevCsr A, B, C;
+    NttDomain dom;
+    DevBuf<Fr> w_canon, w_mont, va, vb, vc, h_canon;
+    hipStream_t st[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // 0: witness map + h, 1: l, 2: a, 3: b1, 4: b2
+    hipEvent_t ev_w = nullptr;
+    hipEvent_t ev_t[8] = {nullptr};
+    ~cg_ctx() {
+        for (auto& s : st) if (s) (void)hipStreamDestroy(s);
+        if (ev_w) (void)hipEventDestroy(ev_w);
+        for (auto& e : ev_t) if (e) (void)hipEventDestroy(e);
+    }
+};
+
+namespace cg {
+int translate_current_exception() {
+    try {
+        throw;
+    } catch (const HipError& e) {
+        last_error() = e.what();
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        last_error() = "host allocation failed";
+        return CG_ERR_OUT_OF_MEMORY;
+    } catch (const std::exception& e) {
+        last_error() = e.what();
+        return CG_ERR_HIP;
+    }
+}
+}  // namespace cg
+static int translate_exception() { return cg::translate_current_exception(); }
+
+extern "C" const char* cg_last_error(void) { return last_error().c_str(); }
+
+extern "C" const char* cg_version(void) { return "crescent_gpu 0.1 (gfx950; BN254 Groth16 prove path: MSM G1/G2 + NTT + witness map)"; }
+
+extern "C" int cg_init(int n_devices, const int* device_ids) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) return fail(CG_ERR_NO_DEVICE, "no HIP device visible (%s)", hipGetErrorString(e));
+    for (int i = 0; i < n_devices; ++i)
+        if (!device_ids || device_ids[i] < 0 || device_ids[i] >= count)
+            return fail(CG_ERR_INVALID_ARGUMENT, "device id out of range (have %d devices)", count);
+    return CG_OK;
+}
+
+extern "C" uint64_t cg_domain_size(const cg_ctx* ctx) { return ctx ? ctx->D : 0; }
+
+template <class F>
+static void load_query(MsmBases<F>& bases, MsmEngine<F>& eng, const uint8_t* bytes, uint32_t form, uint64_t first,
+                       uint64_t count, int window_bits, hipStream_t st) {
+    constexpr size_t PT = sizeof(Affine<F>);
+    DevBuf<Affine<F>> tmp(count ? count : 1);
+    import_bases<F>(bytes + first * PT, form, count, tmp.p, st);
+    int c = window_bits > 0 ? window_bits : msm_default_window(count ? count : 1, true);
+    bases.build(tmp.p, count, c, true, st);
+    CG_HIP(hipStreamSynchronize(st));
+    eng.init(&bases);
+}
+
+extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_csr abc[3], uint64_t num_inputs,
+                               uint64_t num_constraints, uint64_t num_variables, const cg_options* opt) {
+    if (!out || !pk || !abc) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (num_inputs == 0 || num_inputs > num_variables) return fail(CG_ERR_INVALID_ARGUMENT, "need 1 <= num_inputs <= num_variables");
+    if (pk->coord_form != CG_FORM_CANONICAL && pk->coord_form != CG_FORM_MONTGOMERY) return fail(CG_ERR_INVALID_ARGUMENT, "bad coord_form");
+    const uint64_t l = num_inputs, m = num_constraints, M = num_variables;
+    const uint64_t dom_in = m + l;
+    const int logD = ilog2_ceil(dom_in);
+    if (logD > 28) return fail(CG_ERR_POLY_DEGREE_TOO_LARGE, "num_constraints + num_inputs = %llu exceeds 2^28", (unsigned long long)dom_in);
+    const uint64_t D = 1ull << logD;
+    // query lengths fixed by the generator (generator.rs:140,162,168,174-179,185)
+    if (pk->a_len != M || pk->b_g1_len != M || pk->b_g2_len != M) return fail(CG_ERR_MALFORMED_KEY, "a/b query length must equal num_variables");
+    if (pk->l_len != M - l) return fail(CG_ERR_MALFORMED_KEY, "l_query length must equal num_variables - num_inputs");
+    if (pk->h_len != D - 1) return fail(CG_ERR_MALFORMED_KEY, "h_query length must equal domain_size - 1 = %llu", (unsigned long long)(D - 1));
+    try {
+        int dev = (opt && opt->device >= 0) ? opt->device : -1;
+        if (dev < 0) CG_HIP(hipGetDevice(&dev));
+        CG_HIP(hipSetDevice(dev));
+        std::unique_ptr<cg_ctx> c(new cg_ctx());
+        c->device = dev;
+        c->l = l; c->m = m; c->M = M; c->D = D; c->logD = logD;
+        c->shard_count = (opt && opt->shard_count > 1) ? opt->shard_count : 1;
+        c->shard_rank = (opt && c->shard_count > 1) ? opt->shard_rank : 0;
+        if (c->shard_rank < 0 || c->shard_rank >= c->shard_count) return fail(CG_ERR_INVALID_ARGUMENT, "shard_rank out of range");
+        const int wb = opt ? opt->window_bits : 0;
+        for (auto& s : c->st) CG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        CG_HIP(hipEventCreateWithFlags(&c->ev_w, hipEventDisableTiming));
+        for (auto& e : c->ev_t) CG_HIP(hipEventCreate(&e));
+        const uint32_t form = pk->coord_form;
+        c->alpha_g1 = g1_import(pk->alpha_g1, form);
+        c->beta_g1 = g1_import(pk->beta_g1, form);
+        c->delta_g1 = g1_import(pk->delta_g1, form);
+        c->beta_g2 = g2_import(pk->beta_g2, form);
+        c->delta_g2 = g2_import(pk->delta_g2, form);
+        c->a0 = g1_import(pk->a_query, form);            // query[0] of calculate_coeff (prover.rs:265)
+        c->b1_0 = g1_import(pk->b_g1_query, form);
+        c->b2_0 = g2_import(pk->b_g2_query, form);
+        c->rh = shard_range(D - 1, c->shard_rank, c->shard_count);
+        c->rl = shard_range(M - l, c->shard_rank, c->shard_count);
+        c->ra = shard_range(M - 1, c->shard_rank, c->shard_count);
+        hipStream_t s0 = c->st[0];
+        load_query<Fq>(c->bh, c->eh, pk->h_query, form, c->rh.lo, c->rh.hi - c->rh.lo, wb, s0);
+        load_query<Fq>(c->bl, c->el, pk->l_query, form, c->rl.lo, c->rl.hi - c->rl.lo, wb, s0);
+        load_query<Fq>(c->ba, c->ea, pk->a_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, s0);    // query[1..] (prover.rs:266)
+        load_query<Fq>(c->bb1, c->eb1, pk->b_g1_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, s0);
+        load_query<Fq2>(c->bb2, c->eb2, pk->b_g2_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, s0);
+        c->A.upload(abc[0], m, M);
+        c->B.upload(abc[1], m, M);
+        c->C.upload(abc[2], m, M);
+        c->dom.build(logD, true, s0);
+        c->w_canon.alloc(M); c->w_mont.alloc(M);
+        c->va.alloc(D); c->vb.alloc(D); c->vc.alloc(D); c->h_canon.alloc(D);
+        CG_HIP(hipStreamSynchronize(s0));
+        *out = c.release();
+        return CG_OK;
+    } catch (...) {
+        return translate_exception();
+    }
+}
+
+extern "C" void cg_circuit_free(cg_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    delete ctx;
+}
+
+// ---------------------------------------------------------------------------------------------
+// witness map on stream st: w_mont must be ready; result h (canonical, natural order) in c->h_canon
+// (LibsnarkReduction::witness_map_from_matrices, r1cs_to_qap.rs:150-213)
+// ---------------------------------------------------------------------------------------------
+static void run_witness_map(cg_ctx* c, hipStream_t st) {
+    const uint64_t D = c->D, m = c->m, l = c->l;
+    CG_HIP(hipMemsetAsync(c->va.p, 0, D * sizeof(Fr), st));
+    CG_HIP(hipMemsetAsync(c->vb.p, 0, D * sizeof(Fr), st));
+    CG_HIP(hipMemsetAsync(c->vc.p, 0, D * sizeof(Fr), st));
+    spmv(c->A, c->w_mont.p, c->va.p, st);   // :164-171
+    spmv(c->B, c->w_mont.p, c->vb.p, st);
+    spmv(c->C, c->w_mont.p, c->vc.p, st);   // :191-196
+    CG_HIP(hipMemcpyAsync(c->va.p + m, c->w_mont.p, l * sizeof(Fr), hipMemcpyDeviceToDevice, st));  // :173-177
+    Fr* v[3] = {c->va.p, c->vb.p, c->vc.p};
+    for (int k = 0; k < 3; ++k) {
+        ntt_dif(v[k], c->dom, true, nullptr, st);                  // ifft (unscaled, bit-reversed)  :179-180,198
+        ntt_dit(v[k], c->dom, false, c->dom.coset_br.p, st);       // x g^i / D, then fft on the coset :182-185,199
+    }
+    qap_pointwise(c->va.p, c->vb.p, c->vc.p, c->va.p, c->dom.vanishing_inv, D, st);   // :187,201-208
+    ntt_dif(c->va.p, c->dom, true, nullptr, st);                   // coset ifft :210 ...
+    ntt_unbitrev_scale(c->va.p, c->h_canon.p, c->dom.icoset_br.p, c->logD, true, st);  // ... x g^-i / D, natural order, canonical
+}
+
+struct Partials {
+    G1Affine h, l, a, b1;
+    G2Affine b2;
+};
+
+static float ev_ms(hipEvent_t a, hipEvent_t b) {
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a, b);
+    return ms;
+}
+
+static int prove_partial_impl(cg_ctx* c, const void* assignment, bool on_device, bool skip_b1, Partials& P, cg_timings* tm) {
+    CG_HIP(hipSetDevice(c->device));
+    auto t0 = std::chrono::steady_clock::now();
+    const uint64_t M = c->M, l = c->l;
+    hipStream_t s0 = c->st[0];
+    float upload_ms = 0;
+    const Fr* w_dev;
+    if (on_device) {
+        w_dev = (const Fr*)assignment;
+    } else {
+        CG_HIP(hipMemcpyAsync(c->w_canon.p, assignment, M * 32, hipMemcpyHostToDevice, s0));
+        if (tm) {
+            CG_HIP(hipStreamSynchronize(s0));
+            upload_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
+        w_dev = c->w_canon.p;
+    }
+    CG_HIP(hipEventRecord(c->ev_w, s0));
+    for (int i = 1; i < 5; ++i) CG_HIP(hipStreamWaitEvent(c->st[i], c->ev_w, 0));
+    // assignment-driven MSMs: operands (prover.rs:70-74, 84-89, 265-266)
+    //   l: l_query[i] x w[l + i];  a, b1, b2: query[1 + i] x w[1 + i]
+    if (tm) CG_HIP(hipEventRecord(c->ev_t[2], c->st[1]));
+    c->el.digits(w_dev + l + c->rl.lo, c->rl.hi - c->rl.lo, c->st[1]);
+    c->ea.digits(w_dev + 1 + c->ra.lo, c->ra.hi - c->ra.lo, c->st[2]);
+    if (!skip_b1) c->eb1.digits(w_dev + 1 + c->ra.lo, c->ra.hi - c->ra.lo, c->st[3]);
+    c->eb2.digits(w_dev + 1 + c->ra.lo, c->ra.hi - c->ra.lo, c->st[4]);
+    // witness map, then h digits, on stream 0
+    if (tm) CG_HIP(hipEventRecord(c->ev_t[0], s0));
+    fr_to_mont(w_dev, c->w_mont.p, M, s0);
+    run_witness_map(c, s0);
+    if (tm) CG_HIP(hipEventRecord(c->ev_t[1], s0));
+    c->eh.digits(c->h_canon.p + c->rh.lo, c->rh.hi - c->rh.lo, s0);
+    // second phase (each waits for its own entry count)
+    c->el.accumulate(c->st[1]);
+    if (tm) CG_HIP(hipEventRecord(c->ev_t[3], c->st[1]));
+    c->ea.accumulate(c->st[2]);
+    if (!skip_b1) c->eb1.accumulate(c->st[3]);
+    c->eb2.accumulate(c->st[4]);
+    c->eh.accumulate(s0);
+    if (tm) CG_HIP(hipEventRecord(c->ev_t[4], s0));
+    for (int i = 0; i < 5; ++i) CG_HIP(hipStreamSynchronize(c->st[i]));
+    P.h = to_affine(c->eh.value());
+    P.l = to_affine(c->el.value());
+    P.a = to_affine(c->ea.value());
+    P.b1 = skip_b1 ? G1Affine::inf() : to_affine(c->eb1.value());
+    P.b2 = to_affine(c->eb2.value());
+    if (tm) {
+        memset(tm, 0, sizeof(*tm));
+        tm->upload_ms = upload_ms;
+        tm->witness_map_ms = ev_ms(c->ev_t[0], c->ev_t[1]);
+        tm->msm_h_ms = ev_ms(c->ev_t[1], c->ev_t[4]);
+        tm->msm_l_ms = ev_ms(c->ev_t[2], c->ev_t[3]);
+        tm->msm_g1_pairs = c->eh.n_scalars + c->el.n_scalars + c->ea.n_scalars + (skip_b1 ? 0 : c->eb1.n_scalars);
+        tm->msm_g2_pairs = c->eb2.n_scalars;
+        tm->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return CG_OK;
+}
+
+// prover.rs:76-135 with the MSM values given
+static void assemble_impl(const cg_ctx* c, const Partials& S, const uint8_t r[32], const uint8_t s[32], uint8_t proof_out[256]) {
+    const bool r_zero = scalar_is_zero(r);
+    // r_s_delta_g1 = (delta_g1 * r) * s   (:76-80)
+    G1XYZZ r_g1 = scalar_mul_bytes(c->delta_g1, r);            // :94
+    G1XYZZ rs_delta = scalar_mul_bytes(r_g1, s);
+    // A = r*delta + a_query[0] + msm_a + alpha   (:96, 256-274)
+    G1XYZZ g_a = r_g1;
+    madd(g_a, c->a0);
+    madd(g_a, S.a);
+    madd(g_a, c->alpha_g1);
+    G1XYZZ s_g_a = scalar_mul_bytes(g_a, s);                   // :98
+    // B in G1 (:102-112)
+    G1XYZZ g1_b = G1XYZZ::inf();
+    if (!r_zero) {
+        g1_b = scalar_mul_bytes(c->delta_g1, s);
+        madd(g1_b, c->b1_0);
+        madd(g1_b, S.b1);
+        madd(g1_b, c->beta_g1);
+    }
+    // B in G2 (:116-117)
+    G2XYZZ g2_b = scalar_mul_bytes(c->delta_g2, s);
+    madd(g2_b, c->b2_0);
+    madd(g2_b, S.b2);
+    madd(g2_b, c->beta_g2);
+    G1XYZZ r_g1_b = scalar_mul_bytes(g1_b, r);                 // :118
+    // C = s*A + r*B1 - r*s*delta + l_aux_acc + h_acc (:123-128)
+    G1XYZZ g_c = s_g_a;
+    add(g_c, r_g1_b);
+    add(g_c, neg(rs_delta));
+    madd(g_c, S.l);
+    madd(g_c, S.h);
+    g1_serialize_uncompressed(to_affine(g_a), proof_out);          // Proof { a, b, c } (:131-135; data_structures.rs:7-14)
+    g2_serialize_uncompressed(to_affine(g2_b), proof_out + 64);
+    g1_serialize_uncompressed(to_affine(g_c), proof_out + 192);
+}
+
+static void partials_to_bytes(const Partials& P, uint8_t out[384]) {
+    g1_export_canonical(P.h, out);
+    g1_export_canonical(P.l, out + 64);
+    g1_export_canonical(P.a, out + 128);
+    g1_export_canonical(P.b1, out + 192);
+    g2_export_canonical(P.b2, out + 256);
+}
+
+static int check_rs(const uint8_t r[32], const uint8_t s[32]) {
+    if (!r || !s) return fail(CG_ERR_INVALID_ARGUMENT, "null r/s");
+    if (!scalar_is_canonical(r) || !scalar_is_canonical(s)) return fail(CG_ERR_INVALID_ARGUMENT, "r/s not canonical (>= field modulus)");
+    return CG_OK;
+}
+
+static int prove_common(cg_ctx* ctx, const void* assignment, bool on_device, const uint8_t r[32], const uint8_t s[32],
+                        uint8_t proof_out[256], cg_timings* tm) {
+    if (!ctx || !assignment || !proof_out) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
+    if (int e = check_rs(r, s)) return e;
+    if (ctx->shard_count != 1) return fail(CG_ERR_INVALID_ARGUMENT, "context is a shard; use cg_prove_partial + cg_assemble");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    try {
+        Partials P;
+        int e = prove_partial_impl(ctx, assignment, on_device, scalar_is_zero(r), P, tm);
+        if (e) return e;
+        auto t0 = std::chrono::steady_clock::now();
+        assemble_impl(ctx, P, r, s, proof_out);
+        if (tm) {
+            tm->finish_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            tm->total_ms += tm->finish_ms;
+        }
+        return CG_OK;
+    } catch (...) {
+        return translate_exception();
+    }
+}
+
+extern "C" int cg_prove(cg_ctx* ctx, const uint8_t* full_assignment, const uint8_t r[32], const uint8_t s[32],
+                        uint8_t proof_out[256], cg_timings* timings) {
+    return prove_common(ctx, full_assignment, false, r, s, proof_out, timings);
+}
+extern "C" int cg_prove_dev(cg_ctx* ctx, const void* d_full_assignment, const uint8_t r[32], const uint8_t s[32],
+                            uint8_t proof_out[256], cg_timings* timings) {
+    return prove_common(ctx, d_full_assignment, true, r, s, proof_out, timings);
+}
+
+extern "C" int cg_prove_partial(cg_ctx* ctx, const void* full_assignment, int assignment_on_device, const uint8_t r[32],
+                                uint8_t out_partials[384], cg_timings* timings) {
+    if (!ctx || !full_assignment || !out_partials || !r) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
+    if (!scalar_is_canonical(r)) return fail(CG_ERR_INVALID_ARGUMENT, "r not canonical");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    try {
+        Partials P;
+        int e = prove_partial_impl(ctx, full_assignment, assignment_on_device != 0, scalar_is_zero(r), P, timings);
+        if (e) return e;
+        partials_to_bytes(P, out_partials);
+        return CG_OK;
+    } catch (...) {
+        return translate_exception();
+    }
+}
+
+extern "C" int cg_assemble(cg_ctx* ctx, const uint8_t* partials, uint32_t n_shards, const uint8_t r[32], const uint8_t s[32],
+                           uint8_t proof_out[256]) {
+    if (!ctx || !partials || !proof_out || n_shards == 0) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
+    if (int e = check_rs(r, s)) return e;
+    try {
+        G1XYZZ h = G1XYZZ::inf(), l = G1XYZZ::inf(), a = G1XYZZ::inf(), b1 = G1XYZZ::inf();
+        G2XYZZ b2 = G2XYZZ::inf();
+        for (uint32_t k = 0; k < n_shards; ++k) {
+            const uint8_t* p = partials + (size_t)k * 384;
+            madd(h, g1_import(p, CG_FORM_CANONICAL));
+            madd(l, g1_import(p + 64, CG_FORM_CANONICAL));
+            madd(a, g1_import(p + 128, CG_FORM_CANONICAL));
+            madd(b1, g1_import(p + 192, CG_FORM_CANONICAL));
+            madd(b2, g2_import(p + 256, CG_FORM_CANONICAL));
+        }
+        Partials S{to_affine(h), to_affine(l), to_affine(a), to_affine(b1), to_affine(b2)};
+        assemble_impl(ctx, S, r, s, proof_out);
+        return CG_OK;
+    } catch (...) {
+        return translate_exception();
+    }
+}
+
+extern "C" int cg_witness_map(cg_ctx* ctx, const uint8_t* full_assignment, uint8_t* h_out) {
+    if (!ctx || !full_assignment || !h_out) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    try {
+        CG_HIP(hipSetDevice(ctx->device));
+        hipStream_t s0 = ctx->st[0];
+        CG_HIP(hipMemcpyAsync(ctx->w_canon.p, full_assignment, ctx->M * 32, hipMemcpyHostToDevice, s0));
+        fr_to_mont(ctx->w_canon.p, ctx->w_mont.p, ctx->M, s0);
+        run_witness_map(ctx, s0);
+        CG_HIP(hipMemcpyAsync(h_out, ctx->h_canon.p, ctx->D * 32, hipMemcpyDeviceToHost, s0));
+        CG_HIP(hipStreamSynchronize(s0));
+        return CG_OK;
+    } catch (...) {
+        return translate_exception();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// unit-level MSM / NTT
+// ---------------------------------------------------------------------------------------------
+template <class F>
+static int msm_unit(const uint8_t* bases, uint32_t form, uint64_t n_bases, const uint8_t* scalars, uint64_t n_scalars,
+                    int window_bits, Affine<F>& out) {
+    uint64_t n = n_bases < n_scalars ? n_bases : n_scalars;
+    out = Affine<F>::inf();
+    if (n == 0) return CG_OK;
+    if (!bases || !scalars) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
+    hipStream_t st;
+    CG_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    try {
+        DevBuf<Affine<F>> pts(n);
+        import_bases<F>(bases, form, n, pts.p, st);
+        DevBuf<Fr> sc(n);
+        CG_HIP(hipMemcpyAsync(sc.p, scalars, n * 32, hipMemcpyHostToDevice, st));
+        MsmBases<F> mb;
+        int c = window_bits > 0 ? window_bits : msm_default_window(n, false);
+        if (c < 2 || c > 22) throw HipError(CG_ERR_INVALID_ARGUMENT, "window_bits must be in [2, 22]");
+        mb.build(pts.p, n, c, false, st);
+        MsmEngine<F> eng;
+        eng.init(&mb);
+        eng.digits(sc.p, n, st);
+        eng.accumulate(st);
+        CG_HIP(hipStreamSynchronize(st));
+        out = to_affine(eng.value());
+    } catch (...) {
+        (void)hipStreamDestroy(st);
+        throw;
+    }
+    (void)hipStreamDestroy(st);
+    return CG_OK;
+}
+
+static int check_scalars_canonical(const uint8_t* scalars, uint64_t n) {
+    for (uint64_t i = 0; i < n; ++i)
+        if (!scalar_is_canonical(scalars + 32 * i)) return fail(CG_ERR_INVALID_ARGUMENT, "scalar %llu not canonical", (unsigned long long)i);
+    return CG_OK;
+}
+
+extern "C" int cg_msm_g1(const uint8_t* bases, uint32_t coord_form, uint64_t n_bases, const uint8_t* scalars,
+                         uint64_t n_scalars, int32_t window_bits, uint8_t out[64]) {
+    if (!out) return fail(CG_ERR_INVALID_ARGUMENT, "null out");
+    try {
+        uint64_t n = n_bases < n_scalars ? n_bases : n_scalars;
+        if (n && scalars) if (int e = check_scalars_canonical(scalars, n)) return e;
+        G1Affine r;
+        int e = msm_unit<Fq>(bases, coord_form, n_bases, scalars, n_scalars, window_bits, r);
+        if (e) return e;
+        g1_export_canonical(r, out);
+        return CG_OK;
+    } catch (...) {
+        return translate_exception();
+    }
+}
+extern "C" int cg_msm_g2(const uint8_t* bases, uint32_t coord_form, uint64_t n_bases, const uint8_t* scalars,
+                         uint64_t n_scalars, int32_t window_bits, uint8_t out[128]) {
+    if (!out) return fail(CG_ERR_INVALID_ARGUMENT, "null out");
+    try {
+        uint64_t n = n_bases < n_scalars ? n_bases : n_scalars;
+        if (n && scalars) if (int e = check_scalars_canonical(scalars, n)) return e;
+        G2Affine r;
+        int e = msm_unit<Fq2>(bases, coord_form, n_bases, scalars, n_scalars, window_bits, r);
+        if (e) return e;
+        g2_export_canonical(r, out);
+        return CG_OK;
+    } catch (...) {
+        return translate_exception();
+    }
+}
+
+extern "C" int cg_ntt(uint8_t* data, uint32_t log_n, int inverse, int coset) {
+    if (!data) return fail(CG_ERR_INVALID_ARGUMENT, "null data");
+    if (log_n > 28) return fail(CG_ERR_POLY_DEGREE_TOO_LARGE, "log_n > 28");
+    try {
+        const uint64_t n = 1ull << log_n;
+        hipStream_t st = nullptr;  // default stream
+        NttDomain dom;
+        dom.build((int)log_n, false, st);
+        DevBuf<Fr> a(n), b(n), scale;
+        CG_HIP(hipMemcpyAsync(a.p, data, n * 32, hipMemcpyHostToDevice, st));
+        fr_to_mont(a.p, a.p, n, st);
+        Fr g = fr_from_u64(5);
+        if (!inverse) {
+            // out[k] = Σ a[j] (g^j) ω^{jk}: pre-scale in natural order, DIF, undo the bit reversal
+            if (coset) {
+                scale.alloc(n);
+                fr_pow_table(scale.p, g, Fr::one(), n, false, (int)log_n, st);
+                fr_mul_vec(a.p, scale.p, n, st);
+            }
+            ntt_dif(a.p, dom, false, nullptr, st);
+            ntt_unbitrev_scale(a.p, b.p, nullptr, (int)log_n, true, st);
+        } else {
+            // coefficients = (1/n) DFT^-1, then x g^-i for the coset variant
+            scale.alloc(n);
+            Fr ninv = inv(fr_from_u64(n));
+            fr_pow_table(scale.p, coset ? inv(g) : Fr::one(), ninv, n, true, (int)log_n, st);
+            ntt_dif(a.p, dom, true, nullptr, st);
+            ntt_unbitrev_scale(a.p, b.p, scale.p, (int)log_n, true, st);
+        }
+        CG_HIP(hipMemcpyAsync(data, b.p, n * 32, hipMemcpyDeviceToHost, st));
+        CG_HIP(hipStreamSynchronize(st));
+        return CG_OK;
+    } catch (...) {
+        return translate_exception();
+    }
+}

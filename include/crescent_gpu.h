@@ -1,0 +1,210 @@
+/*
+ * crescent_gpu.h — C ABI of the MI355X-native Groth16 prover hot path for Crescent.
+ *
+ * This is the drop-in boundary for `forks/groth16` of microsoft/crescent-credentials: every entry
+ * point names the reference interface it replaces (paths relative to the reference root).  The
+ * reference has no FFI today (Rust generics only); the seams are
+ *   - the `QAP: R1CSToQAP` type parameter      forks/groth16/src/lib.rs:55, r1cs_to_qap.rs:49-98
+ *   - the three `msm_bigint` call sites         forks/groth16/src/prover.rs:66,74,266
+ *   - the caller                                creds/src/lib.rs:283 (Groth16::<Bn254>::prove)
+ * INTEGRATION.md shows the Rust `extern "C"` block + shim a maintainer would add.
+ *
+ * Conventions
+ *   - All field elements cross the boundary as 32-byte little-endian integers.
+ *     CG_FORM_CANONICAL : the plain integer in [0, p)   (what ark-serialize files contain and what
+ *                         `into_bigint()` yields, prover.rs:64,71,86)
+ *     CG_FORM_MONTGOMERY: x * 2^256 mod p, i.e. arkworks' in-memory Fp256<MontBackend<_,4>> limbs
+ *                         (KAT: forks/circom-compat/src/zkey.rs:397-402)
+ *   - G1 affine point  = x ‖ y                  (64 bytes);   identity = 64 zero bytes
+ *   - G2 affine point  = x.c0 ‖ x.c1 ‖ y.c0 ‖ y.c1 (128 bytes); identity = 128 zero bytes
+ *     (same component order as snarkjs/arkworks, zkey.rs:421-431)
+ *   - Scalars (witness, r, s) are always CG_FORM_CANONICAL.
+ *   - Every function returns CG_OK (0) or a negative cg_status; cg_last_error() returns a
+ *     thread-local human-readable message for the last failure on the calling thread.
+ *   - The caller owns every host buffer; the library copies what it keeps.
+ *   - A cg_ctx is bound to one GPU.  Calls on different contexts are independent and may run
+ *     concurrently from different threads; calls on one context are serialised internally.
+ */
+#ifndef CRESCENT_GPU_H
+#define CRESCENT_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum cg_status {
+    CG_OK = 0,
+    CG_ERR_INVALID_ARGUMENT = -1,
+    CG_ERR_NO_DEVICE = -2,            /* no HIP device / HIP runtime failure at init */
+    CG_ERR_HIP = -3,                  /* a HIP call failed; see cg_last_error() */
+    CG_ERR_OUT_OF_MEMORY = -4,
+    CG_ERR_POLY_DEGREE_TOO_LARGE = -5, /* SynthesisError::PolynomialDegreeTooLarge, r1cs_to_qap.rs:156-157 */
+    CG_ERR_MALFORMED_KEY = -6,        /* query lengths inconsistent with the circuit (SynthesisError::MalformedVerifyingKey analogue) */
+    CG_ERR_PARSE = -7,                /* .r1cs / serialized key parse failure */
+    CG_ERR_UNSATISFIED = -8           /* witness does not satisfy the R1CS (debug check only) */
+} cg_status;
+
+enum { CG_FORM_CANONICAL = 0, CG_FORM_MONTGOMERY = 1 };
+
+typedef struct cg_ctx cg_ctx;
+
+/* Packed arrays of a Groth16 proving key.
+ * Replaces: `ProvingKey<E>` / `VerifyingKey<E>` operands of the prover,
+ *           forks/groth16/src/data_structures.rs:31-44,101-118.
+ * Lengths must be (generator.rs:140,162,168,174-179,185):
+ *   a_query, b_g1_query, b_g2_query : num_variables
+ *   l_query                         : num_variables - num_inputs
+ *   h_query                         : domain_size - 1   (domain_size = next pow2 >= m + num_inputs) */
+typedef struct cg_proving_key {
+    uint32_t coord_form;        /* CG_FORM_CANONICAL or CG_FORM_MONTGOMERY for every coordinate below */
+    const uint8_t* alpha_g1;    /* vk.alpha_g1  64 B */
+    const uint8_t* beta_g1;     /* pk.beta_g1   64 B */
+    const uint8_t* delta_g1;    /* pk.delta_g1  64 B */
+    const uint8_t* beta_g2;     /* vk.beta_g2  128 B */
+    const uint8_t* delta_g2;    /* vk.delta_g2 128 B */
+    const uint8_t* a_query;     uint64_t a_len;      /* G1 */
+    const uint8_t* b_g1_query;  uint64_t b_g1_len;   /* G1 */
+    const uint8_t* b_g2_query;  uint64_t b_g2_len;   /* G2 */
+    const uint8_t* h_query;     uint64_t h_len;      /* G1 */
+    const uint8_t* l_query;     uint64_t l_len;      /* G1 */
+} cg_proving_key;
+
+/* One R1CS matrix in CSR form.
+ * Replaces: one of `ConstraintMatrices<F>::{a,b,c}` (Vec<Vec<(F, usize)>>),
+ *           operand of forks/groth16/src/prover.rs:26-33 / r1cs_to_qap.rs:150-155.
+ * Row i holds terms [row_ptr[i], row_ptr[i+1]); column = variable index (instance vars first,
+ * forks/circom-compat/src/circom/circuit.rs:61-67). */
+typedef struct cg_csr {
+    const uint64_t* row_ptr;   /* num_constraints + 1 entries */
+    const uint32_t* col;       /* nnz entries, each < num_variables */
+    const uint8_t* coeff;      /* nnz x 32 B, CG_FORM_CANONICAL */
+    uint64_t nnz;
+} cg_csr;
+
+typedef struct cg_options {
+    int32_t device;        /* HIP device ordinal; -1 = current device */
+    int32_t window_bits;   /* Pippenger window c; 0 = library default for the size */
+    int32_t shard_rank;    /* multi-GPU MSM range sharding: this context's rank ... */
+    int32_t shard_count;   /* ... of shard_count; 0 or 1 = unsharded */
+    int32_t reserved[4];
+} cg_options;
+
+/* Per-phase wall/GPU times of one cg_prove call, mirroring the reference's `print-trace` phases
+ * (forks/groth16/src/prover.rs:35-36,62,93,103,115,123). Milliseconds. */
+typedef struct cg_timings {
+    float upload_ms;       /* host -> device copy of the assignment (0 for *_dev entry points) */
+    float witness_map_ms;  /* "R1CS to QAP witness map" */
+    float msm_h_ms;        /* "Compute C": h_query MSM */
+    float msm_l_ms;        /* "Compute C": l_query MSM */
+    float msm_a_ms;        /* "Compute A" */
+    float msm_b1_ms;       /* "Compute B in G1" */
+    float msm_b2_ms;       /* "Compute B in G2" */
+    float finish_ms;       /* "Finish C" + affine normalisation + serialisation (host) */
+    float total_ms;        /* "Groth16::Prover" */
+    uint64_t msm_g1_pairs; /* (base, scalar) pairs consumed by the four G1 MSMs */
+    uint64_t msm_g2_pairs;
+} cg_timings;
+
+/* Process-wide initialisation: checks that a HIP device is present.
+ * n_devices/device_ids may be 0/NULL (use whatever is visible). */
+int cg_init(int n_devices, const int* device_ids);
+
+/* Thread-local description of the last error on this thread ("" if none). */
+const char* cg_last_error(void);
+
+/* Load a circuit: copy the proving key and the three constraint matrices to the GPU, build the
+ * per-window base tables and the NTT tables.  One-time per circuit.
+ * Replaces: `read_from_file::<ProverParams>` + `CircomConfig::new` products as consumed by the
+ *           prover (creds/src/lib.rs:258,268), and `cs.to_matrices()` (r1cs_to_qap.rs:62).
+ * num_inputs (ℓ) counts the constant-one variable; num_variables (M) = instance + witness. */
+int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_csr abc[3],
+                    uint64_t num_inputs, uint64_t num_constraints, uint64_t num_variables,
+                    const cg_options* opt);
+
+void cg_circuit_free(cg_ctx* ctx);
+
+/* Create one Groth16 proof.
+ * Replaces: `Groth16::<E,QAP>::create_proof_with_reduction_and_matrices`,
+ *           forks/groth16/src/prover.rs:26-51 (and through it :54-136, :256-274 and
+ *           r1cs_to_qap.rs:150-213).
+ * full_assignment: num_variables x 32 B canonical (instance ‖ witness, full_assignment[0] = 1).
+ * r, s: 32 B canonical each (prover.rs:150-151 samples them; r = s = 0 gives the no-zk proof,
+ *       prover.rs:160-173).
+ * proof_out: 256 B = ark-serialize uncompressed a ‖ b ‖ c (data_structures.rs:7-14).
+ * timings may be NULL. */
+int cg_prove(cg_ctx* ctx, const uint8_t* full_assignment, const uint8_t r[32], const uint8_t s[32],
+             uint8_t proof_out[256], cg_timings* timings);
+
+/* Same, with the assignment already resident in this context's GPU memory
+ * (d_full_assignment is a device pointer, num_variables x 32 B canonical). */
+int cg_prove_dev(cg_ctx* ctx, const void* d_full_assignment, const uint8_t r[32], const uint8_t s[32],
+                 uint8_t proof_out[256], cg_timings* timings);
+
+/* Multi-GPU: a context loaded with shard_count > 1 owns a contiguous range of every
+ * query.  cg_prove_partial computes this shard's five partial sums
+ *   out = h ‖ l ‖ a ‖ b1 (4 x 64 B G1 affine canonical) ‖ b2 (128 B G2 affine canonical) = 384 B
+ * (identity = zeros; b1 is all-zero and skipped when r == 0, prover.rs:102-112).
+ * cg_assemble adds the gathered partials of all shards and finishes A, B, C exactly as
+ * prover.rs:76-135.  partials: n_shards x 384 B. */
+int cg_prove_partial(cg_ctx* ctx, const void* full_assignment, int assignment_on_device,
+                     const uint8_t r[32], uint8_t out_partials[384], cg_timings* timings);
+int cg_assemble(cg_ctx* ctx, const uint8_t* partials, uint32_t n_shards, const uint8_t r[32],
+                const uint8_t s[32], uint8_t proof_out[256]);
+
+/* R1CS -> QAP witness map only: h coefficients, domain_size x 32 B canonical.
+ * Replaces: `LibsnarkReduction::witness_map_from_matrices`, r1cs_to_qap.rs:150-213. */
+int cg_witness_map(cg_ctx* ctx, const uint8_t* full_assignment, uint8_t* h_out);
+uint64_t cg_domain_size(const cg_ctx* ctx);
+
+/* Unit level: Σ scalars[i]·bases[i] over BN254 G1 / G2 for caller-supplied bases.
+ * Replaces: `<G as VariableBaseMSM>::msm_bigint(bases, scalars)` (ark-ec; call sites
+ *           prover.rs:66,74,266).  bases in `coord_form`; scalars canonical; result affine
+ *           canonical (64 / 128 B, zeros = identity).  Uses min(n_bases, n_scalars) pairs, as
+ *           msm_bigint's zip does. */
+int cg_msm_g1(const uint8_t* bases, uint32_t coord_form, uint64_t n_bases, const uint8_t* scalars,
+              uint64_t n_scalars, int32_t window_bits, uint8_t out[64]);
+int cg_msm_g2(const uint8_t* bases, uint32_t coord_form, uint64_t n_bases, const uint8_t* scalars,
+              uint64_t n_scalars, int32_t window_bits, uint8_t out[128]);
+
+/* Unit level: in-place radix-2 NTT over Fr, natural order in and out, 2^log_n x 32 B canonical.
+ * Replaces: `EvaluationDomain::{fft,ifft}_in_place` and the coset variants obtained through
+ *           `get_coset(F::GENERATOR)` (ark-poly; call sites r1cs_to_qap.rs:179-185,198-199,210).
+ * inverse = 0: out[k] = Σ a[j] (g^j if coset) ω^{jk};  inverse = 1: the inverse map. */
+int cg_ntt(uint8_t* data, uint32_t log_n, int inverse, int coset);
+
+/* Trusted setup from explicit toxic waste, on the GPU.
+ * Replaces: `generate_parameters_with_qap`, forks/groth16/src/generator.rs:50-228, with
+ *           gamma = 1 and the standard generators as the fork fixes them (:28,:34-35).
+ * Outputs are written canonical into caller buffers sized as in cg_proving_key;
+ * gamma_abc_g1 gets num_inputs x 64 B (vk.gamma_abc_g1), vk_points gets
+ * alpha_g1(64) ‖ beta_g1(64) ‖ delta_g1(64) ‖ beta_g2(128) ‖ gamma_g2(128) ‖ delta_g2(128). */
+int cg_setup(const cg_csr abc[3], uint64_t num_inputs, uint64_t num_constraints,
+             uint64_t num_variables, const uint8_t tau[32], const uint8_t alpha[32],
+             const uint8_t beta[32], const uint8_t delta[32], uint8_t* a_query, uint8_t* b_g1_query,
+             uint8_t* b_g2_query, uint8_t* h_query, uint8_t* l_query, uint8_t* gamma_abc_g1,
+             uint8_t vk_points[576]);
+
+/* .r1cs (iden3 binary) -> CSR.  Replaces: `R1CSFile::new` + `R1CS::from`,
+ * forks/circom-compat/src/circom/r1cs_reader.rs:54-148,26-38.
+ * The returned object owns its arrays; cg_r1cs_csr fills views valid until cg_r1cs_free. */
+typedef struct cg_r1cs cg_r1cs;
+typedef struct cg_r1cs_header {
+    uint32_t field_size, n_wires, n_pub_out, n_pub_in, n_prv_in, n_constraints;
+    uint64_t n_labels;
+    uint64_t num_inputs;      /* 1 + n_pub_in + n_pub_out  (r1cs_reader.rs:28) */
+    uint64_t num_variables;   /* n_wires */
+} cg_r1cs_header;
+int cg_r1cs_parse(const uint8_t* data, uint64_t len, cg_r1cs** out);
+int cg_r1cs_get(const cg_r1cs* r, cg_r1cs_header* header, cg_csr abc[3], const uint64_t** wire_mapping);
+void cg_r1cs_free(cg_r1cs* r);
+
+/* Library / device description for logs ("crescent_gpu 0.1 gfx950 ..."). */
+const char* cg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRESCENT_GPU_H */

@@ -1,0 +1,111 @@
+"""Pins the oracle (oracle/bn254_oracle.py) against every known-answer datum the reference's own tests
+hold for this path: field/curve encodings, the Fr modulus, the .r1cs parser KAT, and
+the Groth16 verification equation as the acceptance criterion."""
+import random
+
+from conftest import load_golden
+
+K = load_golden("reference_kats.json")
+
+
+def test_fq_montgomery_one_bytes(oracle):
+    # forks/circom-compat/src/zkey.rs:397-402 (`fq_buf`): LE bytes of R mod q
+    assert (oracle.MONT_R % oracle.Q).to_bytes(32, "little") == bytes(K["fq_montgomery_one_le"])
+
+
+def test_g1_generator_montgomery_bytes(oracle):
+    # zkey.rs:408-415 (`g1_buf`) = Mont(1) ‖ Mont(2); generator (1, 2) per zkey.rs:434-439
+    x, y = oracle.G1_GEN
+    enc = (x * oracle.MONT_R % oracle.Q).to_bytes(32, "little") + (y * oracle.MONT_R % oracle.Q).to_bytes(32, "little")
+    assert enc == bytes(K["g1_generator_montgomery_le"])
+    assert oracle.G1.is_on_curve(oracle.G1_GEN)
+
+
+def test_g2_generator_bytes_and_decimals(oracle):
+    # zkey.rs:421-431 (`g2_buf`, order x.c0 ‖ x.c1 ‖ y.c0 ‖ y.c1) and zkey.rs:442-460 (decimals)
+    d = K["g2_generator_decimal"]
+    gen = ((int(d["x_c0"]), int(d["x_c1"])), (int(d["y_c0"]), int(d["y_c1"])))
+    assert gen == oracle.G2_GEN
+    enc = b"".join((c * oracle.MONT_R % oracle.Q).to_bytes(32, "little") for c in (gen[0][0], gen[0][1], gen[1][0], gen[1][1]))
+    assert enc == bytes(K["g2_generator_montgomery_le"])
+    assert oracle.G2.is_on_curve(oracle.G2_GEN)
+    assert oracle.G2.to_affine(oracle.G2.mul_affine(oracle.G2_GEN, oracle.R)) is None
+
+
+def test_fr_modulus(oracle):
+    # r1cs_reader.rs:183 and witness_calculator.rs:464-467
+    assert oracle.R.to_bytes(32, "little").hex() == K["fr_modulus_le_hex"]
+    assert "%064x" % oracle.R == K["fr_modulus_hex"]
+    assert oracle.FR_MODULUS_LE.hex() == K["fr_modulus_le_hex"]
+
+
+def test_root_of_unity(oracle):
+    w = oracle.FR_ROOT_2_28
+    assert pow(w, 1 << 28, oracle.R) == 1 and pow(w, 1 << 27, oracle.R) != 1
+    assert w == 0x2A3C09F0A58A7E8500E0A7EB8EF62ABC402D111E41112ED49BD61B6E725B19F0
+    assert oracle.root_of_unity(1 << 21) == 0x1DED8980AE2BDD1A4222150E8598FC8C58F50577CA5A5CE3B2C87885FCD0B523
+
+
+def test_r1cs_sample(oracle):
+    # r1cs_reader.rs:264-345
+    e = K["r1cs_sample_expected"]
+    f = oracle.parse_r1cs(bytes.fromhex(K["r1cs_sample_hex"]))
+    h = f["header"]
+    assert f["version"] == e["version"] and h["field_size"] == e["field_size"]
+    assert (h["n_wires"], h["n_pub_out"], h["n_pub_in"], h["n_prv_in"]) == (e["n_wires"], e["n_pub_out"], e["n_pub_in"], e["n_prv_in"])
+    assert h["n_labels"] == e["n_labels"] and h["n_constraints"] == e["n_constraints"]
+    c = f["constraints"]
+    assert len(c) == e["n_constraints_len"] and len(c[0][0]) == e["c0_a_len"]
+    assert c[0][0][0] == (e["c0_a0_wire"], e["c0_a0_coeff"])
+    assert c[2][1][0] == (e["c2_b0_wire"], e["c2_b0_coeff"])
+    assert len(c[1][2]) == e["c1_c_len"]
+    assert len(f["wire_mapping"]) == e["wire_mapping_len"] and f["wire_mapping"][1] == e["wire_mapping_1"]
+    mats, l, m, M = oracle.r1cs_to_matrices(f)
+    assert (l, m, M) == (1 + 2 + 1, 3, 7)       # r1cs_reader.rs:28-30
+
+
+def test_r1cs_rejections(oracle):
+    import pytest
+    good = bytearray(bytes.fromhex(K["r1cs_sample_hex"]))
+    bad = bytearray(good); bad[0] ^= 1
+    with pytest.raises(ValueError, match="magic"):
+        oracle.parse_r1cs(bytes(bad))
+    bad = bytearray(good); bad[4] = 2
+    with pytest.raises(ValueError, match="version"):
+        oracle.parse_r1cs(bytes(bad))
+    bad = bytearray(good); bad[28] ^= 1          # first byte of the prime
+    with pytest.raises(ValueError, match="bn256"):
+        oracle.parse_r1cs(bytes(bad))
+
+
+def test_pairing_bilinear(oracle):
+    from bn254_oracle import _f12_one, _f12_pow
+    e1 = oracle.pairing(oracle.G1_GEN, oracle.G2_GEN)
+    assert e1 != _f12_one() and _f12_pow(e1, oracle.R) == _f12_one()
+    a, b = 0x1234567, 0x7654321
+    pa = oracle.G1.to_affine(oracle.G1.mul_affine(oracle.G1_GEN, a))
+    qb = oracle.G2.to_affine(oracle.G2.mul_affine(oracle.G2_GEN, b))
+    assert oracle.pairing(pa, qb) == _f12_pow(e1, a * b)
+
+
+def test_serialisation_flags(oracle):
+    # SWFlags [ark-mem]: bit 7 <=> y > -y; bit 6 <=> infinity with zero coordinates
+    P = oracle.G1_GEN
+    enc = oracle.g1_uncompressed(P)
+    assert enc[63] & 0x80 == 0 and enc[:32] == (1).to_bytes(32, "little")         # y = 2 < q - 2
+    encn = oracle.g1_uncompressed(oracle.G1.neg_affine(P))
+    assert encn[63] & 0x80 == 0x80
+    assert oracle.g1_uncompressed(None) == bytes(63) + b"\x40"
+    assert oracle.g2_uncompressed(None) == bytes(127) + b"\x40"
+    q = oracle.G2_GEN
+    f1, f2 = oracle.g2_uncompressed(q)[127] & 0x80, oracle.g2_uncompressed(oracle.G2.neg_affine(q))[127] & 0x80
+    assert {f1, f2} == {0, 0x80}
+    assert len(oracle.proof_compressed((P, q, P))) == 128 and len(oracle.proof_uncompressed((P, q, P))) == 256
+
+
+def test_msm_matches_serial_sum(oracle):
+    # forks/halo2curves/src/msm.rs:601-636 pattern: Pippenger vs the naive sum
+    rng = random.Random(5)
+    pts = [oracle.G1.to_affine(oracle.G1.mul_affine(oracle.G1_GEN, rng.randrange(1, oracle.R))) for _ in range(20)] + [None]
+    sc = [rng.randrange(oracle.R) for _ in range(19)] + [0, 1]
+    assert oracle.G1.to_affine(oracle.G1.msm(pts, sc)) == oracle.G1.to_affine(oracle.G1.msm_naive(pts, sc))

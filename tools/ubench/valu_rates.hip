@@ -1,0 +1,134 @@
+// Micro-benchmark: issue rate of the integer/FP64 VALU instructions that BN254 limb arithmetic
+// is built from, on gfx950.  Prints wave-instructions per cycle per SIMD (1/cycles-per-instr).
+// Usage: ./valu_rates   (needs a GPU)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <vector>
+#include "../../crescent-credentials_amd/csrc/field.cuh"
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+#define REP8(x) x x x x x x x x
+#define REP64(x) REP8(REP8(x))
+
+template <int KIND>
+__global__ void __launch_bounds__(256) k_rate(uint32_t* out, int iters, uint32_t seed) {
+    uint32_t a0 = threadIdx.x + seed, a1 = a0 * 3 + 1, a2 = a0 * 5 + 7, a3 = a0 ^ 0x1234567;
+    uint64_t d0 = a0, d1 = a1, d2 = a2, d3 = a3;
+    double f0 = a0, f1 = a1, f2 = a2, f3 = a3;
+    for (int i = 0; i < iters; ++i) {
+        if (KIND == 0) {  // v_mad_u64_u32, 4 independent chains
+            REP64(asm volatile("v_mad_u64_u32 %0, s[10:11], %4, %5, %0\n v_mad_u64_u32 %1, s[10:11], %4, %6, %1\n"
+                               "v_mad_u64_u32 %2, s[10:11], %5, %6, %2\n v_mad_u64_u32 %3, s[10:11], %6, %7, %3\n"
+                               : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "s10", "s11");)
+        } else if (KIND == 1) {  // v_mul_lo_u32
+            REP64(asm volatile("v_mul_lo_u32 %0, %0, %4\n v_mul_lo_u32 %1, %1, %4\n v_mul_lo_u32 %2, %2, %4\n v_mul_lo_u32 %3, %3, %4\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed));)
+        } else if (KIND == 2) {  // v_mul_hi_u32
+            REP64(asm volatile("v_mul_hi_u32 %0, %0, %4\n v_mul_hi_u32 %1, %1, %4\n v_mul_hi_u32 %2, %2, %4\n v_mul_hi_u32 %3, %3, %4\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed));)
+        } else if (KIND == 3) {  // v_add_co_u32 + v_addc_co_u32 chain
+            REP64(asm volatile("v_add_co_u32 %0, vcc, %0, %4\n v_addc_co_u32 %1, vcc, %1, %4, vcc\n v_addc_co_u32 %2, vcc, %2, %4, vcc\n v_addc_co_u32 %3, vcc, %3, %4, vcc\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed) : "vcc");)
+        } else if (KIND == 4) {  // v_lshl_add_u64
+            REP64(asm volatile("v_lshl_add_u64 %0, %0, 0, %1\n v_lshl_add_u64 %1, %1, 0, %2\n v_lshl_add_u64 %2, %2, 0, %3\n v_lshl_add_u64 %3, %3, 0, %0\n"
+                               : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));)
+        } else if (KIND == 5) {  // v_mov_b32
+            REP64(asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %0\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+        } else if (KIND == 6) {  // v_mad_u32_u24
+            REP64(asm volatile("v_mad_u32_u24 %0, %0, %4, %1\n v_mad_u32_u24 %1, %1, %4, %2\n v_mad_u32_u24 %2, %2, %4, %3\n v_mad_u32_u24 %3, %3, %4, %0\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed));)
+        } else if (KIND == 7) {  // v_mul_hi_u32_u24
+            REP64(asm volatile("v_mul_hi_u32_u24 %0, %0, %4\n v_mul_hi_u32_u24 %1, %1, %4\n v_mul_hi_u32_u24 %2, %2, %4\n v_mul_hi_u32_u24 %3, %3, %4\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed));)
+        } else if (KIND == 8) {  // v_fma_f64
+            REP64(asm volatile("v_fma_f64 %0, %0, %4, %1\n v_fma_f64 %1, %1, %4, %2\n v_fma_f64 %2, %2, %4, %3\n v_fma_f64 %3, %3, %4, %0\n"
+                               : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(1.0000001));)
+        } else if (KIND == 9) {  // v_add3_u32
+            REP64(asm volatile("v_add3_u32 %0, %0, %4, %1\n v_add3_u32 %1, %1, %4, %2\n v_add3_u32 %2, %2, %4, %3\n v_add3_u32 %3, %3, %4, %0\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed));)
+        } else if (KIND == 10) {  // v_mad_u64_u32 with carry-out consumed by v_addc_co_u32
+            REP64(asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n v_addc_co_u32 %2, vcc, 0, %2, vcc\n"
+                               "v_mad_u64_u32 %1, vcc, %5, %4, %1\n v_addc_co_u32 %3, vcc, 0, %3, vcc\n"
+                               : "+v"(d0), "+v"(d1), "+v"(a2), "+v"(a3) : "v"(a0), "v"(a1) : "vcc");)
+        } else if (KIND == 11) {  // v_mul_u32_u24
+            REP64(asm volatile("v_mul_u32_u24 %0, %0, %4\n v_mul_u32_u24 %1, %1, %4\n v_mul_u32_u24 %2, %2, %4\n v_mul_u32_u24 %3, %3, %4\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed));)
+        } else if (KIND == 12) {  // v_cndmask_b32
+            REP64(asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %0, vcc\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) :: "vcc");)
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + (uint32_t)(d0 + d1 + d2 + d3) + (uint32_t)(f0 + f1 + f2 + f3);
+}
+
+// Fq Montgomery products per second with the library's own mul() (4 independent chains / lane)
+template <class F>
+__global__ void __launch_bounds__(256) k_fpmul(F* io, int iters) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    F a = io[t], b = io[t + gridDim.x * blockDim.x];
+    F c = cg::add(a, b), d = cg::sub(a, b);
+    for (int i = 0; i < iters; ++i) {
+        a = cg::mul(a, b); b = cg::mul(b, c); c = cg::mul(c, d); d = cg::mul(d, a);
+    }
+    io[t] = cg::add(cg::add(a, b), cg::add(c, d));
+}
+
+template <int KIND>
+void run(const char* name, int per_iter, uint32_t* d_out, double clk_hz) {
+    const int blocks = 256 * 8, threads = 256, iters = 200;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    k_rate<KIND><<<blocks, threads>>>(d_out, 10, 1);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    k_rate<KIND><<<blocks, threads>>>(d_out, iters, 1);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    double wave_instr = (double)blocks * (threads / 64) * iters * 64.0 * per_iter;
+    double per_simd_per_s = wave_instr / (ms * 1e-3) / (256.0 * 4);
+    printf("%-28s %8.3f ms  %7.2f G wave-instr/s/SIMD-sum  cycles/wave-instr/SIMD @%.2f GHz = %.2f\n",
+           name, ms, wave_instr / (ms * 1e-3) / 1e9, clk_hz / 1e9, clk_hz / per_simd_per_s);
+}
+
+int main() {
+    hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
+    double clk = p.clockRate * 1e3;
+    printf("device %s CUs %d clock %.0f MHz\n", p.name, p.multiProcessorCount, clk / 1e6);
+    uint32_t* d_out; CHECK(hipMalloc(&d_out, 256 * 8 * 256 * 4));
+    run<0>("v_mad_u64_u32", 4, d_out, clk);
+    run<10>("v_mad_u64_u32+v_addc_co", 4, d_out, clk);
+    run<1>("v_mul_lo_u32", 4, d_out, clk);
+    run<2>("v_mul_hi_u32", 4, d_out, clk);
+    run<3>("v_add_co/addc_co", 4, d_out, clk);
+    run<4>("v_lshl_add_u64", 4, d_out, clk);
+    run<5>("v_mov_b32", 4, d_out, clk);
+    run<6>("v_mad_u32_u24", 4, d_out, clk);
+    run<7>("v_mul_hi_u32_u24", 4, d_out, clk);
+    run<11>("v_mul_u32_u24", 4, d_out, clk);
+    run<8>("v_fma_f64", 4, d_out, clk);
+    run<9>("v_add3_u32", 4, d_out, clk);
+    run<12>("v_cndmask_b32", 4, d_out, clk);
+    // field mul throughput
+    {
+        const int blocks = 256 * 8, threads = 256, iters = 2000;
+        cg::Fq* io; CHECK(hipMalloc(&io, sizeof(cg::Fq) * blocks * threads * 2));
+        std::vector<cg::Fq> h(blocks * threads * 2);
+        for (size_t i = 0; i < h.size(); ++i) for (int k = 0; k < 8; ++k) h[i].l[k] = (uint32_t)(i * 2654435761u + k * 40503u) & (k == 7 ? 0x1fffffffu : 0xffffffffu);
+        CHECK(hipMemcpy(io, h.data(), sizeof(cg::Fq) * h.size(), hipMemcpyHostToDevice));
+        hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        k_fpmul<cg::Fq><<<blocks, threads>>>(io, 10);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0));
+        k_fpmul<cg::Fq><<<blocks, threads>>>(io, iters);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        double muls = (double)blocks * threads * iters * 4;
+        printf("Fq mont mul: %.3f ms, %.2f G mul/s  (%.1f cycles/wave-mul/SIMD)\n", ms, muls / (ms * 1e-3) / 1e9,
+               clk / (muls / 64 / (ms * 1e-3) / 1024));
+    }
+    return 0;
+}
