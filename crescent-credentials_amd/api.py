@@ -57,7 +57,10 @@ class CgTimings(C.Structure):
     _fields_ = [("upload_ms", C.c_float), ("witness_map_ms", C.c_float), ("msm_h_ms", C.c_float),
                 ("msm_l_ms", C.c_float), ("msm_a_ms", C.c_float), ("msm_b1_ms", C.c_float),
                 ("msm_b2_ms", C.c_float), ("finish_ms", C.c_float), ("total_ms", C.c_float),
-                ("msm_g1_pairs", C.c_uint64), ("msm_g2_pairs", C.c_uint64)]
+                ("msm_g1_pairs", C.c_uint64), ("msm_g2_pairs", C.c_uint64),
+                ("accum_g1_ms", C.c_float), ("accum_g2_ms", C.c_float), ("sort_ms", C.c_float), ("reserved_ms", C.c_float),
+                ("entries_g1", C.c_uint64), ("entries_g2", C.c_uint64),
+                ("accum_g1_launches", C.c_uint32), ("accum_g2_launches", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

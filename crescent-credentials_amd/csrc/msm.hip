@@ -395,11 +395,23 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
     h_count.alloc(1);
     h_result.alloc(wins);
     CG_HIP(hipEventCreateWithFlags(&ev_count, hipEventDisableTiming));
+    for (auto& e : ev_t) CG_HIP(hipEventCreate(&e));
 }
+
+template <class F>
+static float elapsed(hipEvent_t a, hipEvent_t b) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0.f;
+    return ms;
+}
+template <class F> float MsmEngine<F>::ms_total() const { return elapsed<F>(ev_t[0], ev_t[5]); }
+template <class F> float MsmEngine<F>::ms_sort() const { return n_entries ? elapsed<F>(ev_t[1], ev_t[2]) : 0.f; }
+template <class F> float MsmEngine<F>::ms_accum() const { return n_entries ? elapsed<F>(ev_t[3], ev_t[4]) : 0.f; }
 
 template <class F>
 MsmEngine<F>::~MsmEngine() {
     if (ev_count) (void)hipEventDestroy(ev_count);
+    for (auto& e : ev_t) if (e) (void)hipEventDestroy(e);
 }
 
 template <class F>
@@ -407,6 +419,7 @@ void MsmEngine<F>::digits(const Fr* scalars_dev, uint64_t n, hipStream_t st) {
     if (n > bases->n) n = bases->n;  // msm_bigint zips and truncates to the shorter operand
     n_scalars = n;
     h_count.p[0] = 0;
+    CG_HIP(hipEventRecord(ev_t[0], st));
     if (!n) return;
     const int c = bases->c, W = bases->W;
     k_digit_count<<<ceil_div(n, 256), 256, 0, st>>>(scalars_dev, bases->valid.p, n, c, W, thread_counts.p);
@@ -436,14 +449,18 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
         if (!bases->precomputed) key_bits += ilog2_ceil((uint64_t)bases->W);
         if (key_bits < 1) key_bits = 1;
         size_t tmp = sort_tmp_bytes;
+        CG_HIP(hipEventRecord(ev_t[1], st));
         CG_HIP(rocprim::radix_sort_pairs(sort_tmp.p, tmp, keys_a.p, keys_b.p, vals_a.p, vals_b.p, (size_t)N, 0u,
                                          (unsigned)key_bits, st));
+        CG_HIP(hipEventRecord(ev_t[2], st));
         // level 1
         uint32_t L = level1_L(N);
         uint32_t T = ceil_div(N, L);
+        CG_HIP(hipEventRecord(ev_t[3], st));
         k_accum_affine<F><<<ceil_div(T, 256), 256, 0, st>>>(keys_b.p, vals_b.p, N, L, T, bases->table.p, bucket_sums.p,
                                                             part_keys_a.p, part_pts_a.p);
         CG_KERNEL_CHECK();
+        CG_HIP(hipEventRecord(ev_t[4], st));
         // combine partials until one lane covers everything
         bool from_a = true;
         uint32_t count = (T == 1) ? 0 : 2 * T;
@@ -480,6 +497,7 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
         XYZZ<F>* tswap = src; src = dst; dst = tswap;
     }
     CG_HIP(hipMemcpyAsync(h_result.p, result.p, wins * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+    CG_HIP(hipEventRecord(ev_t[5], st));
 }
 
 template <class F>

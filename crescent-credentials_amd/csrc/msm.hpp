@@ -45,6 +45,12 @@ struct MsmEngine {
     uint64_t n_scalars = 0;
     uint32_t n_entries = 0;
     hipEvent_t ev_count = nullptr;
+    // timing events (recorded on the MSM's own stream): digits start, sort begin/end, level-1
+    // accumulation kernel begin/end, result ready
+    hipEvent_t ev_t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    float ms_total() const;   // digits start -> result ready (valid after the stream is synchronised)
+    float ms_sort() const;
+    float ms_accum() const;
 
     void init(const MsmBases<F>* b);
     ~MsmEngine();

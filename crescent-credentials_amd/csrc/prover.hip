@@ -332,8 +332,18 @@ static int prove_partial_impl(cg_ctx* c, const void* assignment, bool on_device,
         memset(tm, 0, sizeof(*tm));
         tm->upload_ms = upload_ms;
         tm->witness_map_ms = ev_ms(c->ev_t[0], c->ev_t[1]);
-        tm->msm_h_ms = ev_ms(c->ev_t[1], c->ev_t[4]);
-        tm->msm_l_ms = ev_ms(c->ev_t[2], c->ev_t[3]);
+        tm->msm_h_ms = c->eh.ms_total();
+        tm->msm_l_ms = c->el.ms_total();
+        tm->msm_a_ms = c->ea.ms_total();
+        tm->msm_b1_ms = skip_b1 ? 0.f : c->eb1.ms_total();
+        tm->msm_b2_ms = c->eb2.ms_total();
+        tm->accum_g1_ms = c->eh.ms_accum() + c->el.ms_accum() + c->ea.ms_accum() + (skip_b1 ? 0.f : c->eb1.ms_accum());
+        tm->accum_g2_ms = c->eb2.ms_accum();
+        tm->sort_ms = c->eh.ms_sort() + c->el.ms_sort() + c->ea.ms_sort() + (skip_b1 ? 0.f : c->eb1.ms_sort()) + c->eb2.ms_sort();
+        tm->entries_g1 = (uint64_t)c->eh.n_entries + c->el.n_entries + c->ea.n_entries + (skip_b1 ? 0 : c->eb1.n_entries);
+        tm->entries_g2 = c->eb2.n_entries;
+        tm->accum_g1_launches = (c->eh.n_entries != 0) + (c->el.n_entries != 0) + (c->ea.n_entries != 0) + (!skip_b1 && c->eb1.n_entries != 0);
+        tm->accum_g2_launches = c->eb2.n_entries != 0;
         tm->msm_g1_pairs = c->eh.n_scalars + c->el.n_scalars + c->ea.n_scalars + (skip_b1 ? 0 : c->eb1.n_scalars);
         tm->msm_g2_pairs = c->eb2.n_scalars;
         tm->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();

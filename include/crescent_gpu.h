@@ -106,6 +106,15 @@ typedef struct cg_timings {
     float total_ms;        /* "Groth16::Prover" */
     uint64_t msm_g1_pairs; /* (base, scalar) pairs consumed by the four G1 MSMs */
     uint64_t msm_g2_pairs;
+    /* HIP-event durations of the dominant kernels, summed over this proof's launches */
+    float accum_g1_ms;     /* bucket-accumulation kernel (k_accum_affine<Fq>), the four G1 MSMs */
+    float accum_g2_ms;     /* same kernel over Fq2 (the G2 MSM) */
+    float sort_ms;         /* radix sorts of the digit entries, all five MSMs */
+    float reserved_ms;
+    uint64_t entries_g1;   /* non-zero signed digits (= mixed additions) accumulated, G1 */
+    uint64_t entries_g2;
+    uint32_t accum_g1_launches;
+    uint32_t accum_g2_launches;
 } cg_timings;
 
 /* Process-wide initialisation: checks that a HIP device is present.

@@ -1,0 +1,622 @@
+/*
+ * cpu_ref.c — CPU restatement (plain C, gcc) of the reference's Groth16 prove path, BN254.
+ *
+ * THIS FILE IS TEST INFRASTRUCTURE: the checker for tests/ and the `cpu_baseline` leg of bench.py.
+ * The product (crescent-credentials_amd/) never links, loads or calls it.
+ *
+ * PARITY STATUS: "parity unpinned" for proof bytes — the reference (Rust over un-vendored crates.io
+ * arkworks ^0.4, no Cargo.lock, no rustc here) can be neither built nor run, and its tests pin no
+ * proof bytes (forks/groth16/src/test.rs:70-71, creds/src/lib.rs:288-290).  This file is pinned
+ * instead (tests/test_cpu_ref.py) against the pure-Python oracle's golden vectors, which are in turn
+ * pinned against the reference's encoding KATs and accepted by its verification equation.
+ *
+ * It follows the ALGORITHMS arkworks uses on this path, so that it can stand in as the timed
+ * "arkworks-equivalent" baseline (never labelled "arkworks"):
+ *   - prove:        forks/groth16/src/prover.rs:26-136,256-274
+ *   - witness map:  forks/groth16/src/r1cs_to_qap.rs:16-45,150-213
+ *   - MSM:          ark-ec 0.4 VariableBaseMSM::msm_bigint [ark-mem]: window c = 3 if n < 32 else
+ *                   ln(n)+2 with ln(n) ~ log2(n)*69/100, unsigned c-bit digits, 2^c - 1 Jacobian
+ *                   buckets per window filled by mixed additions, zero scalars skipped and unit
+ *                   scalars added directly in window 0, running-sum bucket reduction, ONE task per
+ *                   window (that is all the parallelism arkworks' MSM has), windows folded with c
+ *                   doublings each.
+ *   - NTT:          radix-2 in-order transforms, ω = 5^((r-1)/2^k), coset offset g = 5
+ *                   (call sites r1cs_to_qap.rs:179-185,198-199,210), loops split across threads.
+ *   - field:        4 x 64-bit-limb Montgomery (R = 2^256), the representation arkworks uses.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <omp.h>
+
+typedef unsigned __int128 u128;
+typedef struct { uint64_t l[4]; } fe;            /* field element, Montgomery form */
+typedef struct { const uint64_t n[4]; uint64_t ninv; fe one; fe r2; } field_t;
+
+static const field_t FQ = {
+    {0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull},
+    0x87d20782e4866389ull,
+    {{0xd35d438dc58f0d9dull, 0x0a78eb28f5c70b3dull, 0x666ea36f7879462cull, 0x0e0a77c19a07df2full}},
+    {{0xf32cfc5b538afa89ull, 0xb5e71911d44501fbull, 0x47ab1eff0a417ff6ull, 0x06d89f71cab8351full}}};
+static const field_t FR = {
+    {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull},
+    0xc2e1f593efffffffull,
+    {{0xac96341c4ffffffbull, 0x36fc76959f60cd29ull, 0x666ea36f7879462eull, 0x0e0a77c19a07df2full}},
+    {{0x1bb8e645ae216da7ull, 0x53fe3ab1e35c59e3ull, 0x8c49833d53bb8085ull, 0x0216d0b17f4e44a5ull}}};
+
+static inline int fe_is_zero(const fe* a) { return (a->l[0] | a->l[1] | a->l[2] | a->l[3]) == 0; }
+static inline int fe_eq(const fe* a, const fe* b) {
+    return ((a->l[0] ^ b->l[0]) | (a->l[1] ^ b->l[1]) | (a->l[2] ^ b->l[2]) | (a->l[3] ^ b->l[3])) == 0;
+}
+static inline int ge_mod(const uint64_t a[4], const uint64_t n[4]) {
+    for (int i = 3; i >= 0; --i) {
+        if (a[i] > n[i]) return 1;
+        if (a[i] < n[i]) return 0;
+    }
+    return 1;
+}
+static inline void sub_mod_raw(uint64_t a[4], const uint64_t n[4]) {
+    u128 br = 0;
+    for (int i = 0; i < 4; ++i) {
+        u128 d = (u128)a[i] - n[i] - (uint64_t)br;
+        a[i] = (uint64_t)d;
+        br = (d >> 64) & 1;
+    }
+}
+static inline void fe_add(const field_t* F, fe* r, const fe* a, const fe* b) {
+    u128 c = 0;
+    for (int i = 0; i < 4; ++i) {
+        c += (u128)a->l[i] + b->l[i];
+        r->l[i] = (uint64_t)c;
+        c >>= 64;
+    }
+    if (ge_mod(r->l, F->n)) sub_mod_raw(r->l, F->n);
+}
+static inline void fe_sub(const field_t* F, fe* r, const fe* a, const fe* b) {
+    u128 br = 0;
+    uint64_t t[4];
+    for (int i = 0; i < 4; ++i) {
+        u128 d = (u128)a->l[i] - b->l[i] - (uint64_t)br;
+        t[i] = (uint64_t)d;
+        br = (d >> 64) & 1;
+    }
+    if (br) {
+        u128 c = 0;
+        for (int i = 0; i < 4; ++i) {
+            c += (u128)t[i] + F->n[i];
+            t[i] = (uint64_t)c;
+            c >>= 64;
+        }
+    }
+    memcpy(r->l, t, 32);
+}
+static inline void fe_neg(const field_t* F, fe* r, const fe* a) {
+    fe z = {{0, 0, 0, 0}};
+    fe_sub(F, r, &z, a);
+}
+static inline void fe_dbl(const field_t* F, fe* r, const fe* a) { fe_add(F, r, a, a); }
+/* Montgomery multiplication, coarsely integrated operand scanning */
+static void fe_mul(const field_t* F, fe* r, const fe* a, const fe* b) {
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) {
+        u128 c = 0;
+        for (int j = 0; j < 4; ++j) {
+            c += (u128)a->l[j] * b->l[i] + t[j];
+            t[j] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[4] = (uint64_t)c;
+        t[5] = (uint64_t)(c >> 64);
+        uint64_t m = t[0] * F->ninv;
+        c = (u128)m * F->n[0] + t[0];
+        c >>= 64;
+        for (int j = 1; j < 4; ++j) {
+            c += (u128)m * F->n[j] + t[j];
+            t[j - 1] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[3] = (uint64_t)c;
+        t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    if (t[4] || ge_mod(t, F->n)) sub_mod_raw(t, F->n);
+    memcpy(r->l, t, 32);
+}
+static inline void fe_sqr(const field_t* F, fe* r, const fe* a) { fe_mul(F, r, a, a); }
+static void fe_pow(const field_t* F, fe* r, const fe* a, const uint64_t e[4]) {
+    fe acc = F->one;
+    for (int i = 3; i >= 0; --i)
+        for (int b = 63; b >= 0; --b) {
+            fe_sqr(F, &acc, &acc);
+            if ((e[i] >> b) & 1) fe_mul(F, &acc, &acc, a);
+        }
+    *r = acc;
+}
+static void fe_inv(const field_t* F, fe* r, const fe* a) {
+    uint64_t e[4] = {F->n[0] - 2, F->n[1], F->n[2], F->n[3]};
+    fe_pow(F, r, a, e);
+}
+static void fe_from_canonical(const field_t* F, fe* r, const uint8_t b[32]) {
+    fe t;
+    memcpy(t.l, b, 32);
+    fe_mul(F, r, &t, &F->r2);
+}
+static void fe_to_canonical(const field_t* F, uint8_t b[32], const fe* a) {
+    fe one = {{1, 0, 0, 0}}, t;
+    fe_mul(F, &t, a, &one);
+    memcpy(b, t.l, 32);
+}
+static void fe_from_u64(const field_t* F, fe* r, uint64_t v) {
+    fe t = {{v, 0, 0, 0}};
+    fe_mul(F, r, &t, &F->r2);
+}
+
+/* ---- Fq2 = Fq[u]/(u^2+1) --------------------------------------------------------------------- */
+typedef struct { fe c0, c1; } fe2;
+static inline int fe2_is_zero(const fe2* a) { return fe_is_zero(&a->c0) && fe_is_zero(&a->c1); }
+static inline void fe2_add(fe2* r, const fe2* a, const fe2* b) { fe_add(&FQ, &r->c0, &a->c0, &b->c0); fe_add(&FQ, &r->c1, &a->c1, &b->c1); }
+static inline void fe2_sub(fe2* r, const fe2* a, const fe2* b) { fe_sub(&FQ, &r->c0, &a->c0, &b->c0); fe_sub(&FQ, &r->c1, &a->c1, &b->c1); }
+static inline void fe2_neg(fe2* r, const fe2* a) { fe_neg(&FQ, &r->c0, &a->c0); fe_neg(&FQ, &r->c1, &a->c1); }
+static void fe2_mul(fe2* r, const fe2* a, const fe2* b) {
+    fe v0, v1, s, t, u;
+    fe_mul(&FQ, &v0, &a->c0, &b->c0);
+    fe_mul(&FQ, &v1, &a->c1, &b->c1);
+    fe_add(&FQ, &s, &a->c0, &a->c1);
+    fe_add(&FQ, &t, &b->c0, &b->c1);
+    fe_mul(&FQ, &u, &s, &t);
+    fe_sub(&FQ, &u, &u, &v0);
+    fe_sub(&FQ, &r->c1, &u, &v1);
+    fe_sub(&FQ, &r->c0, &v0, &v1);
+}
+static void fe2_sqr(fe2* r, const fe2* a) { fe2 t = *a; fe2_mul(r, &t, &t); }
+static void fe2_inv(fe2* r, const fe2* a) {
+    fe n0, n1, n;
+    fe_sqr(&FQ, &n0, &a->c0);
+    fe_sqr(&FQ, &n1, &a->c1);
+    fe_add(&FQ, &n, &n0, &n1);
+    fe_inv(&FQ, &n, &n);
+    fe_mul(&FQ, &r->c0, &a->c0, &n);
+    fe_mul(&FQ, &n0, &a->c1, &n);
+    fe_neg(&FQ, &r->c1, &n0);
+}
+
+/* ---- Jacobian group arithmetic, generated for both coordinate fields ----------------------------
+ * arkworks' short_weierstrass::Projective is Jacobian; formulas: dbl-2009-l, add-2007-bl, madd-2007-bl. */
+#define DEFINE_GROUP(SUF, T, ADD, SUB, MUL, SQR, ISZ, INV, NEG)                                            \
+    typedef struct { T x, y; int inf; } aff##SUF;                                                         \
+    typedef struct { T x, y, z; } jac##SUF; /* z == 0 <=> infinity */                                      \
+    static void jac##SUF##_set_inf(jac##SUF* p) { memset(p, 0, sizeof(*p)); }                             \
+    static int jac##SUF##_is_inf(const jac##SUF* p) { return ISZ(&p->z); }                                \
+    static void jac##SUF##_dbl(jac##SUF* r, const jac##SUF* p) {                                          \
+        if (ISZ(&p->z)) { *r = *p; return; }                                                              \
+        T a, b, c, d, e, f, t, x3, y3, z3;                                                                 \
+        SQR(&a, &p->x); SQR(&b, &p->y); SQR(&c, &b);                                                       \
+        ADD(&t, &p->x, &b); SQR(&t, &t); SUB(&t, &t, &a); SUB(&t, &t, &c); ADD(&d, &t, &t);                \
+        ADD(&e, &a, &a); ADD(&e, &e, &a); SQR(&f, &e);                                                     \
+        SUB(&x3, &f, &d); SUB(&x3, &x3, &d);                                                               \
+        SUB(&t, &d, &x3); MUL(&y3, &e, &t); ADD(&c, &c, &c); ADD(&c, &c, &c); ADD(&c, &c, &c); SUB(&y3, &y3, &c); \
+        MUL(&z3, &p->y, &p->z); ADD(&z3, &z3, &z3);                                                        \
+        r->x = x3; r->y = y3; r->z = z3;                                                                   \
+    }                                                                                                      \
+    static void jac##SUF##_add(jac##SUF* r, const jac##SUF* p, const jac##SUF* q) {                       \
+        if (ISZ(&p->z)) { *r = *q; return; }                                                              \
+        if (ISZ(&q->z)) { *r = *p; return; }                                                              \
+        T z1z1, z2z2, u1, u2, s1, s2, h, i, j, rr, v, t, x3, y3, z3;                                        \
+        SQR(&z1z1, &p->z); SQR(&z2z2, &q->z);                                                              \
+        MUL(&u1, &p->x, &z2z2); MUL(&u2, &q->x, &z1z1);                                                    \
+        MUL(&s1, &p->y, &q->z); MUL(&s1, &s1, &z2z2);                                                      \
+        MUL(&s2, &q->y, &p->z); MUL(&s2, &s2, &z1z1);                                                      \
+        SUB(&h, &u2, &u1); SUB(&rr, &s2, &s1);                                                             \
+        if (ISZ(&h)) { if (ISZ(&rr)) jac##SUF##_dbl(r, p); else jac##SUF##_set_inf(r); return; }           \
+        ADD(&i, &h, &h); SQR(&i, &i); MUL(&j, &h, &i); ADD(&rr, &rr, &rr); MUL(&v, &u1, &i);                \
+        SQR(&x3, &rr); SUB(&x3, &x3, &j); SUB(&x3, &x3, &v); SUB(&x3, &x3, &v);                            \
+        SUB(&t, &v, &x3); MUL(&y3, &rr, &t); MUL(&t, &s1, &j); ADD(&t, &t, &t); SUB(&y3, &y3, &t);          \
+        ADD(&z3, &p->z, &q->z); SQR(&z3, &z3); SUB(&z3, &z3, &z1z1); SUB(&z3, &z3, &z2z2); MUL(&z3, &z3, &h); \
+        r->x = x3; r->y = y3; r->z = z3;                                                                   \
+    }                                                                                                      \
+    static void jac##SUF##_madd(jac##SUF* r, const jac##SUF* p, const aff##SUF* q, const T* one) {        \
+        if (q->inf) { *r = *p; return; }                                                                  \
+        if (ISZ(&p->z)) { r->x = q->x; r->y = q->y; r->z = *one; return; }                                 \
+        T z1z1, u2, s2, h, hh, i, j, rr, v, t, x3, y3, z3;                                                  \
+        SQR(&z1z1, &p->z); MUL(&u2, &q->x, &z1z1); MUL(&s2, &q->y, &p->z); MUL(&s2, &s2, &z1z1);            \
+        SUB(&h, &u2, &p->x); SUB(&rr, &s2, &p->y);                                                         \
+        if (ISZ(&h)) { if (ISZ(&rr)) jac##SUF##_dbl(r, p); else jac##SUF##_set_inf(r); return; }           \
+        SQR(&hh, &h); ADD(&i, &hh, &hh); ADD(&i, &i, &i); MUL(&j, &h, &i); ADD(&rr, &rr, &rr); MUL(&v, &p->x, &i); \
+        SQR(&x3, &rr); SUB(&x3, &x3, &j); SUB(&x3, &x3, &v); SUB(&x3, &x3, &v);                            \
+        SUB(&t, &v, &x3); MUL(&y3, &rr, &t); MUL(&t, &p->y, &j); ADD(&t, &t, &t); SUB(&y3, &y3, &t);        \
+        ADD(&z3, &p->z, &h); SQR(&z3, &z3); SUB(&z3, &z3, &z1z1); SUB(&z3, &z3, &hh);                       \
+        r->x = x3; r->y = y3; r->z = z3;                                                                   \
+    }                                                                                                      \
+    static void jac##SUF##_neg(jac##SUF* r, const jac##SUF* p) { *r = *p; NEG(&r->y, &p->y); }             \
+    static void jac##SUF##_to_affine(aff##SUF* r, const jac##SUF* p) {                                    \
+        if (ISZ(&p->z)) { memset(r, 0, sizeof(*r)); r->inf = 1; return; }                                  \
+        T zi, zi2, zi3;                                                                                    \
+        INV(&zi, &p->z); SQR(&zi2, &zi); MUL(&zi3, &zi2, &zi);                                             \
+        MUL(&r->x, &p->x, &zi2); MUL(&r->y, &p->y, &zi3); r->inf = 0;                                      \
+    }                                                                                                      \
+    /* k * p, k a 256-bit little-endian integer, MSB-first double-and-add (mul_bigint) */                  \
+    static void jac##SUF##_mul(jac##SUF* r, const jac##SUF* p, const uint64_t k[4]) {                     \
+        jac##SUF acc; jac##SUF##_set_inf(&acc);                                                            \
+        for (int i = 3; i >= 0; --i) for (int b = 63; b >= 0; --b) {                                       \
+            jac##SUF##_dbl(&acc, &acc);                                                                    \
+            if ((k[i] >> b) & 1) jac##SUF##_add(&acc, &acc, p);                                            \
+        }                                                                                                  \
+        *r = acc;                                                                                          \
+    }
+
+static inline void q_add(fe* r, const fe* a, const fe* b) { fe_add(&FQ, r, a, b); }
+static inline void q_sub(fe* r, const fe* a, const fe* b) { fe_sub(&FQ, r, a, b); }
+static inline void q_mul(fe* r, const fe* a, const fe* b) { fe_mul(&FQ, r, a, b); }
+static inline void q_sqr(fe* r, const fe* a) { fe_sqr(&FQ, r, a); }
+static inline void q_inv(fe* r, const fe* a) { fe_inv(&FQ, r, a); }
+static inline void q_neg(fe* r, const fe* a) { fe_neg(&FQ, r, a); }
+DEFINE_GROUP(1, fe, q_add, q_sub, q_mul, q_sqr, fe_is_zero, q_inv, q_neg)
+DEFINE_GROUP(2, fe2, fe2_add, fe2_sub, fe2_mul, fe2_sqr, fe2_is_zero, fe2_inv, fe2_neg)
+
+static const fe2* fe2_one(void) {
+    static fe2 o;
+    o.c0 = FQ.one;
+    memset(&o.c1, 0, sizeof(fe));
+    return &o;
+}
+
+/* packed canonical bytes <-> affine (identity = all zero, include/crescent_gpu.h conventions) */
+static int all_zero(const uint8_t* b, int n) { for (int i = 0; i < n; ++i) if (b[i]) return 0; return 1; }
+static void aff1_load(aff1* p, const uint8_t b[64]) {
+    if (all_zero(b, 64)) { memset(p, 0, sizeof(*p)); p->inf = 1; return; }
+    fe_from_canonical(&FQ, &p->x, b); fe_from_canonical(&FQ, &p->y, b + 32); p->inf = 0;
+}
+static void aff2_load(aff2* p, const uint8_t b[128]) {
+    if (all_zero(b, 128)) { memset(p, 0, sizeof(*p)); p->inf = 1; return; }
+    fe_from_canonical(&FQ, &p->x.c0, b); fe_from_canonical(&FQ, &p->x.c1, b + 32);
+    fe_from_canonical(&FQ, &p->y.c0, b + 64); fe_from_canonical(&FQ, &p->y.c1, b + 96); p->inf = 0;
+}
+static void aff1_store(uint8_t b[64], const aff1* p) {
+    if (p->inf) { memset(b, 0, 64); return; }
+    fe_to_canonical(&FQ, b, &p->x); fe_to_canonical(&FQ, b + 32, &p->y);
+}
+static void aff2_store(uint8_t b[128], const aff2* p) {
+    if (p->inf) { memset(b, 0, 128); return; }
+    fe_to_canonical(&FQ, b, &p->x.c0); fe_to_canonical(&FQ, b + 32, &p->x.c1);
+    fe_to_canonical(&FQ, b + 64, &p->y.c0); fe_to_canonical(&FQ, b + 96, &p->y.c1);
+}
+
+/* ---- Pippenger, as ark-ec 0.4 msm_bigint [ark-mem] ------------------------------------------- */
+static int ln_without_floats(uint64_t a) {  /* log2(a) * 69 / 100 */
+    int lg = 0;
+    while ((1ull << (lg + 1)) <= a && lg < 62) ++lg;
+    return lg * 69 / 100;
+}
+static inline int big_is_zero(const uint64_t s[4]) { return (s[0] | s[1] | s[2] | s[3]) == 0; }
+static inline int big_is_one(const uint64_t s[4]) { return s[0] == 1 && (s[1] | s[2] | s[3]) == 0; }
+static inline uint64_t big_window(const uint64_t s[4], int start, int c) {
+    int w = start >> 6, sh = start & 63;
+    uint64_t v = s[w] >> sh;
+    if (sh && w + 1 < 4) v |= s[w + 1] << (64 - sh);
+    return v & ((1ull << c) - 1);
+}
+
+#define DEFINE_MSM(SUF, ONEPTR)                                                                            \
+    static void msm##SUF(jac##SUF* out, const aff##SUF* bases, const uint64_t (*scalars)[4], uint64_t n, int nthreads) { \
+        jac##SUF##_set_inf(out);                                                                           \
+        if (n == 0) return;                                                                                \
+        const int c = n < 32 ? 3 : ln_without_floats(n) + 2;                                               \
+        const int num_bits = 254;                                                                          \
+        const int nwin = (num_bits + c - 1) / c;                                                           \
+        jac##SUF* sums = (jac##SUF*)malloc(sizeof(jac##SUF) * nwin);                                       \
+        _Pragma("omp parallel for schedule(dynamic, 1) num_threads(nthreads)")                             \
+        for (int w = 0; w < nwin; ++w) {                                                                   \
+            const int start = w * c;                                                                       \
+            const uint64_t nb = (1ull << c) - 1;                                                           \
+            jac##SUF* buckets = (jac##SUF*)calloc(nb, sizeof(jac##SUF));                                    \
+            jac##SUF res; jac##SUF##_set_inf(&res);                                                        \
+            for (uint64_t i = 0; i < n; ++i) {                                                             \
+                const uint64_t* s = scalars[i];                                                            \
+                if (big_is_zero(s)) continue;                                                              \
+                if (big_is_one(s)) { if (start == 0) jac##SUF##_madd(&res, &res, &bases[i], ONEPTR); continue; } \
+                uint64_t d = big_window(s, start, c);                                                      \
+                if (d) jac##SUF##_madd(&buckets[d - 1], &buckets[d - 1], &bases[i], ONEPTR);               \
+            }                                                                                              \
+            jac##SUF run; jac##SUF##_set_inf(&run);                                                        \
+            for (uint64_t b = nb; b-- > 0;) {                                                              \
+                jac##SUF##_add(&run, &run, &buckets[b]);                                                   \
+                jac##SUF##_add(&res, &res, &run);                                                          \
+            }                                                                                              \
+            sums[w] = res;                                                                                 \
+            free(buckets);                                                                                 \
+        }                                                                                                  \
+        jac##SUF total; jac##SUF##_set_inf(&total);                                                        \
+        for (int w = nwin - 1; w >= 1; --w) {                                                              \
+            jac##SUF##_add(&total, &total, &sums[w]);                                                      \
+            for (int k = 0; k < c; ++k) jac##SUF##_dbl(&total, &total);                                    \
+        }                                                                                                  \
+        jac##SUF##_add(out, &total, &sums[0]);                                                             \
+        free(sums);                                                                                        \
+    }
+DEFINE_MSM(1, &FQ.one)
+DEFINE_MSM(2, fe2_one())
+
+/* ---- radix-2 NTT over Fr (ark-poly Radix2EvaluationDomain semantics) --------------------------- */
+static void fr_root_of_unity(fe* w, int logn) {
+    /* 5^((r-1)/2^28) squared down to order 2^logn */
+    uint64_t e[4], nm1[4] = {FR.n[0] - 1, FR.n[1], FR.n[2], FR.n[3]};
+    for (int i = 0; i < 4; ++i) e[i] = (nm1[i] >> 28) | (i + 1 < 4 ? nm1[i + 1] << 36 : 0);
+    fe g;
+    fe_from_u64(&FR, &g, 5);
+    fe_pow(&FR, w, &g, e);
+    for (int i = 28; i > logn; --i) fe_sqr(&FR, w, w);
+}
+static uint64_t bitrev(uint64_t x, int bits) {
+    uint64_t r = 0;
+    for (int i = 0; i < bits; ++i) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+}
+/* in place, natural order in and out: a[k] <- Σ_j a[j] w^{jk} */
+static void ntt_inplace(fe* a, int logn, const fe* w, int nthreads) {
+    const uint64_t n = 1ull << logn;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint64_t j = bitrev(i, logn);
+        if (i < j) { fe t = a[i]; a[i] = a[j]; a[j] = t; }
+    }
+    fe* tw = (fe*)malloc(sizeof(fe) * (n > 1 ? n / 2 : 1));
+    tw[0] = FR.one;
+    for (uint64_t i = 1; i < n / 2; ++i) fe_mul(&FR, &tw[i], &tw[i - 1], w);
+    for (int s = 1; s <= logn; ++s) {
+        const uint64_t len = 1ull << s, half = len >> 1, step = n / len;
+        _Pragma("omp parallel for schedule(static) num_threads(nthreads)")
+        for (uint64_t b = 0; b < n / 2; ++b) {
+            uint64_t blk = b / half, k = b % half;
+            uint64_t i0 = blk * len + k, i1 = i0 + half;
+            fe v, u = a[i0];
+            fe_mul(&FR, &v, &a[i1], &tw[k * step]);
+            fe_add(&FR, &a[i0], &u, &v);
+            fe_sub(&FR, &a[i1], &u, &v);
+        }
+    }
+    free(tw);
+}
+typedef struct { int logn; uint64_t n; fe w, winv, ninv, g, ginv; } domain_t;
+static void domain_init(domain_t* d, int logn) {
+    d->logn = logn; d->n = 1ull << logn;
+    fr_root_of_unity(&d->w, logn);
+    fe_inv(&FR, &d->winv, &d->w);
+    fe nn; fe_from_u64(&FR, &nn, d->n); fe_inv(&FR, &d->ninv, &nn);
+    fe_from_u64(&FR, &d->g, 5);                       /* F::GENERATOR (r1cs_to_qap.rs:182) */
+    fe_inv(&FR, &d->ginv, &d->g);
+}
+static void scale_powers(fe* a, uint64_t n, const fe* base, const fe* scale0, int nthreads) {
+    /* a[i] *= scale0 * base^i, split in chunks with an independent power start per chunk */
+    _Pragma("omp parallel num_threads(nthreads)")
+    {
+        int t = omp_get_thread_num(), T = omp_get_num_threads();
+        uint64_t lo = n * t / T, hi = n * (t + 1) / T;
+        uint64_t e[4] = {lo, 0, 0, 0};
+        fe p; fe_pow(&FR, &p, base, e); fe_mul(&FR, &p, &p, scale0);
+        for (uint64_t i = lo; i < hi; ++i) { fe_mul(&FR, &a[i], &a[i], &p); fe_mul(&FR, &p, &p, base); }
+    }
+}
+static void dom_fft(const domain_t* d, fe* a, int coset, int nt) {
+    if (coset) scale_powers(a, d->n, &d->g, &FR.one, nt);      /* coset_domain.fft_in_place */
+    ntt_inplace(a, d->logn, &d->w, nt);
+}
+static void dom_ifft(const domain_t* d, fe* a, int coset, int nt) {
+    ntt_inplace(a, d->logn, &d->winv, nt);
+    fe one = FR.one;
+    scale_powers(a, d->n, coset ? &d->ginv : &one, &d->ninv, nt);  /* x 1/n, and g^-i for the coset */
+}
+
+/* ---- witness map (r1cs_to_qap.rs:16-45,150-213) ----------------------------------------------- */
+typedef struct { const uint64_t* row_ptr; const uint32_t* col; const uint8_t* coeff; uint64_t nnz; } csr_t;
+
+static void spmv(const csr_t* m, uint64_t rows, const fe* w, fe* out, int nt) {
+    _Pragma("omp parallel for schedule(static, 1024) num_threads(nt)")
+    for (uint64_t i = 0; i < rows; ++i) {
+        fe acc = {{0, 0, 0, 0}};
+        for (uint64_t t = m->row_ptr[i]; t < m->row_ptr[i + 1]; ++t) {
+            const uint8_t* cb = m->coeff + 32 * t;
+            fe v = w[m->col[t]];
+            int is_one = cb[0] == 1 && all_zero(cb + 1, 31);          /* coeff.is_one() shortcut :31-35 */
+            if (!is_one) { fe c; fe_from_canonical(&FR, &c, cb); fe_mul(&FR, &v, &v, &c); }
+            fe_add(&FR, &acc, &acc, &v);
+        }
+        out[i] = acc;
+    }
+}
+static int ilog2_ceil(uint64_t n) { int l = 0; while ((1ull << l) < n) ++l; return l; }
+
+/* h (Montgomery) of length D; returns D or 0 when the domain is too large */
+static uint64_t witness_map(const csr_t abc[3], uint64_t l, uint64_t m, const fe* w, fe** h_out, int nt) {
+    int logd = ilog2_ceil(m + l);
+    if (logd > 28) return 0;                                       /* PolynomialDegreeTooLarge :156-157 */
+    domain_t d; domain_init(&d, logd);
+    uint64_t D = d.n;
+    fe* a = (fe*)calloc(D, sizeof(fe)); fe* b = (fe*)calloc(D, sizeof(fe)); fe* c = (fe*)calloc(D, sizeof(fe));
+    spmv(&abc[0], m, w, a, nt); spmv(&abc[1], m, w, b, nt);        /* :164-171 */
+    memcpy(a + m, w, l * sizeof(fe));                              /* :173-177 */
+    dom_ifft(&d, a, 0, nt); dom_ifft(&d, b, 0, nt);                /* :179-180 */
+    dom_fft(&d, a, 1, nt); dom_fft(&d, b, 1, nt);                  /* :182-185 */
+    _Pragma("omp parallel for num_threads(nt)")
+    for (uint64_t i = 0; i < D; ++i) fe_mul(&FR, &a[i], &a[i], &b[i]);   /* :187 */
+    spmv(&abc[2], m, w, c, nt);                                    /* :191-196 */
+    dom_ifft(&d, c, 0, nt); dom_fft(&d, c, 1, nt);                 /* :198-199 */
+    fe gn, vinv; uint64_t e[4] = {D, 0, 0, 0};
+    fe_pow(&FR, &gn, &d.g, e); fe_sub(&FR, &gn, &gn, &FR.one); fe_inv(&FR, &vinv, &gn);   /* :201-204 */
+    _Pragma("omp parallel for num_threads(nt)")
+    for (uint64_t i = 0; i < D; ++i) { fe_sub(&FR, &a[i], &a[i], &c[i]); fe_mul(&FR, &a[i], &a[i], &vinv); }   /* :205-208 */
+    dom_ifft(&d, a, 1, nt);                                        /* :210 */
+    free(b); free(c);
+    *h_out = a;
+    return D;
+}
+
+/* ---- ark-serialize uncompressed encodings [ark-mem], isolated ---------------------------------- */
+static int canon_gt(const uint8_t a[32], const uint8_t b[32]) {
+    for (int i = 31; i >= 0; --i) { if (a[i] > b[i]) return 1; if (a[i] < b[i]) return 0; }
+    return 0;
+}
+static void ser_g1(uint8_t out[64], const aff1* p) {
+    if (p->inf) { memset(out, 0, 64); out[63] |= 0x40; return; }
+    aff1_store(out, p);
+    fe ny; uint8_t nb[32];
+    fe_neg(&FQ, &ny, &p->y); fe_to_canonical(&FQ, nb, &ny);
+    if (canon_gt(out + 32, nb)) out[63] |= 0x80;                   /* y > -y */
+}
+static void ser_g2(uint8_t out[128], const aff2* p) {
+    if (p->inf) { memset(out, 0, 128); out[127] |= 0x40; return; }
+    aff2_store(out, p);
+    fe2 ny; uint8_t n0[32], n1[32];
+    fe2_neg(&ny, &p->y); fe_to_canonical(&FQ, n0, &ny.c0); fe_to_canonical(&FQ, n1, &ny.c1);
+    int gt = canon_gt(out + 96, n1) || (!memcmp(out + 96, n1, 32) && canon_gt(out + 64, n0));   /* c1 first, then c0 */
+    if (gt) out[127] |= 0x80;
+}
+
+/* ---- public entry points (ctypes) -------------------------------------------------------------- */
+typedef struct {
+    const uint8_t *alpha_g1, *beta_g1, *delta_g1, *beta_g2, *delta_g2;
+    const uint8_t *a_query, *b_g1_query, *b_g2_query, *h_query, *l_query;   /* canonical packed */
+    uint64_t a_len, b_g1_len, b_g2_len, h_len, l_len;
+} ref_pk;
+typedef struct { double witness_map_s, msm_h_s, msm_l_s, msm_a_s, msm_b1_s, msm_b2_s, load_s, total_s; } ref_timings;
+
+static void load_scalars(uint64_t (*dst)[4], const uint8_t* src, uint64_t n) { memcpy(dst, src, n * 32); }
+
+static void load_g1s(aff1* dst, const uint8_t* src, uint64_t n, int nt) {
+    _Pragma("omp parallel for num_threads(nt)")
+    for (uint64_t i = 0; i < n; ++i) aff1_load(&dst[i], src + 64 * i);
+}
+static void load_g2s(aff2* dst, const uint8_t* src, uint64_t n, int nt) {
+    _Pragma("omp parallel for num_threads(nt)")
+    for (uint64_t i = 0; i < n; ++i) aff2_load(&dst[i], src + 128 * i);
+}
+
+int ref_num_procs(void) { return omp_get_num_procs(); }
+
+/* Σ s_i P_i over G1 / G2; result packed canonical affine */
+int ref_msm_g1(const uint8_t* bases, const uint8_t* scalars, uint64_t n, uint8_t out[64], int nthreads) {
+    aff1* b = (aff1*)malloc(sizeof(aff1) * (n ? n : 1));
+    load_g1s(b, bases, n, nthreads);
+    jac1 r; msm1(&r, b, (const uint64_t(*)[4])scalars, n, nthreads);
+    aff1 a; jac1_to_affine(&a, &r); aff1_store(out, &a);
+    free(b);
+    return 0;
+}
+int ref_msm_g2(const uint8_t* bases, const uint8_t* scalars, uint64_t n, uint8_t out[128], int nthreads) {
+    aff2* b = (aff2*)malloc(sizeof(aff2) * (n ? n : 1));
+    load_g2s(b, bases, n, nthreads);
+    jac2 r; msm2(&r, b, (const uint64_t(*)[4])scalars, n, nthreads);
+    aff2 a; jac2_to_affine(&a, &r); aff2_store(out, &a);
+    free(b);
+    return 0;
+}
+/* natural-order in-place transform on canonical data */
+int ref_ntt(uint8_t* data, int logn, int inverse, int coset, int nthreads) {
+    if (logn > 28) return -5;
+    domain_t d; domain_init(&d, logn);
+    fe* a = (fe*)malloc(sizeof(fe) * d.n);
+    for (uint64_t i = 0; i < d.n; ++i) fe_from_canonical(&FR, &a[i], data + 32 * i);
+    if (inverse) dom_ifft(&d, a, coset, nthreads); else dom_fft(&d, a, coset, nthreads);
+    for (uint64_t i = 0; i < d.n; ++i) fe_to_canonical(&FR, data + 32 * i, &a[i]);
+    free(a);
+    return 0;
+}
+int ref_witness_map(const csr_t abc[3], uint64_t l, uint64_t m, uint64_t M, const uint8_t* w_bytes, uint8_t* h_out, int nthreads) {
+    fe* w = (fe*)malloc(sizeof(fe) * M);
+    for (uint64_t i = 0; i < M; ++i) fe_from_canonical(&FR, &w[i], w_bytes + 32 * i);
+    fe* h; uint64_t D = witness_map(abc, l, m, w, &h, nthreads);
+    free(w);
+    if (!D) return -5;
+    for (uint64_t i = 0; i < D; ++i) fe_to_canonical(&FR, h_out + 32 * i, &h[i]);
+    free(h);
+    return 0;
+}
+
+/* prover.rs:256-274 */
+static void calculate_coeff1(jac1* res, const jac1* initial, const aff1* query, uint64_t qlen, const aff1* vk_param,
+                             const uint64_t (*assignment)[4], uint64_t alen, int nt) {
+    jac1 acc; uint64_t n = qlen - 1 < alen ? qlen - 1 : alen;
+    msm1(&acc, query + 1, assignment, n, nt);
+    jac1_madd(res, initial, &query[0], &FQ.one);
+    jac1_add(res, res, &acc);
+    jac1_madd(res, res, vk_param, &FQ.one);
+}
+static void calculate_coeff2(jac2* res, const jac2* initial, const aff2* query, uint64_t qlen, const aff2* vk_param,
+                             const uint64_t (*assignment)[4], uint64_t alen, int nt) {
+    jac2 acc; uint64_t n = qlen - 1 < alen ? qlen - 1 : alen;
+    msm2(&acc, query + 1, assignment, n, nt);
+    jac2_madd(res, initial, &query[0], fe2_one());
+    jac2_add(res, res, &acc);
+    jac2_madd(res, res, vk_param, fe2_one());
+}
+
+/* create_proof_with_reduction_and_matrices (prover.rs:26-51) -> 256-byte uncompressed proof.
+ * The key arrives as packed canonical arrays; converting it to Montgomery affine points is the
+ * analogue of deserialising prover_params.bin (creds/src/lib.rs:268) and is timed separately (load_s). */
+int ref_prove(const ref_pk* pk, const csr_t abc[3], uint64_t l, uint64_t m, uint64_t M, const uint8_t* w_bytes,
+              const uint8_t r_b[32], const uint8_t s_b[32], uint8_t proof_out[256], int nthreads, ref_timings* tm) {
+    double t_start = omp_get_wtime();
+    aff1 *aq = (aff1*)malloc(sizeof(aff1) * pk->a_len), *b1q = (aff1*)malloc(sizeof(aff1) * pk->b_g1_len);
+    aff1 *hq = (aff1*)malloc(sizeof(aff1) * pk->h_len), *lq = (aff1*)malloc(sizeof(aff1) * (pk->l_len ? pk->l_len : 1));
+    aff2* b2q = (aff2*)malloc(sizeof(aff2) * pk->b_g2_len);
+    load_g1s(aq, pk->a_query, pk->a_len, nthreads); load_g1s(b1q, pk->b_g1_query, pk->b_g1_len, nthreads);
+    load_g1s(hq, pk->h_query, pk->h_len, nthreads); load_g1s(lq, pk->l_query, pk->l_len, nthreads);
+    load_g2s(b2q, pk->b_g2_query, pk->b_g2_len, nthreads);
+    aff1 alpha_g1, beta_g1, delta_g1; aff2 beta_g2, delta_g2;
+    aff1_load(&alpha_g1, pk->alpha_g1); aff1_load(&beta_g1, pk->beta_g1); aff1_load(&delta_g1, pk->delta_g1);
+    aff2_load(&beta_g2, pk->beta_g2); aff2_load(&delta_g2, pk->delta_g2);
+    fe* w = (fe*)malloc(sizeof(fe) * M);
+    for (uint64_t i = 0; i < M; ++i) fe_from_canonical(&FR, &w[i], w_bytes + 32 * i);
+    double t_loaded = omp_get_wtime();
+
+    /* witness map (prover.rs:37-43) */
+    fe* h; uint64_t D = witness_map(abc, l, m, w, &h, nthreads);
+    if (!D) return -5;
+    double t_wm = omp_get_wtime();
+
+    /* into_bigint (prover.rs:63-65,70-72,84-89) */
+    uint64_t (*h_big)[4] = (uint64_t(*)[4])malloc(32 * D);
+    for (uint64_t i = 0; i < D; ++i) fe_to_canonical(&FR, (uint8_t*)h_big[i], &h[i]);
+    const uint64_t (*w_big)[4] = (const uint64_t(*)[4])w_bytes;   /* canonical scalars as given */
+    uint64_t r[4], s[4];
+    memcpy(r, r_b, 32); memcpy(s, s_b, 32);
+
+    jac1 h_acc, l_aux_acc;
+    msm1(&h_acc, hq, (const uint64_t(*)[4])h_big, pk->h_len < D ? pk->h_len : D, nthreads);   /* :66 (zip truncates) */
+    double t_h = omp_get_wtime();
+    msm1(&l_aux_acc, lq, w_big + l, pk->l_len < M - l ? pk->l_len : M - l, nthreads);           /* :74 */
+    double t_l = omp_get_wtime();
+
+    jac1 d1 = {delta_g1.x, delta_g1.y, FQ.one}, r_g1, rs_delta;
+    jac1_mul(&r_g1, &d1, r);                                       /* :76-80, :94 */
+    jac1_mul(&rs_delta, &r_g1, s);
+    jac1 g_a, s_g_a;
+    calculate_coeff1(&g_a, &r_g1, aq, pk->a_len, &alpha_g1, w_big + 1, M - 1, nthreads);        /* :96 */
+    jac1_mul(&s_g_a, &g_a, s);                                     /* :98 */
+    double t_a = omp_get_wtime();
+    jac1 g1_b; jac1_set_inf(&g1_b);
+    if (!big_is_zero(r)) {                                         /* :102-112 */
+        jac1 s_g1; jac1_mul(&s_g1, &d1, s);
+        calculate_coeff1(&g1_b, &s_g1, b1q, pk->b_g1_len, &beta_g1, w_big + 1, M - 1, nthreads);
+    }
+    double t_b1 = omp_get_wtime();
+    jac2 d2 = {delta_g2.x, delta_g2.y, *fe2_one()}, s_g2, g2_b;
+    jac2_mul(&s_g2, &d2, s);                                       /* :116 */
+    calculate_coeff2(&g2_b, &s_g2, b2q, pk->b_g2_len, &beta_g2, w_big + 1, M - 1, nthreads);    /* :117 */
+    jac1 r_g1_b; jac1_mul(&r_g1_b, &g1_b, r);                      /* :118 */
+    double t_b2 = omp_get_wtime();
+    jac1 g_c = s_g_a, neg;                                         /* :123-128 */
+    jac1_add(&g_c, &g_c, &r_g1_b);
+    jac1_neg(&neg, &rs_delta); jac1_add(&g_c, &g_c, &neg);
+    jac1_add(&g_c, &g_c, &l_aux_acc);
+    jac1_add(&g_c, &g_c, &h_acc);
+    aff1 pa, pc; aff2 pb;                                          /* :131-135 */
+    jac1_to_affine(&pa, &g_a); jac2_to_affine(&pb, &g2_b); jac1_to_affine(&pc, &g_c);
+    ser_g1(proof_out, &pa); ser_g2(proof_out + 64, &pb); ser_g1(proof_out + 192, &pc);
+    double t_end = omp_get_wtime();
+    if (tm) {
+        tm->load_s = t_loaded - t_start; tm->witness_map_s = t_wm - t_loaded; tm->msm_h_s = t_h - t_wm; tm->msm_l_s = t_l - t_h;
+        tm->msm_a_s = t_a - t_l; tm->msm_b1_s = t_b1 - t_a; tm->msm_b2_s = t_b2 - t_b1; tm->total_s = t_end - t_loaded;
+    }
+    free(aq); free(b1q); free(hq); free(lq); free(b2q); free(w); free(h); free(h_big);
+    return 0;
+}

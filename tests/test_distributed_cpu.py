@@ -1,0 +1,131 @@
+"""N > 1 path on CPU: two `gloo` ranks run the sharded-proof protocol of crescent_credentials_amd.distributed
+(range-shard every query, all_gather 384-byte partial records, assemble) with the ORACLE standing in for the
+GPU shard, and must reproduce the golden proof of the unsharded prover.  Also covers the rank-timing reduction
+bench.py uses."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_golden
+
+
+def _rows(j):
+    return tuple([[(int(c, 16), col) for c, col in row] for row in mat] for mat in j)
+
+
+def _unpack_pk(o, j):
+    g1s = lambda h: [o.g1_unpack(bytes.fromhex(h)[i:i + 64]) for i in range(0, len(h) // 2, 64)]
+    g2s = lambda h: [o.g2_unpack(bytes.fromhex(h)[i:i + 128]) for i in range(0, len(h) // 2, 128)]
+    vk = dict(alpha_g1=g1s(j["alpha_g1"])[0], beta_g2=g2s(j["beta_g2"])[0], gamma_g2=g2s(j["gamma_g2"])[0],
+              delta_g1=g1s(j["delta_g1"])[0], delta_g2=g2s(j["delta_g2"])[0], gamma_abc_g1=g1s(j["gamma_abc_g1"]))
+    return dict(vk=vk, beta_g1=g1s(j["beta_g1"])[0], delta_g1=vk["delta_g1"], a_query=g1s(j["a_query"]),
+                b_g1_query=g1s(j["b_g1_query"]), b_g2_query=g2s(j["b_g2_query"]), h_query=g1s(j["h_query"]),
+                l_query=g1s(j["l_query"]))
+
+
+class OracleShard:
+    """Stand-in for a GPU shard: same contract as Prover.prove_partial / Prover.assemble, computed by the oracle."""
+
+    def __init__(self, o, pk, mats, l, m, M, rank, count):
+        from crescent_credentials_amd.distributed import shard_range
+        self.o, self.pk, self.mats, self.l, self.m, self.M = o, pk, mats, l, m, M
+        D = o.domain_size_for(m + l)
+        self.rh = shard_range(D - 1, rank, count)
+        self.rl = shard_range(M - l, rank, count)
+        self.ra = shard_range(M - 1, rank, count)
+
+    def prove_partial(self, w, r, on_device=False):
+        o, pk, l = self.o, self.pk, self.l
+        h = o.witness_map_from_matrices(self.mats, l, self.m, w)
+        (h0, h1), (l0, l1), (a0, a1) = self.rh, self.rl, self.ra
+        ph = o.G1.to_affine(o.G1.msm(pk["h_query"][h0:h1], h[h0:h1]))
+        pl = o.G1.to_affine(o.G1.msm(pk["l_query"][l0:l1], w[l + l0:l + l1]))
+        pa = o.G1.to_affine(o.G1.msm(pk["a_query"][1 + a0:1 + a1], w[1 + a0:1 + a1]))
+        pb1 = None if r == 0 else o.G1.to_affine(o.G1.msm(pk["b_g1_query"][1 + a0:1 + a1], w[1 + a0:1 + a1]))
+        pb2 = o.G2.to_affine(o.G2.msm(pk["b_g2_query"][1 + a0:1 + a1], w[1 + a0:1 + a1]))
+        return o.g1_packed(ph) + o.g1_packed(pl) + o.g1_packed(pa) + o.g1_packed(pb1) + o.g2_packed(pb2)
+
+    def assemble(self, parts, n, r, s):
+        o, pk = self.o, self.pk
+        acc = [o.G1.jac_infinity() for _ in range(4)]
+        acc2 = o.G2.jac_infinity()
+        for k in range(n):
+            p = parts[384 * k:384 * (k + 1)]
+            for i in range(4):
+                acc[i] = o.G1.add_affine(acc[i], o.g1_unpack(p[64 * i:64 * i + 64]))
+            acc2 = o.G2.add_affine(acc2, o.g2_unpack(p[256:384]))
+        h_acc, l_acc, a_acc, b1_acc = acc
+        d1 = o.G1.to_jac(pk["delta_g1"])
+        r_g1 = o.G1.mul(d1, r)
+        rs_delta = o.G1.mul(r_g1, s)
+        g_a = o.G1.add_affine(o.G1.add(o.G1.add_affine(r_g1, pk["a_query"][0]), a_acc), pk["vk"]["alpha_g1"])
+        s_g_a = o.G1.mul(g_a, s)
+        if r != 0:
+            g1_b = o.G1.add_affine(o.G1.add(o.G1.add_affine(o.G1.mul(d1, s), pk["b_g1_query"][0]), b1_acc), pk["beta_g1"])
+        else:
+            g1_b = o.G1.jac_infinity()
+        g2_b = o.G2.add_affine(o.G2.add(o.G2.add_affine(o.G2.mul(o.G2.to_jac(pk["vk"]["delta_g2"]), s), pk["b_g2_query"][0]), acc2),
+                               pk["vk"]["beta_g2"])
+        g_c = o.G1.add(s_g_a, o.G1.mul(g1_b, r))
+        g_c = o.G1.add(g_c, o.G1.neg(rs_delta))
+        g_c = o.G1.add(o.G1.add(g_c, l_acc), h_acc)
+        return o.proof_uncompressed((o.G1.to_affine(g_a), o.G2.to_affine(g2_b), o.G1.to_affine(g_c)))
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import bn254_oracle as o
+    from crescent_credentials_amd.distributed import ShardedProver, barrier_sync, max_over_ranks
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        g = load_golden("groth16_d8.json")
+        pk = _unpack_pk(o, g["pk"])
+        w = [int(x, 16) for x in g["witness"]]
+        shard = OracleShard(o, pk, _rows(g["matrices"]), g["num_inputs"], g["num_constraints"], g["num_variables"], rank, world)
+        sp = ShardedProver(shard, torch.device("cpu"))
+        ok = True
+        for case in g["proofs"]:
+            proof = sp.prove(w, int(case["r"], 16), int(case["s"], 16))
+            ok = ok and proof.hex() == case["proof"]
+        barrier_sync(world)
+        mx = max_over_ranks(float(rank + 1), world, torch.device("cpu"))
+        q.put((rank, ok, mx))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_ranges_partition():
+    from crescent_credentials_amd.distributed import shard_range
+    for n in (0, 1, 7, 1023, 1499999):
+        for count in (1, 2, 3, 8):
+            rs = [shard_range(n, k, count) for k in range(count)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(rs[k][1] == rs[k + 1][0] for k in range(count - 1))
+            assert max(b - a for a, b in rs) - min(b - a for a, b in rs) <= 1
+
+
+def test_sharded_proof_two_gloo_ranks():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r for r, _, _ in res) == [0, 1]
+    assert all(ok for _, ok, _ in res), "sharded proof differs from the golden proof"
+    assert all(mx == 2.0 for _, _, mx in res)
