@@ -1,0 +1,253 @@
+// XYZZ group arithmetic over the lazy 29-bit-limb fields (field29.cuh): the formulas the MSM hot
+// kernels run.  Same EFD formulas as curve.cuh (madd-2008-s, add-2008-s, dbl-2008-s-1), but every
+// subtraction names the multiple of N it adds and every place a carry propagation is needed is
+// explicit.  The bounds (values in units of N, limbs in units of 2^29) are machine-checked by
+// tools/bounds29.py for BOTH coordinate fields with these constants:
+//
+//     stored accumulator invariant:  X < 13 N,  Y < 8 N,  ZZ, ZZZ < 3 N,  all normalised
+//     KX = 14, KY = 9, K1 = 4, K2 = 6        (and FQ2_NEGK = 12, FQ2_KS = 17 inside Fq2)
+//
+// Identity is tracked by an explicit flag in registers and stored as ZZ = all-zero limbs.
+#pragma once
+#include "curve.cuh"
+#include "field29.cuh"
+
+namespace cg {
+
+static constexpr int KX = 14, KY = 9, K1 = 4, K2 = 6;
+
+template <class F>
+struct Affine29 {   // table point: coordinates canonical (< N), normalised; never the identity
+    F x, y;
+};
+template <class F>
+struct XYZZ29 {
+    F x, y, zz, zzz;
+};
+
+// number of u32 words of a packed table point / of a stored accumulator
+template <class F> struct Words29;
+template <> struct Words29<Fq29> { static constexpr int AFF = 16, ACC = 36, NF = 1; };
+template <> struct Words29<Fq2_29> { static constexpr int AFF = 32, ACC = 72, NF = 2; };
+
+// ---- memory forms ------------------------------------------------------------------------------------
+CG_HD Fq29 load_packed(const uint32_t* w) { return unpack29<Fq29P>(w); }
+CG_HD void load_coord(Fq29& f, const uint32_t* w) { f = unpack29<Fq29P>(w); }
+CG_HD void load_coord(Fq2_29& f, const uint32_t* w) { f.c0 = unpack29<Fq29P>(w); f.c1 = unpack29<Fq29P>(w + 8); }
+CG_HD void load_limbs(Fq29& f, const uint32_t* w) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) f.l[i] = w[i];
+}
+CG_HD void load_limbs(Fq2_29& f, const uint32_t* w) { load_limbs(f.c0, w); load_limbs(f.c1, w + 9); }
+CG_HD void store_limbs(const Fq29& f, uint32_t* w) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) w[i] = f.l[i];
+}
+CG_HD void store_limbs(const Fq2_29& f, uint32_t* w) { store_limbs(f.c0, w); store_limbs(f.c1, w + 9); }
+
+#if defined(__HIPCC__)
+// table point i of `table` (AFF words each), y negated when `negate`
+template <class F>
+CG_HD Affine29<F> load_table_point(const uint32_t* __restrict__ table, uint32_t idx, bool negate) {
+    constexpr int AFF = Words29<F>::AFF;
+    const uint4* p = reinterpret_cast<const uint4*>(table + (size_t)idx * AFF);
+    uint32_t w[AFF];
+#pragma unroll
+    for (int i = 0; i < AFF / 4; ++i) {
+        uint4 v = p[i];
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+    Affine29<F> a;
+    load_coord(a.x, w);
+    load_coord(a.y, w + AFF / 2);
+    F ny = normalize(sub<2, 1>(F::zero(), a.y));   // 2N - y
+    if (negate) a.y = ny;
+    return a;
+}
+
+// accumulator <-> memory (ACC words; identity = zz all zero)
+template <class F>
+CG_HD void store_acc(uint32_t* __restrict__ dst, const XYZZ29<F>& a, bool inf) {
+    constexpr int ACC = Words29<F>::ACC;
+    uint32_t w[ACC];
+    store_limbs(a.x, w);
+    store_limbs(a.y, w + ACC / 4);
+    store_limbs(a.zz, w + ACC / 2);
+    store_limbs(a.zzz, w + 3 * ACC / 4);
+    if (inf) {
+#pragma unroll
+        for (int i = 0; i < ACC; ++i) w[i] = 0;
+    }
+    uint4* p = reinterpret_cast<uint4*>(dst);
+#pragma unroll
+    for (int i = 0; i < ACC / 4; ++i) p[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+template <class F>
+CG_HD bool load_acc(const uint32_t* __restrict__ src, XYZZ29<F>& a) {   // returns inf
+    constexpr int ACC = Words29<F>::ACC;
+    uint32_t w[ACC];
+    const uint4* p = reinterpret_cast<const uint4*>(src);
+#pragma unroll
+    for (int i = 0; i < ACC / 4; ++i) {
+        uint4 v = p[i];
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+    load_limbs(a.x, w);
+    load_limbs(a.y, w + ACC / 4);
+    load_limbs(a.zz, w + ACC / 2);
+    load_limbs(a.zzz, w + 3 * ACC / 4);
+    return a.zz.all_zero();
+}
+#endif  // __HIPCC__
+
+// ---- group law -------------------------------------------------------------------------------------
+// 2·(affine p)  -> XYZZ           (mdbl-2008-s-1)
+template <class F>
+CG_HD XYZZ29<F> dbl_affine29(const Affine29<F>& p) {
+    F U = normalize(dbl(p.y));
+    F V = sqr(U);
+    F W = mul(U, V);
+    F S = mul(p.x, V);
+    F X2 = sqr(p.x);
+    F M = normalize(add(dbl(X2), X2));
+    F X3 = normalize(sub<K2, 2>(sqr(M), dbl(S)));
+    F d = normalize(sub<KX, 1>(S, X3));
+    F Y3 = normalize(sub<K1, 1>(mul(d, M), mul(p.y, W)));
+    return {X3, Y3, V, W};
+}
+// 2·a (a not the identity)        (dbl-2008-s-1, curve a = 0)
+template <class F>
+CG_HD XYZZ29<F> dbl29(const XYZZ29<F>& a) {
+    F U = normalize(dbl(a.y));
+    F V = sqr(U);
+    F W = mul(U, V);
+    F S = mul(a.x, V);
+    F X2 = sqr(a.x);
+    F M = normalize(add(dbl(X2), X2));
+    F X3 = normalize(sub<K2, 2>(sqr(M), dbl(S)));
+    F d = normalize(sub<KX, 1>(S, X3));
+    F Y3 = normalize(sub<K1, 1>(mul(d, M), mul(a.y, W)));
+    return {X3, Y3, mul(a.zz, V), mul(a.zzz, W)};
+}
+
+// acc += p (p affine, never the identity)          (madd-2008-s)
+// Statement order keeps at most seven field values live (an Fq2 value is 18 VGPRs).
+// In every Fq2 product the SECOND operand is the one that is normalised with the smaller bound.
+template <class F>
+CG_HD void madd29(XYZZ29<F>& acc, bool& inf, const Affine29<F>& p) {
+    if (inf) {
+        acc.x = p.x; acc.y = p.y; acc.zz = F::one(); acc.zzz = F::one();
+        inf = false;
+        return;
+    }
+    F P = normalize(sub<KX, 1>(mul(acc.zz, p.x), acc.x));       // U2 - X1
+    F PP = sqr(P);
+    F ZZ3 = mul(acc.zz, PP);
+    if (is_zero_mod(ZZ3)) {                      // P ≡ 0: same x.  Rare (repeated base / s and r-s).
+        F R0 = normalize(sub<KY, 1>(mul(acc.zzz, p.y), acc.y));
+        if (is_zero_mod(canonical(R0))) acc = dbl_affine29(p);
+        else inf = true;
+        return;
+    }
+    F Q = mul(acc.x, PP);
+    F PPP = mul(P, PP);
+    F R = normalize(sub<KY, 1>(mul(acc.zzz, p.y), acc.y));      // S2 - Y1
+    F ZZZ3 = mul(acc.zzz, PPP);
+    F T = mul(acc.y, PPP);
+    F X3 = normalize(sub<K2, 2>(sub<K1, 1>(sqr(R), PPP), dbl(Q)));
+    F d = normalize(sub<KX, 1>(Q, X3));
+    acc.y = normalize(sub<K1, 1>(mul(d, R), T));
+    acc.x = X3;
+    acc.zz = ZZ3;
+    acc.zzz = ZZZ3;
+}
+
+// acc += q (both XYZZ under the stored invariant)   (add-2008-s)
+template <class F>
+CG_HD void add29(XYZZ29<F>& acc, bool& inf, const XYZZ29<F>& q, bool qinf) {
+    if (qinf) return;
+    if (inf) {
+        acc = q;
+        inf = false;
+        return;
+    }
+    F U1 = mul(acc.x, q.zz);
+    F P = normalize(sub<K1, 1>(mul(q.x, acc.zz), U1));          // U2 - U1
+    F PP = sqr(P);
+    F ZZ3 = mul(mul(acc.zz, q.zz), PP);
+    if (is_zero_mod(ZZ3)) {
+        F R0 = normalize(sub<K1, 1>(mul(q.y, acc.zzz), mul(acc.y, q.zzz)));
+        if (is_zero_mod(canonical(R0))) acc = dbl29(acc);
+        else inf = true;
+        return;
+    }
+    F Q = mul(U1, PP);
+    F PPP = mul(P, PP);
+    F S1 = mul(acc.y, q.zzz);
+    F R = normalize(sub<K1, 1>(mul(q.y, acc.zzz), S1));         // S2 - S1
+    F ZZZ3 = mul(mul(acc.zzz, q.zzz), PPP);
+    F T = mul(S1, PPP);
+    F X3 = normalize(sub<K2, 2>(sub<K1, 1>(sqr(R), PPP), dbl(Q)));
+    F d = normalize(sub<KX, 1>(Q, X3));
+    acc.y = normalize(sub<K1, 1>(mul(d, R), T));
+    acc.x = X3;
+    acc.zz = ZZ3;
+    acc.zzz = ZZZ3;
+}
+
+// ---- inversion / affine normalisation (load-time and result paths only) -----------------------------------
+// a^(N-2), a normalised with value < 16 N
+template <class P>
+CG_HD F29<P> inv29(const F29<P>& a) {
+    typedef typename P::P256 P8;
+    F29<P> r = F29<P>::one();
+    bool started = false;
+    for (int i = 7; i >= 0; --i) {
+        uint32_t e = P8::N[i] - (i == 0 ? 2u : 0u);   // N - 2: no borrow for either modulus
+        for (int b = 31; b >= 0; --b) {
+            if (started) r = sqr(r);
+            if ((e >> b) & 1u) { r = started ? mul(r, a) : a; started = true; }
+        }
+    }
+    return r;
+}
+CG_HD Fq2_29 inv29(const Fq2_29& a) {
+    Fq29 n = inv29(normalize(add(sqr(a.c0), sqr(a.c1))));
+    return {mul(a.c0, n), normalize(sub<3, 1>(Fq29::zero(), mul(a.c1, n)))};
+}
+CG_HD void store_packed_coord(const Fq29& c, uint32_t* w) { pack29(canonical(c), w); }
+CG_HD void store_packed_coord(const Fq2_29& c, uint32_t* w) { pack29(canonical(c.c0), w); pack29(canonical(c.c1), w + 8); }
+// XYZZ (not the identity) -> packed affine table point
+template <class F>
+CG_HD void store_table_point_from_xyzz(const XYZZ29<F>& a, uint32_t* w) {
+    constexpr int AFF = Words29<F>::AFF;
+    F t = inv29(mul(a.zz, a.zzz));
+    F izz = mul(a.zzz, t);
+    F izzz = mul(a.zz, t);
+    store_packed_coord(mul(a.x, izz), w);
+    store_packed_coord(mul(a.y, izzz), w + AFF / 2);
+}
+
+using G1Affine29 = Affine29<Fq29>;
+using G2Affine29 = Affine29<Fq2_29>;
+using G1XYZZ29 = XYZZ29<Fq29>;
+using G2XYZZ29 = XYZZ29<Fq2_29>;
+
+// which 29-bit field carries which saturated field
+template <class F> struct To29;
+template <> struct To29<Fq> { typedef Fq29 type; };
+template <> struct To29<Fq2> { typedef Fq2_29 type; };
+
+// ---- conversions with the saturated (R = 2^256) forms used by the host and the load-time kernels ---------
+// Montgomery(2^256) affine point -> packed table point (canonical x·R' mod N)
+CG_HD void pack_table_coord(const Fq& c, uint32_t* w) {
+    Fq29 t = from_mont256<Fq29P>(c);
+    pack29(t, w);
+}
+CG_HD void pack_table_point(const Affine<Fq>& p, uint32_t* w) { pack_table_coord(p.x, w); pack_table_coord(p.y, w + 8); }
+CG_HD void pack_table_point(const Affine<Fq2>& p, uint32_t* w) {
+    pack_table_coord(p.x.c0, w); pack_table_coord(p.x.c1, w + 8);
+    pack_table_coord(p.y.c0, w + 16); pack_table_coord(p.y.c1, w + 24);
+}
+
+}  // namespace cg

@@ -17,6 +17,7 @@
 //              run up as a partial; partials are reduced by the same kernel recursively.
 //   reduce   : Σ (b+1)·S_b by chunked running sums, a small scalar multiple per chunk, and a tree
 //              sum.
+// All curve arithmetic here runs on the lazy 29-bit-limb representation (field29.cuh / curve29.cuh).
 #include "msm.hpp"
 
 #include <cstring>
@@ -37,8 +38,8 @@ int msm_default_window(uint64_t n, bool precomputed) {
         if ((double)W * (double)n >= 2147483648.0) continue;
         double buckets = (double)(1u << (c - 1)) * (precomputed ? 1 : W);
         if (buckets > (double)(1u << 24)) continue;
-        // mixed add ~ 10 field products, bucket-reduction add ~ 14, two per bucket
-        double cost = (double)n * W * 10.0 + buckets * 2.0 * 14.0;
+        // mixed add ~ 12 field products, bucket-reduction add ~ 16, two per bucket
+        double cost = (double)n * W * 12.0 + buckets * 2.0 * 16.0;
         if (cost < best) { best = cost; best_c = c; }
     }
     return best_c;
@@ -82,30 +83,50 @@ void import_bases(const uint8_t* host_bytes, uint32_t coord_form, uint64_t n, Af
 template void import_bases<Fq>(const uint8_t*, uint32_t, uint64_t, Affine<Fq>*, hipStream_t);
 template void import_bases<Fq2>(const uint8_t*, uint32_t, uint64_t, Affine<Fq2>*, hipStream_t);
 
+// row 0: Montgomery(2^256) points -> packed table points (x·2^261 mod q)
 template <class F>
-__global__ void __launch_bounds__(256) k_table_first(const Affine<F>* __restrict__ bases, Affine<F>* __restrict__ table,
+__global__ void __launch_bounds__(256) k_table_first(const Affine<F>* __restrict__ bases, uint32_t* __restrict__ table,
                                                      uint8_t* __restrict__ valid, uint64_t n) {
+    typedef typename To29<F>::type F29T;
+    constexpr int AFF = Words29<F29T>::AFF;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Affine<F> p = bases[i];
-    table[i] = p;
-    valid[i] = p.is_inf() ? 0 : 1;
+    uint32_t w[AFF];
+    const bool inf = p.is_inf();
+    if (inf) {
+#pragma unroll
+        for (int k = 0; k < AFF; ++k) w[k] = 0;
+    } else {
+        pack_table_point(p, w);
+    }
+    uint4* dst = reinterpret_cast<uint4*>(table + i * AFF);
+#pragma unroll
+    for (int k = 0; k < AFF / 4; ++k) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+    valid[i] = inf ? 0 : 1;
 }
 
-// table[j*n + i] = 2^c * table[(j-1)*n + i]
-template <class F>
-__global__ void __launch_bounds__(256) k_table_next(Affine<F>* __restrict__ table, const uint8_t* __restrict__ valid,
+// row j = 2^c * row (j-1)
+template <class F29T>
+__global__ void __launch_bounds__(256) k_table_next(uint32_t* __restrict__ table, const uint8_t* __restrict__ valid,
                                                     uint64_t n, int j, int c) {
+    constexpr int AFF = Words29<F29T>::AFF;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    uint32_t* dstw = table + ((uint64_t)j * n + i) * AFF;
+    uint32_t w[AFF];
     if (!valid[i]) {
-        table[(uint64_t)j * n + i] = Affine<F>::inf();
-        return;
+#pragma unroll
+        for (int k = 0; k < AFF; ++k) w[k] = 0;
+    } else {
+        Affine29<F29T> p = load_table_point<F29T>(table + (uint64_t)(j - 1) * n * AFF, (uint32_t)i, false);
+        XYZZ29<F29T> a = dbl_affine29(p);
+        for (int k = 1; k < c; ++k) a = dbl29(a);       // a point of odd prime order never doubles to the identity
+        store_table_point_from_xyzz(a, w);
     }
-    Affine<F> p = table[(uint64_t)(j - 1) * n + i];
-    XYZZ<F> a = dbl_affine(p);
-    for (int k = 1; k < c; ++k) a = dbl(a);
-    table[(uint64_t)j * n + i] = to_affine(a);  // a point of odd prime order never doubles to infinity
+    uint4* dst = reinterpret_cast<uint4*>(dstw);
+#pragma unroll
+    for (int k = 0; k < AFF / 4; ++k) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
 }
 
 template <class F>
@@ -116,14 +137,14 @@ void MsmBases<F>::build(const Affine<F>* bases_dev, uint64_t n_, int c_, bool pr
     precomputed = precompute;
     if ((uint64_t)W * n >= (1ull << 31)) throw HipError(CG_ERR_INVALID_ARGUMENT, "MSM too large for 31-bit table indices");
     const uint64_t rows = precompute ? (uint64_t)W : 1;
-    table.alloc(n ? rows * n : 1);
+    table.alloc(n ? rows * n * AFF : 4);
     valid.alloc(n ? n : 1);
     if (!n) return;
     k_table_first<F><<<ceil_div(n, 256), 256, 0, st>>>(bases_dev, table.p, valid.p, n);
     CG_KERNEL_CHECK();
     if (precompute)
         for (int j = 1; j < W; ++j) {
-            k_table_next<F><<<ceil_div(n, 256), 256, 0, st>>>(table.p, valid.p, n, j, c);
+            k_table_next<F29T><<<ceil_div(n, 256), 256, 0, st>>>(table.p, valid.p, n, j, c);
             CG_KERNEL_CHECK();
         }
 }
@@ -202,89 +223,95 @@ __global__ void __launch_bounds__(256) k_digit_emit(const Fr* __restrict__ scala
 // ---------------------------------------------------------------------------------------------
 // bucket accumulation over equal segments of the sorted entry list
 // ---------------------------------------------------------------------------------------------
-template <class F>
-__device__ __forceinline__ void flush_run(uint32_t key, const XYZZ<F>& acc, bool first, bool final_level, uint32_t t,
-                                          XYZZ<F>* __restrict__ bucket_sums, uint32_t* __restrict__ part_keys,
-                                          XYZZ<F>* __restrict__ part_pts) {
+template <class F29T>
+__device__ __forceinline__ void flush_run(uint32_t key, const XYZZ29<F29T>& acc, bool inf, bool first, bool final_level,
+                                          uint32_t t, uint32_t* __restrict__ bucket_sums, uint32_t* __restrict__ part_keys,
+                                          uint32_t* __restrict__ part_pts) {
+    constexpr int ACC = Words29<F29T>::ACC;
     if (first && !final_level) {
         part_keys[2 * t] = key;
-        part_pts[2 * t] = acc;
+        store_acc(part_pts + (size_t)(2 * t) * ACC, acc, inf);
     } else {
-        bucket_sums[key] = acc;
+        store_acc(bucket_sums + (size_t)key * ACC, acc, inf);
     }
 }
 
-template <class F>
+template <class F29T>
 __global__ void __launch_bounds__(256) k_accum_affine(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                      uint32_t N, uint32_t L, uint32_t T, const Affine<F>* __restrict__ table,
-                                                      XYZZ<F>* __restrict__ bucket_sums, uint32_t* __restrict__ part_keys,
-                                                      XYZZ<F>* __restrict__ part_pts) {
+                                                      uint32_t N, uint32_t L, uint32_t T, const uint32_t* __restrict__ table,
+                                                      uint32_t* __restrict__ bucket_sums, uint32_t* __restrict__ part_keys,
+                                                      uint32_t* __restrict__ part_pts) {
+    constexpr int ACC = Words29<F29T>::ACC;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     const bool final_level = (T == 1);
     uint32_t beg = t * L;
     uint32_t end = beg + L < N ? beg + L : N;
-    XYZZ<F> acc = XYZZ<F>::inf();
+    XYZZ29<F29T> acc;
+    bool inf = true;
     uint32_t cur = keys[beg];
     bool first = true;
     for (uint32_t k = beg; k < end; ++k) {
         uint32_t key = keys[k];
         uint32_t v = vals[k];
         if (key != cur) {
-            flush_run(cur, acc, first, final_level, t, bucket_sums, part_keys, part_pts);
+            flush_run(cur, acc, inf, first, final_level, t, bucket_sums, part_keys, part_pts);
             first = false;
-            acc = XYZZ<F>::inf();
+            inf = true;
             cur = key;
         }
-        Affine<F> p = table[v & 0x7fffffffu];
-        if (v >> 31) p.y = neg(p.y);
-        madd(acc, p);
+        Affine29<F29T> p = load_table_point<F29T>(table, v & 0x7fffffffu, (v >> 31) != 0);
+        madd29(acc, inf, p);
     }
     if (final_level) {
-        bucket_sums[cur] = acc;
+        store_acc(bucket_sums + (size_t)cur * ACC, acc, inf);
     } else if (first) {  // the whole segment is one run
         part_keys[2 * t] = cur;
-        part_pts[2 * t] = acc;
+        store_acc(part_pts + (size_t)(2 * t) * ACC, acc, inf);
         part_keys[2 * t + 1] = cur;
-        part_pts[2 * t + 1] = XYZZ<F>::inf();
+        store_acc(part_pts + (size_t)(2 * t + 1) * ACC, acc, true);
     } else {
         part_keys[2 * t + 1] = cur;
-        part_pts[2 * t + 1] = acc;
+        store_acc(part_pts + (size_t)(2 * t + 1) * ACC, acc, inf);
     }
 }
 
-template <class F>
-__global__ void __launch_bounds__(256) k_accum_xyzz(const uint32_t* __restrict__ keys, const XYZZ<F>* __restrict__ pts,
-                                                    uint32_t N, uint32_t L, uint32_t T, XYZZ<F>* __restrict__ bucket_sums,
-                                                    uint32_t* __restrict__ part_keys, XYZZ<F>* __restrict__ part_pts) {
+template <class F29T>
+__global__ void __launch_bounds__(256) k_accum_xyzz(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ pts,
+                                                    uint32_t N, uint32_t L, uint32_t T, uint32_t* __restrict__ bucket_sums,
+                                                    uint32_t* __restrict__ part_keys, uint32_t* __restrict__ part_pts) {
+    constexpr int ACC = Words29<F29T>::ACC;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     const bool final_level = (T == 1);
     uint32_t beg = t * L;
     uint32_t end = beg + L < N ? beg + L : N;
-    XYZZ<F> acc = XYZZ<F>::inf();
+    XYZZ29<F29T> acc;
+    bool inf = true;
     uint32_t cur = keys[beg];
     bool first = true;
     for (uint32_t k = beg; k < end; ++k) {
         uint32_t key = keys[k];
         if (key != cur) {
-            flush_run(cur, acc, first, final_level, t, bucket_sums, part_keys, part_pts);
+            flush_run(cur, acc, inf, first, final_level, t, bucket_sums, part_keys, part_pts);
             first = false;
-            acc = XYZZ<F>::inf();
+            inf = true;
             cur = key;
         }
-        add(acc, pts[k]);
+        XYZZ29<F29T> q;
+        bool qinf = load_acc(pts + (size_t)k * ACC, q);
+        add29(acc, inf, q, qinf);
     }
     if (final_level) {
-        bucket_sums[cur] = acc;
+        store_acc(bucket_sums + (size_t)cur * ACC, acc, inf);
     } else if (first) {
         part_keys[2 * t] = cur;
-        part_pts[2 * t] = acc;
+        store_acc(part_pts + (size_t)(2 * t) * ACC, acc, inf);
         part_keys[2 * t + 1] = cur;
-        part_pts[2 * t + 1] = XYZZ<F>::inf();
+        store_acc(part_pts + (size_t)(2 * t + 1) * ACC, acc, true);
     } else {
         part_keys[2 * t + 1] = cur;
-        part_pts[2 * t + 1] = acc;
+        store_acc(part_pts + (size_t)(2 * t + 1) * ACC, acc, inf);
     }
 }
 
@@ -293,63 +320,79 @@ __global__ void __launch_bounds__(256) k_accum_xyzz(const uint32_t* __restrict__
 // ---------------------------------------------------------------------------------------------
 // thread t of window w covers buckets [t*K, t*K+K) of that window:
 //   out = Σ (b - tK + 1)·S_b + (tK)·Σ S_b
-template <class F>
-__global__ void __launch_bounds__(256) k_reduce_chunks(const XYZZ<F>* __restrict__ bucket_sums, uint32_t nb_per_window,
+template <class F29T>
+__global__ void __launch_bounds__(256) k_reduce_chunks(const uint32_t* __restrict__ bucket_sums, uint32_t nb_per_window,
                                                        uint32_t K, uint32_t chunks_per_window, uint32_t total_chunks,
-                                                       XYZZ<F>* __restrict__ out) {
+                                                       uint32_t* __restrict__ out) {
+    constexpr int ACC = Words29<F29T>::ACC;
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total_chunks) return;
     uint32_t w = g / chunks_per_window, t = g % chunks_per_window;
-    const XYZZ<F>* S = bucket_sums + (uint64_t)w * nb_per_window;
+    const uint32_t* S = bucket_sums + (size_t)w * nb_per_window * ACC;
     uint32_t lo = t * K;
     uint32_t hi = lo + K < nb_per_window ? lo + K : nb_per_window;
-    XYZZ<F> run = XYZZ<F>::inf(), acc = XYZZ<F>::inf();
+    XYZZ29<F29T> run, acc;
+    bool run_inf = true, acc_inf = true;
     for (uint32_t b = hi; b-- > lo;) {
-        add(run, S[b]);
-        add(acc, run);
+        XYZZ29<F29T> q;
+        bool qinf = load_acc(S + (size_t)b * ACC, q);
+        add29(run, run_inf, q, qinf);
+        add29(acc, acc_inf, run, run_inf);
     }
-    if (lo != 0 && !run.is_inf()) {
+    if (lo != 0 && !run_inf) {
         // (lo)·run by MSB-first double-and-add; lo < 2^22
-        XYZZ<F> m = run;
+        XYZZ29<F29T> m = run;
+        bool m_inf = false;
         int top = 31 - __clz(lo);
         for (int bit = top - 1; bit >= 0; --bit) {
-            m = dbl(m);
-            if ((lo >> bit) & 1u) add(m, run);
+            if (!m_inf) m = dbl29(m);
+            if ((lo >> bit) & 1u) add29(m, m_inf, run, false);
         }
-        add(acc, m);
+        add29(acc, acc_inf, m, m_inf);
     }
-    out[g] = acc;
+    store_acc(out + (size_t)g * ACC, acc, acc_inf);
 }
 
 // out[w*out_per_window + blk] = Σ of this block's slice of in[w*in_per_window ...]
-template <class F>
-__global__ void __launch_bounds__(256) k_sum_points(const XYZZ<F>* __restrict__ in, uint32_t in_per_window,
-                                                    XYZZ<F>* __restrict__ out, uint32_t out_per_window) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    XYZZ<F>* sm = reinterpret_cast<XYZZ<F>*>(smem_raw);
+template <class F29T>
+__global__ void __launch_bounds__(256) k_sum_points(const uint32_t* __restrict__ in, uint32_t in_per_window,
+                                                    uint32_t* __restrict__ out, uint32_t out_per_window) {
+    constexpr int ACC = Words29<F29T>::ACC;
+    extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
     const uint32_t w = blockIdx.y;
     const uint32_t blk = blockIdx.x;
-    const XYZZ<F>* src = in + (uint64_t)w * in_per_window;
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (uint32_t i = blk * blockDim.x + threadIdx.x; i < in_per_window; i += gridDim.x * blockDim.x) add(acc, src[i]);
-    sm[threadIdx.x] = acc;
+    const uint32_t* src = in + (size_t)w * in_per_window * ACC;
+    XYZZ29<F29T> acc;
+    bool inf = true;
+    for (uint32_t i = blk * blockDim.x + threadIdx.x; i < in_per_window; i += gridDim.x * blockDim.x) {
+        XYZZ29<F29T> q;
+        bool qinf = load_acc(src + (size_t)i * ACC, q);
+        add29(acc, inf, q, qinf);
+    }
+    store_acc(sm + (size_t)threadIdx.x * ACC, acc, inf);
     __syncthreads();
     for (uint32_t s = blockDim.x / 2; s > 0; s >>= 1) {
         if (threadIdx.x < s) {
-            XYZZ<F> a = sm[threadIdx.x];
-            add(a, sm[threadIdx.x + s]);
-            sm[threadIdx.x] = a;
+            XYZZ29<F29T> a, b;
+            bool ai = load_acc(sm + (size_t)threadIdx.x * ACC, a);
+            bool bi = load_acc(sm + (size_t)(threadIdx.x + s) * ACC, b);
+            add29(a, ai, b, bi);
+            store_acc(sm + (size_t)threadIdx.x * ACC, a, ai);
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[(uint64_t)w * out_per_window + blk] = sm[0];
+    if (threadIdx.x == 0) {
+        XYZZ29<F29T> a;
+        bool ai = load_acc(sm, a);
+        store_acc(out + ((size_t)w * out_per_window + blk) * ACC, a, ai);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
 // engine
 // ---------------------------------------------------------------------------------------------
 static constexpr uint32_t ACC_TARGET_THREADS = 256u * 4u * 4u * 64u * 2u;  // CUs x SIMDs x waves x lanes x rounds
-static constexpr uint32_t ACC_MIN_L = 8;
+static constexpr uint32_t ACC_MIN_L = 16;
 static constexpr uint32_t ACC_LEVEL_L = 8;   // segment length of the partial-combining levels
 static constexpr uint32_t RED_K = 16;        // buckets per thread in the running-sum reduction
 
@@ -377,36 +420,33 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
     (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, keys_a.p, keys_b.p, vals_a.p, vals_b.p, (size_t)cap_entries, 0u, 32u);
     sort_tmp_bytes = scan_bytes > sort_bytes ? scan_bytes : sort_bytes;
     sort_tmp.alloc(sort_tmp_bytes ? sort_tmp_bytes : 1);
-    bucket_sums.alloc(nbuckets_total);
-    // partial buffers: level 1 emits 2*T1 partials with T1 <= cap/ACC_MIN_L ... but L grows with N,
-    // so T1 <= max(ACC_TARGET_THREADS, cap/ACC_MIN_L) capped by cap.
+    bucket_sums.alloc((size_t)nbuckets_total * ACC);
     uint64_t t1 = (cap_entries + ACC_MIN_L - 1) / ACC_MIN_L;
     if (t1 > ACC_TARGET_THREADS) t1 = ACC_TARGET_THREADS;
     uint64_t pa = 2 * t1;
     uint64_t t2 = (pa + ACC_LEVEL_L - 1) / ACC_LEVEL_L;
     uint64_t pb = 2 * t2;
-    part_keys_a.alloc(pa); part_pts_a.alloc(pa);
-    part_keys_b.alloc(pb); part_pts_b.alloc(pb);
+    part_keys_a.alloc(pa); part_pts_a.alloc(pa * ACC);
+    part_keys_b.alloc(pb); part_pts_b.alloc(pb * ACC);
     const uint32_t wins = b->precomputed ? 1u : (uint32_t)W;
     uint32_t chunks = ceil_div(nb, RED_K);
-    red_a.alloc((uint64_t)chunks * wins);
-    red_b.alloc((uint64_t)ceil_div(chunks, 256) * wins + wins);
-    result.alloc(wins);
+    red_a.alloc((uint64_t)chunks * wins * ACC);
+    red_b.alloc(((uint64_t)ceil_div(chunks, 256) * wins + wins) * ACC);
+    result.alloc((size_t)wins * ACC);
     h_count.alloc(1);
-    h_result.alloc(wins);
+    h_result.alloc((size_t)wins * ACC);
     CG_HIP(hipEventCreateWithFlags(&ev_count, hipEventDisableTiming));
     for (auto& e : ev_t) CG_HIP(hipEventCreate(&e));
 }
 
-template <class F>
-static float elapsed(hipEvent_t a, hipEvent_t b) {
+static float elapsed_ms(hipEvent_t a, hipEvent_t b) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0.f;
     return ms;
 }
-template <class F> float MsmEngine<F>::ms_total() const { return elapsed<F>(ev_t[0], ev_t[5]); }
-template <class F> float MsmEngine<F>::ms_sort() const { return n_entries ? elapsed<F>(ev_t[1], ev_t[2]) : 0.f; }
-template <class F> float MsmEngine<F>::ms_accum() const { return n_entries ? elapsed<F>(ev_t[3], ev_t[4]) : 0.f; }
+template <class F> float MsmEngine<F>::ms_total() const { return elapsed_ms(ev_t[0], ev_t[5]); }
+template <class F> float MsmEngine<F>::ms_sort() const { return n_entries ? elapsed_ms(ev_t[1], ev_t[2]) : 0.f; }
+template <class F> float MsmEngine<F>::ms_accum() const { return n_entries ? elapsed_ms(ev_t[3], ev_t[4]) : 0.f; }
 
 template <class F>
 MsmEngine<F>::~MsmEngine() {
@@ -457,8 +497,8 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
         uint32_t L = level1_L(N);
         uint32_t T = ceil_div(N, L);
         CG_HIP(hipEventRecord(ev_t[3], st));
-        k_accum_affine<F><<<ceil_div(T, 256), 256, 0, st>>>(keys_b.p, vals_b.p, N, L, T, bases->table.p, bucket_sums.p,
-                                                            part_keys_a.p, part_pts_a.p);
+        k_accum_affine<F29T><<<ceil_div(T, 256), 256, 0, st>>>(keys_b.p, vals_b.p, N, L, T, bases->table.p, bucket_sums.p,
+                                                               part_keys_a.p, part_pts_a.p);
         CG_KERNEL_CHECK();
         CG_HIP(hipEventRecord(ev_t[4], st));
         // combine partials until one lane covers everything
@@ -468,10 +508,10 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
             uint32_t Lk = ACC_LEVEL_L;
             uint32_t Tk = ceil_div(count, Lk);
             const uint32_t* ik = from_a ? part_keys_a.p : part_keys_b.p;
-            const XYZZ<F>* ip = from_a ? part_pts_a.p : part_pts_b.p;
+            const uint32_t* ip = from_a ? part_pts_a.p : part_pts_b.p;
             uint32_t* ok = from_a ? part_keys_b.p : part_keys_a.p;
-            XYZZ<F>* op = from_a ? part_pts_b.p : part_pts_a.p;
-            k_accum_xyzz<F><<<ceil_div(Tk, 256), 256, 0, st>>>(ik, ip, count, Lk, Tk, bucket_sums.p, ok, op);
+            uint32_t* op = from_a ? part_pts_b.p : part_pts_a.p;
+            k_accum_xyzz<F29T><<<ceil_div(Tk, 256), 256, 0, st>>>(ik, ip, count, Lk, Tk, bucket_sums.p, ok, op);
             CG_KERNEL_CHECK();
             count = (Tk == 1) ? 0 : 2 * Tk;
             from_a = !from_a;
@@ -480,35 +520,92 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
     // bucket reduction
     const uint32_t chunks = ceil_div(nb, RED_K);
     const uint32_t total_chunks = chunks * wins;
-    k_reduce_chunks<F><<<ceil_div(total_chunks, 256), 256, 0, st>>>(bucket_sums.p, nb, RED_K, chunks, total_chunks, red_a.p);
+    k_reduce_chunks<F29T><<<ceil_div(total_chunks, 256), 256, 0, st>>>(bucket_sums.p, nb, RED_K, chunks, total_chunks, red_a.p);
     CG_KERNEL_CHECK();
     uint32_t per_win = chunks;
-    XYZZ<F>* src = red_a.p;
-    XYZZ<F>* dst = red_b.p;
+    uint32_t* src = red_a.p;
+    uint32_t* dst = red_b.p;
     while (true) {
         uint32_t blocks = ceil_div(per_win, 256);
-        uint32_t threads = per_win < 256 ? 64u : 256u;
+        uint32_t threads = 256;
         if (per_win < 256) { threads = 64; while (threads < per_win) threads <<= 1; }
-        XYZZ<F>* out = (blocks == 1) ? result.p : dst;
-        k_sum_points<F><<<dim3(blocks, wins), threads, threads * sizeof(XYZZ<F>), st>>>(src, per_win, out, blocks == 1 ? 1 : blocks);
+        uint32_t* out = (blocks == 1) ? result.p : dst;
+        k_sum_points<F29T><<<dim3(blocks, wins), threads, (size_t)threads * ACC * 4, st>>>(src, per_win, out, blocks == 1 ? 1 : blocks);
         CG_KERNEL_CHECK();
         if (blocks == 1) break;
         per_win = blocks;
-        XYZZ<F>* tswap = src; src = dst; dst = tswap;
+        uint32_t* tswap = src; src = dst; dst = tswap;
     }
-    CG_HIP(hipMemcpyAsync(h_result.p, result.p, wins * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+    CG_HIP(hipMemcpyAsync(h_result.p, result.p, (size_t)wins * ACC * 4, hipMemcpyDeviceToHost, st));
     CG_HIP(hipEventRecord(ev_t[5], st));
+}
+
+// ---- host: lazy 29-bit accumulator -> saturated Montgomery(2^256) XYZZ ---------------------------------
+// value = Σ l_i 2^(29 i) < 2^261 is x·2^261 mod q up to a multiple of q; reduce, then x·2^256 = value / 32.
+static Fq fq_from_limbs29(const uint32_t l[9]) {
+    typedef unsigned __int128 u128;
+    uint64_t v[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 9; ++i) {
+        int bit = 29 * i, w = bit >> 6, sh = bit & 63;
+        u128 x = (u128)l[i] << sh;
+        u128 s = (u128)v[w] + (uint64_t)x;
+        v[w] = (uint64_t)s;
+        u128 carry = (s >> 64) + (x >> 64);
+        for (int k = w + 1; k < 5 && carry; ++k) {
+            u128 t = (u128)v[k] + (uint64_t)carry;
+            v[k] = (uint64_t)t;
+            carry = t >> 64;
+        }
+    }
+    uint64_t n[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) n[i] = (uint64_t)FqP::N[2 * i] | ((uint64_t)FqP::N[2 * i + 1] << 32);
+    auto ge = [&]() {
+        for (int i = 4; i >= 0; --i) {
+            if (v[i] > n[i]) return true;
+            if (v[i] < n[i]) return false;
+        }
+        return true;
+    };
+    while (ge()) {
+        u128 br = 0;
+        for (int i = 0; i < 5; ++i) {
+            u128 d = (u128)v[i] - n[i] - (uint64_t)br;
+            v[i] = (uint64_t)d;
+            br = (d >> 64) & 1;
+        }
+    }
+    Fq a;
+    for (int i = 0; i < 4; ++i) { a.l[2 * i] = (uint32_t)v[i]; a.l[2 * i + 1] = (uint32_t)(v[i] >> 32); }
+    Fq c2 = Fq::zero();
+    c2.l[7] = 0x08000000u;   // 2^251 = (2^256)^2 / 2^261
+    return mul(a, c2);       // a · 2^251 / 2^256 = a / 32
+}
+static void coord_from_limbs29(Fq& out, const uint32_t* w) { out = fq_from_limbs29(w); }
+static void coord_from_limbs29(Fq2& out, const uint32_t* w) { out.c0 = fq_from_limbs29(w); out.c1 = fq_from_limbs29(w + 9); }
+
+template <class F>
+static XYZZ<F> xyzz_from_words(const uint32_t* w, int acc_words) {
+    const int q = acc_words / 4;
+    bool inf = true;
+    for (int i = 0; i < q; ++i) if (w[2 * q + i]) inf = false;
+    if (inf) return XYZZ<F>::inf();
+    XYZZ<F> r;
+    coord_from_limbs29(r.x, w);
+    coord_from_limbs29(r.y, w + q);
+    coord_from_limbs29(r.zz, w + 2 * q);
+    coord_from_limbs29(r.zzz, w + 3 * q);
+    return r;
 }
 
 template <class F>
 XYZZ<F> MsmEngine<F>::value() const {
-    if (bases->precomputed) return h_result.p[0];
+    if (bases->precomputed) return xyzz_from_words<F>(h_result.p, ACC);
     // Horner over the windows: Σ_j 2^(c j) S_j
     const int W = bases->W, c = bases->c;
     XYZZ<F> acc = XYZZ<F>::inf();
     for (int j = W - 1; j >= 0; --j) {
         for (int k = 0; k < c; ++k) acc = dbl(acc);
-        add(acc, h_result.p[j]);
+        add(acc, xyzz_from_words<F>(h_result.p + (size_t)j * ACC, ACC));
     }
     return acc;
 }

@@ -3,22 +3,26 @@
 // (call sites forks/groth16/src/prover.rs:66,74,266).
 #pragma once
 #include "common.hpp"
+#include "curve29.cuh"
 
 namespace cg {
 
-// Fixed bases of one query, expanded for every window: table[j*n + i] = 2^(c*j) * P_i (affine,
-// Montgomery).  With all windows pre-shifted, every signed digit of every scalar lands in ONE
-// shared set of 2^(c-1) buckets, so a whole MSM is a single bucket accumulation plus a single
-// bucket reduction — the layout 288 GB of HBM makes affordable (13x the key size at c = 20).
+// Fixed bases of one query, expanded for every window: row j holds 2^(c*j) * P_i.  With all windows
+// pre-shifted, every signed digit of every scalar lands in ONE shared set of 2^(c-1) buckets, so a whole
+// MSM is a single bucket accumulation plus a single bucket reduction — the layout 288 GB of HBM makes
+// affordable (13x the key size at c = 20).  A table point is its two (G1) or four (G2) coordinates as
+// canonical x·2^261 mod q, eight u32 each: 64 B / 128 B, exactly the size of the key's own points.
 template <class F>
 struct MsmBases {
+    typedef typename To29<F>::type F29T;
+    static constexpr int AFF = Words29<F29T>::AFF;
     uint64_t n = 0;
     int c = 0;          // window bits
     int W = 0;          // number of windows = ceil(255 / c)
     bool precomputed = true;   // false: table holds only window 0 and keys carry the window index
-    DevBuf<Affine<F>> table;
+    DevBuf<uint32_t> table;    // rows * n * AFF words, window-major
     DevBuf<uint8_t> valid;     // 1 = base is not the identity
-    // bases_dev: n affine points already in Montgomery form on the device (identity = all zero)
+    // bases_dev: n affine points in Montgomery(2^256) form on the device (identity = all zero)
     void build(const Affine<F>* bases_dev, uint64_t n, int c, bool precompute, hipStream_t st);
 };
 
@@ -27,21 +31,22 @@ int msm_default_window(uint64_t n, bool precomputed);
 // Per-MSM working set; reusable across proofs.
 template <class F>
 struct MsmEngine {
+    typedef typename To29<F>::type F29T;
+    static constexpr int ACC = Words29<F29T>::ACC;   // u32 words of a stored XYZZ accumulator (144 B / 288 B)
     const MsmBases<F>* bases = nullptr;
     uint64_t cap_entries = 0;
     uint32_t nbuckets_total = 0;  // buckets per window * windows-in-key-space
     DevBuf<uint32_t> keys_a, keys_b, vals_a, vals_b;
-    DevBuf<uint32_t> thread_counts;   // per-scalar non-zero digit count, then exclusive offsets
-    DevBuf<uint32_t> block_sums;
+    DevBuf<uint32_t> thread_counts;   // per-scalar non-zero digit count, then inclusive offsets
     DevBuf<uint8_t> sort_tmp;
     size_t sort_tmp_bytes = 0;
-    DevBuf<XYZZ<F>> bucket_sums;
+    DevBuf<uint32_t> bucket_sums;     // nbuckets_total * ACC
     DevBuf<uint32_t> part_keys_a, part_keys_b;
-    DevBuf<XYZZ<F>> part_pts_a, part_pts_b;
-    DevBuf<XYZZ<F>> red_a, red_b;
-    DevBuf<XYZZ<F>> result;           // W_keyspace points (1 when precomputed)
+    DevBuf<uint32_t> part_pts_a, part_pts_b;
+    DevBuf<uint32_t> red_a, red_b;
+    DevBuf<uint32_t> result;          // W_keyspace accumulators (1 when precomputed)
     PinnedBuf<uint32_t> h_count;
-    PinnedBuf<XYZZ<F>> h_result;
+    PinnedBuf<uint32_t> h_result;
     uint64_t n_scalars = 0;
     uint32_t n_entries = 0;
     hipEvent_t ev_count = nullptr;
@@ -59,7 +64,7 @@ struct MsmEngine {
     void digits(const Fr* scalars_dev, uint64_t n, hipStream_t st);
     // phase 2 (waits for the count): sort by bucket, accumulate, reduce; result copied to h_result.
     void accumulate(hipStream_t st);
-    // after the stream has been synchronised: the MSM value
+    // after the stream has been synchronised: the MSM value (host arithmetic, Montgomery 2^256 form)
     XYZZ<F> value() const;
 };
 

@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Bound checker for the lazy 29-bit-limb formulas of csrc/curve29.cuh.
+
+Every field value is tracked as (V, L): V = upper bound of the value in units of the modulus N,
+L = upper bound of limbs 0..7 in units of 2^29.  The script replays the exact operation sequence of
+madd / add / dbl for Fq and Fq2 and asserts every precondition (64-bit column sums, non-negative
+limb-wise subtraction, representability < 2^261) and that the accumulator invariant (X, Y, ZZ, ZZZ
+bounds) is closed under all three operations.  Run: python tools/bounds29.py
+"""
+import math
+
+RN = 169.28          # 2^261 / N  (both BN254 moduli)
+CAP = 160.0          # values must stay below 2^261 / N with margin
+
+
+class B:
+    def __init__(self, V, L, norm=None):
+        self.V, self.L = V, L
+        assert V < CAP, "value bound %.1f exceeds representable range" % V
+        assert L * 2 ** 29 < 2 ** 32 - 16, "limb overflow L=%.2f" % L
+
+    def __repr__(self):
+        return "B(V=%.2f, L=%.2f)" % (self.V, self.L)
+
+
+def col_ok(pairs, nprod):
+    """pairs: list of (La, Lb) limb bounds (units 2^29) of the nprod-per-column product groups."""
+    tot = 0.0
+    for la, lb in pairs:
+        tot += 9 * (la * 2 ** 29) * (lb * 2 ** 29)
+    tot += 9 * (2 ** 29) ** 2 + 2 ** 36      # m*N products + carry
+    assert tot < 2 ** 64, "column accumulator overflow: 2^%.2f" % math.log2(tot)
+
+
+class Fq:
+    name = "Fq"
+
+    @staticmethod
+    def mul(a, b):
+        col_ok([(a.L, b.L)], 9)
+        return B(a.V * b.V / RN + 1.0, 1.0)
+
+    @staticmethod
+    def sqr(a):
+        # doubled copy: limbs 2 a.L against a.L, ~half the products
+        col_ok([(2 * a.L, a.L)], 5)
+        return B(a.V * a.V / RN + 1.0, 1.0)
+
+    @staticmethod
+    def add(a, b):
+        return B(a.V + b.V, a.L + b.L)
+
+    @staticmethod
+    def dbl(a):
+        return B(2 * a.V, 2 * a.L)
+
+    @staticmethod
+    def sub(a, b, K, T):
+        assert b.L <= T + 1e-9, "sub<%d,%d>: subtrahend limbs %.2f exceed boost" % (K, T, b.L)
+        assert b.V <= K - 1 + 1e-9, "sub<%d,%d>: subtrahend value %.2f needs K >= %.0f" % (K, T, b.V, math.ceil(b.V + 1))
+        return B(a.V + K, a.L + T + 1)
+
+    @staticmethod
+    def norm(a):
+        return B(a.V, 1.0)
+
+
+class Fq2:
+    """components tracked with a common bound.  mul2(x0,y0,x1,y1) = (x0 y0 + x1 y1)/R' is one dual-product
+    Montgomery reduction (18 products per column):
+       mul(a, b): c0 = mul2(a0, b0, a1, NEGK N - b1),  c1 = mul2(a0, b1, a1, b0)      (b = the smaller operand)
+       sqr(a):    c0 = mul2(a0, a0, a1, KS N - a1),     c1 = mul(2 a0, a1)"""
+    name = "Fq2"
+    NEGK = 12
+    KS = 17
+
+    @staticmethod
+    def mul(a, b):
+        if a.V < b.V:
+            a, b = b, a
+        assert b.L <= 1.0 + 1e-9, "Fq2.mul: negated operand must be normalised"
+        assert b.V <= Fq2.NEGK - 1 + 1e-9, "Fq2.mul: operand value %.2f needs NEGK >= %d" % (b.V, math.ceil(b.V + 1))
+        bneg = B(float(Fq2.NEGK), 2.0)
+        col_ok([(a.L, b.L), (a.L, bneg.L)], 18)
+        c0 = (a.V * b.V + a.V * bneg.V) / RN + 1.0
+        c1 = 2 * a.V * b.V / RN + 1.0
+        return B(max(c0, c1), 1.0)
+
+    @staticmethod
+    def sqr(a):
+        assert a.L <= 1.0 + 1e-9
+        assert a.V <= Fq2.KS - 1 + 1e-9, "Fq2.sqr: value %.2f needs KS >= %d" % (a.V, math.ceil(a.V + 1))
+        aneg = B(float(Fq2.KS), 2.0)
+        col_ok([(a.L, a.L), (a.L, aneg.L)], 18)
+        c0 = (a.V * a.V + a.V * aneg.V) / RN + 1.0
+        col_ok([(2 * a.L, a.L)], 9)
+        c1 = 2 * a.V * a.V / RN + 1.0
+        return B(max(c0, c1), 1.0)
+
+    add = Fq.add
+    dbl = Fq.dbl
+    sub = Fq.sub
+    norm = Fq.norm
+
+
+# ---- the formulas of curve29.cuh, operation by operation ----------------------------------------------
+
+
+def madd(F, inv, k):
+    X1, Y1, ZZ1, ZZZ1 = (B(inv["x"], 1.0), B(inv["y"], 1.0), B(inv["z"], 1.0), B(inv["z"], 1.0))
+    X2 = B(1.0, 1.0)
+    Y2 = F.norm(F.sub(B(0.0, 0.0), B(1.0, 1.0), 2, 1))     # table y, possibly negated: 2N - y, normalised
+    U2 = F.mul(X2, ZZ1)
+    S2 = F.mul(Y2, ZZZ1)
+    P = F.norm(F.sub(U2, X1, k["KX"], 1))
+    R = F.norm(F.sub(S2, Y1, k["KY"], 1))
+    PP = F.sqr(P)
+    PPP = F.mul(P, PP)
+    Q = F.mul(X1, PP)
+    RR = F.sqr(R)
+    t = F.sub(RR, PPP, k["K1"], 1)
+    X3 = F.norm(F.sub(t, F.dbl(Q), k["K2"], 2))
+    d = F.norm(F.sub(Q, X3, k["KX"], 1))
+    Y3 = F.norm(F.sub(F.mul(R, d), F.mul(Y1, PPP), k["K1"], 1))
+    ZZ3 = F.mul(ZZ1, PP)
+    ZZZ3 = F.mul(ZZZ1, PPP)
+    return X3, Y3, ZZ3, ZZZ3
+
+
+def add(F, inv, k):
+    X1 = X2 = B(inv["x"], 1.0)
+    Y1 = Y2 = B(inv["y"], 1.0)
+    Z = B(inv["z"], 1.0)
+    U1 = F.mul(X1, Z); U2 = F.mul(X2, Z)
+    S1 = F.mul(Y1, Z); S2 = F.mul(Y2, Z)
+    P = F.norm(F.sub(U2, U1, k["K1"], 1))
+    R = F.norm(F.sub(S2, S1, k["K1"], 1))
+    PP = F.sqr(P)
+    PPP = F.mul(P, PP)
+    Q = F.mul(U1, PP)
+    RR = F.sqr(R)
+    t = F.sub(RR, PPP, k["K1"], 1)
+    X3 = F.norm(F.sub(t, F.dbl(Q), k["K2"], 2))
+    d = F.norm(F.sub(Q, X3, k["KX"], 1))
+    Y3 = F.norm(F.sub(F.mul(R, d), F.mul(S1, PPP), k["K1"], 1))
+    ZZ3 = F.mul(F.mul(Z, Z), PP)
+    ZZZ3 = F.mul(F.mul(Z, Z), PPP)
+    return X3, Y3, ZZ3, ZZZ3
+
+
+def dbl(F, inv, k, affine=False):
+    X1, Y1 = B(inv["x"], 1.0), B(inv["y"], 1.0)
+    if affine:
+        X1 = Y1 = B(1.0, 1.0)
+    Z = B(inv["z"], 1.0)
+    U = F.norm(F.dbl(Y1))
+    V = F.sqr(U)
+    W = F.mul(U, V)
+    S = F.mul(X1, V)
+    X2 = F.sqr(X1)
+    M = F.norm(F.add(F.dbl(X2), X2))
+    X3 = F.norm(F.sub(F.sqr(M), F.dbl(S), k["K2"], 2))
+    d = F.norm(F.sub(S, X3, k["KX"], 1))
+    Y3 = F.norm(F.sub(F.mul(M, d), F.mul(W, Y1), k["K1"], 1))
+    if affine:
+        return X3, Y3, V, W
+    return X3, Y3, F.mul(V, Z), F.mul(W, Z)
+
+
+def check(F, inv, k):
+    for name, fn in (("madd", lambda: madd(F, inv, k)), ("add", lambda: add(F, inv, k)), ("dbl", lambda: dbl(F, inv, k)),
+                     ("dbl_affine", lambda: dbl(F, inv, k, True))):
+        X3, Y3, ZZ3, ZZZ3 = fn()
+        ok = X3.V <= inv["x"] and Y3.V <= inv["y"] and ZZ3.V <= inv["z"] and ZZZ3.V <= inv["z"]
+        print("%-4s %-10s X3 %.2f (<=%g)  Y3 %.2f (<=%g)  ZZ3 %.3f ZZZ3 %.3f (<=%g)  %s" %
+              (F.name, name, X3.V, inv["x"], Y3.V, inv["y"], ZZ3.V, ZZZ3.V, inv["z"], "ok" if ok else "VIOLATED"))
+        assert ok
+    assert k["KX"] >= inv["x"] + 1 and k["KY"] >= inv["y"] + 1
+
+
+if __name__ == "__main__":
+    # invariant of stored accumulators (values in units of N) and the K constants of curve29.cuh
+    INV = dict(x=13.0, y=8.0, z=3.0)
+    KC = dict(KX=14, KY=9, K1=4, K2=6)
+    check(Fq, INV, KC)
+    check(Fq2, INV, KC)
+    print("all bounds hold; constants:", INV, KC)
