@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-uniform", action="store_true", help="skip the secondary uniform-witness measurement")
     ap.add_argument("--window", type=int, default=0)
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="proofs in flight per GPU (throughput mode): host threads x context proof_slots")
     return ap.parse_args()
 
 
@@ -87,7 +89,7 @@ def main():
         prover = cc.Prover(pk, cm, device=local_rank, window_bits=a.window, shard_rank=rank, shard_count=world)
         sp = ShardedProver(prover, dev)
     else:
-        prover = cc.Prover(pk, cm, device=local_rank, window_bits=a.window)
+        prover = cc.Prover(pk, cm, device=local_rank, window_bits=a.window, proof_slots=a.inflight)
     log("circuit loaded on GPU in %.1fs (D = %d)" % (time.time() - t0, prover.domain_size))
     w_dev = torch.from_numpy(w_np).to(dev)            # the witness is resident in HBM before timing starts
     torch.cuda.synchronize()
@@ -103,13 +105,24 @@ def main():
             return p, tm, (r, s)
         return prover.prove_dev(w_dev.data_ptr(), r, s), None, (r, s)
 
+    from concurrent.futures import ThreadPoolExecutor
+    inflight = 1 if sharded else max(1, a.inflight)
+    pool = ThreadPoolExecutor(max_workers=inflight) if inflight > 1 else None
+
+    def run_proofs(count):
+        """`count` proofs with fresh (r, s), up to `inflight` at a time (ctypes releases the GIL inside cg_prove_dev)"""
+        if pool is None:
+            for _ in range(count):
+                one_proof()
+            return
+        rs = [(rs_rng.randrange(R), rs_rng.randrange(R)) for _ in range(count)]
+        list(pool.map(lambda x: prover.prove_dev(w_dev.data_ptr(), x[0], x[1]), rs))
+
     def timed_run(steps, warmup):
-        for _ in range(warmup):
-            one_proof()
+        run_proofs(warmup)
         barrier_sync(world)
         t_start = time.perf_counter()
-        for _ in range(steps):
-            one_proof()
+        run_proofs(steps)
         torch.cuda.synchronize()
         barrier_sync(world)
         dt = time.perf_counter() - t_start
@@ -154,7 +167,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%s shape S21: D=2^%d, m=%d, M=%d, l=%d; witness=%s; pk from seeded trapdoor (GPU setup)" %
                    (a.shape, prover.domain_size.bit_length() - 1, m, M, l, a.witness),
-                   "mode": a.mode, "proofs_per_rank": a.steps, "inputs": "witness resident in HBM; (r,s) fresh per proof"},
+                   "mode": a.mode, "proofs_per_rank": a.steps, "proofs_in_flight_per_gpu": inflight,
+                   "inputs": "witness resident in HBM; (r,s) fresh per proof"},
     }
     if roof:
         out["roofline"] = roof
@@ -190,15 +204,23 @@ def main():
     if rank == 0 and world == 1 and not a.no_uniform and a.witness == "circom":
         cm_u, wu_np = wl.synthetic_circuit(0xC5E5CE47 + 4, l, m, M, 0.0, 3)
         pk_u = cc.generate_parameters_with_qap(cm_u, *trap)
-        pu = cc.Prover(pk_u, cm_u, device=local_rank, window_bits=a.window)
+        prover.close()
+        pu = cc.Prover(pk_u, cm_u, device=local_rank, window_bits=a.window, proof_slots=inflight)
         wu = torch.from_numpy(wu_np).to(dev)
         torch.cuda.synchronize()
-        ksteps = max(3, a.steps // 2)
-        for _ in range(2):
-            pu.prove_dev(wu.data_ptr(), rs_rng.randrange(R), rs_rng.randrange(R))
+        ksteps = max(inflight, a.steps // 2)
+
+        def run_u(count):
+            rs = [(rs_rng.randrange(R), rs_rng.randrange(R)) for _ in range(count)]
+            if pool is None:
+                for r_, s_ in rs:
+                    pu.prove_dev(wu.data_ptr(), r_, s_)
+            else:
+                list(pool.map(lambda x: pu.prove_dev(wu.data_ptr(), x[0], x[1]), rs))
+
+        run_u(inflight)
         t_start = time.perf_counter()
-        for _ in range(ksteps):
-            pu.prove_dev(wu.data_ptr(), rs_rng.randrange(R), rs_rng.randrange(R))
+        run_u(ksteps)
         torch.cuda.synchronize()
         du = time.perf_counter() - t_start
         _, tmu = pu.prove_dev(wu.data_ptr(), 5, 7, timings=True)

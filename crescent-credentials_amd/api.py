@@ -50,7 +50,7 @@ class _CgCsr(C.Structure):
 
 class _CgOptions(C.Structure):
     _fields_ = [("device", C.c_int32), ("window_bits", C.c_int32), ("shard_rank", C.c_int32),
-                ("shard_count", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("shard_count", C.c_int32), ("proof_slots", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class CgTimings(C.Structure):
@@ -261,12 +261,14 @@ class Prover:
     """A circuit loaded on one GPU (cg_ctx): proving key tables + matrices resident in HBM."""
 
     def __init__(self, pk: ProvingKey, matrices: ConstraintMatrices, device: int = -1, window_bits: int = 0,
-                 shard_rank: int = 0, shard_count: int = 1):
+                 shard_rank: int = 0, shard_count: int = 1, proof_slots: int = 1):
         L = lib()
         self.num_inputs = matrices.num_instance_variables
         self.num_constraints = matrices.num_constraints
         self.num_variables = matrices.num_variables
-        opt = _CgOptions(device=device, window_bits=window_bits, shard_rank=shard_rank, shard_count=shard_count)
+        opt = _CgOptions(device=device, window_bits=window_bits, shard_rank=shard_rank, shard_count=shard_count,
+                         proof_slots=proof_slots)
+        self.proof_slots = max(1, proof_slots)
         cpk = pk._c()
         abc, _keep = matrices._c()
         h = C.c_void_p()

@@ -15,8 +15,8 @@
 //              buckets are (circom witnesses are dominated by 0/1 wires).  A lane flushes runs that
 //              lie wholly inside its segment straight to the bucket array and hands the first/last
 //              run up as a partial; partials are reduced by the same kernel recursively.
-//   reduce   : Σ (b+1)·S_b by chunked running sums, a small scalar multiple per chunk, and a tree
-//              sum.
+//   reduce   : Σ (b+1)·S_b through row and column sums of the bucket matrix (all tree-parallel) and two
+//              short weighted sums.
 // All curve arithmetic here runs on the lazy 29-bit-limb representation (field29.cuh / curve29.cuh).
 #include "msm.hpp"
 
@@ -317,40 +317,75 @@ __global__ void __launch_bounds__(256) k_accum_xyzz(const uint32_t* __restrict__
 
 // ---------------------------------------------------------------------------------------------
 // bucket reduction: per window, Σ_b (b+1)·S_b
+//
+// The buckets of a window are viewed as an R x C matrix (b = r·C + col, C = 2^cb):
+//     Σ_b (b+1)·S_b = C · Σ_r r·Row_r  +  Σ_col (col+1)·Col_col,    Row_r = Σ_col S[r,col],  Col_col = Σ_r S[r,col]
+// Row and column sums are plain sums - 2 additions per bucket like the textbook running sum, but fully
+// parallel (tree depth, no serial chain over the buckets) - and the two weighted sums that remain have only
+// R and C terms, each handled as a small scalar multiple followed by a tree sum.
 // ---------------------------------------------------------------------------------------------
-// thread t of window w covers buckets [t*K, t*K+K) of that window:
-//   out = Σ (b - tK + 1)·S_b + (tK)·Σ S_b
+// out[w][o][i] = Σ_{k<cnt} in[w][o·in_o_stride + k·k_stride + i],  i < n_inner  (accumulator units)
 template <class F29T>
-__global__ void __launch_bounds__(256) k_reduce_chunks(const uint32_t* __restrict__ bucket_sums, uint32_t nb_per_window,
-                                                       uint32_t K, uint32_t chunks_per_window, uint32_t total_chunks,
-                                                       uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_sum_axis(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                  uint32_t n_o, uint32_t n_inner, uint32_t cnt, uint32_t in_o_stride,
+                                                  uint32_t k_stride, uint32_t in_win_stride, uint32_t out_win_stride) {
     constexpr int ACC = Words29<F29T>::ACC;
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total_chunks) return;
-    uint32_t w = g / chunks_per_window, t = g % chunks_per_window;
-    const uint32_t* S = bucket_sums + (size_t)w * nb_per_window * ACC;
-    uint32_t lo = t * K;
-    uint32_t hi = lo + K < nb_per_window ? lo + K : nb_per_window;
-    XYZZ29<F29T> run, acc;
-    bool run_inf = true, acc_inf = true;
-    for (uint32_t b = hi; b-- > lo;) {
+    if (g >= n_o * n_inner) return;
+    const uint32_t w = blockIdx.y;
+    uint32_t o = g / n_inner, i = g % n_inner;
+    const uint32_t* src = in + ((size_t)w * in_win_stride + (size_t)o * in_o_stride + i) * ACC;
+    XYZZ29<F29T> acc;
+    bool inf = true;
+    for (uint32_t k = 0; k < cnt; ++k) {
         XYZZ29<F29T> q;
-        bool qinf = load_acc(S + (size_t)b * ACC, q);
-        add29(run, run_inf, q, qinf);
-        add29(acc, acc_inf, run, run_inf);
+        bool qinf = load_acc(src + (size_t)k * k_stride * ACC, q);
+        add29(acc, inf, q, qinf);
     }
-    if (lo != 0 && !run_inf) {
-        // (lo)·run by MSB-first double-and-add; lo < 2^22
-        XYZZ29<F29T> m = run;
-        bool m_inf = false;
-        int top = 31 - __clz(lo);
-        for (int bit = top - 1; bit >= 0; --bit) {
-            if (!m_inf) m = dbl29(m);
-            if ((lo >> bit) & 1u) add29(m, m_inf, run, false);
+    store_acc(out + ((size_t)w * out_win_stride + g) * ACC, acc, inf);
+}
+
+// out[w][blk] = Σ_{i in block} (i + offset)·in[w][i]   (weights < 2^22; double-and-add, then an LDS tree)
+template <class F29T>
+__global__ void __launch_bounds__(256) k_weighted_sum(const uint32_t* __restrict__ in, uint32_t n, uint32_t offset,
+                                                      uint32_t in_win_stride, uint32_t* __restrict__ out, uint32_t out_win_stride) {
+    constexpr int ACC = Words29<F29T>::ACC;
+    extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
+    const uint32_t w = blockIdx.y;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    XYZZ29<F29T> acc;
+    bool inf = true;
+    if (i < n) {
+        XYZZ29<F29T> x;
+        bool xinf = load_acc(in + ((size_t)w * in_win_stride + i) * ACC, x);
+        uint32_t wt = i + offset;
+        if (!xinf && wt != 0) {
+            acc = x;
+            inf = false;
+            int top = 31 - __clz(wt);
+            for (int bit = top - 1; bit >= 0; --bit) {
+                if (!inf) acc = dbl29(acc);
+                if ((wt >> bit) & 1u) add29(acc, inf, x, false);
+            }
         }
-        add29(acc, acc_inf, m, m_inf);
     }
-    store_acc(out + (size_t)g * ACC, acc, acc_inf);
+    store_acc(sm + (size_t)threadIdx.x * ACC, acc, inf);
+    __syncthreads();
+    for (uint32_t s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            XYZZ29<F29T> a, b;
+            bool ai = load_acc(sm + (size_t)threadIdx.x * ACC, a);
+            bool bi = load_acc(sm + (size_t)(threadIdx.x + s) * ACC, b);
+            add29(a, ai, b, bi);
+            store_acc(sm + (size_t)threadIdx.x * ACC, a, ai);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        XYZZ29<F29T> a;
+        bool ai = load_acc(sm, a);
+        store_acc(out + ((size_t)w * out_win_stride + blockIdx.x) * ACC, a, ai);
+    }
 }
 
 // out[w*out_per_window + blk] = Σ of this block's slice of in[w*in_per_window ...]
@@ -394,7 +429,8 @@ __global__ void __launch_bounds__(256) k_sum_points(const uint32_t* __restrict__
 static constexpr uint32_t ACC_TARGET_THREADS = 256u * 4u * 4u * 64u * 2u;  // CUs x SIMDs x waves x lanes x rounds
 static constexpr uint32_t ACC_MIN_L = 16;
 static constexpr uint32_t ACC_LEVEL_L = 8;   // segment length of the partial-combining levels
-static constexpr uint32_t RED_K = 16;        // buckets per thread in the running-sum reduction
+static constexpr uint32_t RED_F_BIG = 4;     // fan-in of a row/column-sum step while the step still fills the GPU ...
+static constexpr uint32_t RED_F = 2;         // ... and below that (latency-bound: minimise the depth)
 
 static uint32_t level1_L(uint64_t N) {
     uint64_t L = (N + ACC_TARGET_THREADS - 1) / ACC_TARGET_THREADS;
@@ -429,12 +465,18 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
     part_keys_a.alloc(pa); part_pts_a.alloc(pa * ACC);
     part_keys_b.alloc(pb); part_pts_b.alloc(pb * ACC);
     const uint32_t wins = b->precomputed ? 1u : (uint32_t)W;
-    uint32_t chunks = ceil_div(nb, RED_K);
-    red_a.alloc((uint64_t)chunks * wins * ACC);
-    red_b.alloc(((uint64_t)ceil_div(chunks, 256) * wins + wins) * ACC);
-    result.alloc((size_t)wins * ACC);
+    // scratch of the bucket reduction: the first row/column-sum step leaves nb/RED_F (+ slack) accumulators
+    uint64_t red_elems = (uint64_t)(nb / 2 + 2048) * wins;
+    red_a.alloc(red_elems * ACC);
+    red_b.alloc(red_elems * ACC);
+    {
+        const int cbits = (b->c - 1 + 1) / 2 > 10 ? 10 : (b->c - 1 + 1) / 2;
+        rows_buf.alloc((size_t)(nb >> cbits) * wins * ACC);
+        cols_buf.alloc((size_t)(1u << cbits) * wins * ACC);
+    }
+    result.alloc((size_t)wins * 2 * ACC);      // per window: rows part, columns part
     h_count.alloc(1);
-    h_result.alloc((size_t)wins * ACC);
+    h_result.alloc((size_t)wins * 2 * ACC);
     CG_HIP(hipEventCreateWithFlags(&ev_count, hipEventDisableTiming));
     for (auto& e : ev_t) CG_HIP(hipEventCreate(&e));
 }
@@ -517,26 +559,64 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
             from_a = !from_a;
         }
     }
-    // bucket reduction
-    const uint32_t chunks = ceil_div(nb, RED_K);
-    const uint32_t total_chunks = chunks * wins;
-    k_reduce_chunks<F29T><<<ceil_div(total_chunks, 256), 256, 0, st>>>(bucket_sums.p, nb, RED_K, chunks, total_chunks, red_a.p);
-    CG_KERNEL_CHECK();
-    uint32_t per_win = chunks;
-    uint32_t* src = red_a.p;
-    uint32_t* dst = red_b.p;
-    while (true) {
-        uint32_t blocks = ceil_div(per_win, 256);
-        uint32_t threads = 256;
-        if (per_win < 256) { threads = 64; while (threads < per_win) threads <<= 1; }
-        uint32_t* out = (blocks == 1) ? result.p : dst;
-        k_sum_points<F29T><<<dim3(blocks, wins), threads, (size_t)threads * ACC * 4, st>>>(src, per_win, out, blocks == 1 ? 1 : blocks);
-        CG_KERNEL_CHECK();
-        if (blocks == 1) break;
-        per_win = blocks;
-        uint32_t* tswap = src; src = dst; dst = tswap;
+    // bucket reduction (see the comment above k_sum_axis)
+    {
+        const int cbits = (bases->c - 1 + 1) / 2 > 10 ? 10 : (bases->c - 1 + 1) / 2;
+        const uint32_t C = 1u << cbits, R = nb / C;
+        // plain sum of `cnt_total` accumulators per (o, i): repeated fan-in RED_F steps over the middle axis
+        auto sum_axis = [&](const uint32_t* in, uint32_t in_win_stride, uint32_t O, uint32_t A, uint32_t I, uint32_t* out_final,
+                            uint32_t out_final_win_stride) {
+            // tensor [O][A][I]; returns [O][I] in out_final
+            const uint32_t* src = in;
+            uint32_t src_win = in_win_stride;
+            bool to_a = true;
+            if (A == 1) {   // nothing to add: copy through a 1-term sum
+                k_sum_axis<F29T><<<dim3(ceil_div((uint64_t)O * I, 256), wins), 256, 0, st>>>(src, out_final, O, I, 1, I, I, src_win, out_final_win_stride);
+                CG_KERNEL_CHECK();
+                return;
+            }
+            while (A > 1) {
+                uint32_t f = ((uint64_t)O * A * I / RED_F_BIG >= 131072 && A % RED_F_BIG == 0) ? RED_F_BIG : RED_F;
+                if (f > A) f = A;
+                uint32_t A2 = A / f;
+                const bool last = (A2 == 1);
+                uint32_t* dst = last ? out_final : (to_a ? red_a.p : red_b.p);
+                uint32_t dst_win = last ? out_final_win_stride : O * A2 * I;
+                // [O][f][A2][I]: out[o][a2*I + i] = Σ_k in[o*A*I + k*A2*I + a2*I + i]
+                k_sum_axis<F29T><<<dim3(ceil_div((uint64_t)O * A2 * I, 256), wins), 256, 0, st>>>(src, dst, O, A2 * I, f, A * I, A2 * I, src_win, dst_win);
+                CG_KERNEL_CHECK();
+                src = dst;
+                src_win = dst_win;
+                A = A2;
+                to_a = !to_a;
+            }
+        };
+        // rows: [R][C][1] -> Row[R];  columns: [1][R][C] -> Col[C]
+        uint32_t* rows = rows_buf.p;
+        uint32_t* cols = cols_buf.p;
+        sum_axis(bucket_sums.p, nb, R, C, 1, rows, R);
+        sum_axis(bucket_sums.p, nb, 1, R, C, cols, C);
+        // weighted sums: Σ_r r·Row_r and Σ_col (col+1)·Col_col, each to one point per window
+        auto weighted = [&](const uint32_t* in, uint32_t n, uint32_t offset, uint32_t slot) {
+            uint32_t blocks = ceil_div(n, 256);
+            uint32_t threads = 256;
+            if (n < 256) { threads = 64; while (threads < n) threads <<= 1; }
+            uint32_t* tmp = (slot == 0) ? red_a.p : red_b.p;
+            uint32_t* dst = (blocks == 1) ? result.p + (size_t)slot * ACC : tmp;
+            uint32_t dst_win = (blocks == 1) ? 2 : blocks;
+            k_weighted_sum<F29T><<<dim3(blocks, wins), threads, (size_t)threads * ACC * 4, st>>>(in, n, offset, n, dst, dst_win);
+            CG_KERNEL_CHECK();
+            if (blocks > 1) {
+                uint32_t t2 = 64;
+                while (t2 < blocks) t2 <<= 1;   // blocks <= 2^22 / 2^10 / 256 <= 16
+                k_sum_points<F29T><<<dim3(1, wins), t2, (size_t)t2 * ACC * 4, st>>>(tmp, blocks, result.p + (size_t)slot * ACC, 2);
+                CG_KERNEL_CHECK();
+            }
+        };
+        weighted(rows, R, 0, 0);
+        weighted(cols, C, 1, 1);
     }
-    CG_HIP(hipMemcpyAsync(h_result.p, result.p, (size_t)wins * ACC * 4, hipMemcpyDeviceToHost, st));
+    CG_HIP(hipMemcpyAsync(h_result.p, result.p, (size_t)wins * 2 * ACC * 4, hipMemcpyDeviceToHost, st));
     CG_HIP(hipEventRecord(ev_t[5], st));
 }
 
@@ -597,15 +677,26 @@ static XYZZ<F> xyzz_from_words(const uint32_t* w, int acc_words) {
     return r;
 }
 
+// one window's sum: 2^cbits · (rows part) + (columns part)
+template <class F>
+static XYZZ<F> window_value(const uint32_t* two_acc, int acc_words, int cbits) {
+    XYZZ<F> rows = xyzz_from_words<F>(two_acc, acc_words);
+    XYZZ<F> cols = xyzz_from_words<F>(two_acc + acc_words, acc_words);
+    for (int k = 0; k < cbits; ++k) rows = dbl(rows);
+    add(rows, cols);
+    return rows;
+}
+
 template <class F>
 XYZZ<F> MsmEngine<F>::value() const {
-    if (bases->precomputed) return xyzz_from_words<F>(h_result.p, ACC);
+    const int cbits = (bases->c - 1 + 1) / 2 > 10 ? 10 : (bases->c - 1 + 1) / 2;
+    if (bases->precomputed) return window_value<F>(h_result.p, ACC, cbits);
     // Horner over the windows: Σ_j 2^(c j) S_j
     const int W = bases->W, c = bases->c;
     XYZZ<F> acc = XYZZ<F>::inf();
     for (int j = W - 1; j >= 0; --j) {
         for (int k = 0; k < c; ++k) acc = dbl(acc);
-        add(acc, xyzz_from_words<F>(h_result.p + (size_t)j * ACC, ACC));
+        add(acc, window_value<F>(h_result.p + (size_t)j * 2 * ACC, ACC, cbits));
     }
     return acc;
 }

@@ -44,6 +44,7 @@ struct MsmEngine {
     DevBuf<uint32_t> part_keys_a, part_keys_b;
     DevBuf<uint32_t> part_pts_a, part_pts_b;
     DevBuf<uint32_t> red_a, red_b;
+    DevBuf<uint32_t> rows_buf, cols_buf;   // row / column sums of the bucket matrix (bucket reduction)
     DevBuf<uint32_t> result;          // W_keyspace accumulators (1 when precomputed)
     PinnedBuf<uint32_t> h_count;
     PinnedBuf<uint32_t> h_result;

@@ -5,12 +5,14 @@
 // which algebraic order), re-laid-out for one MI355X: the proving key lives in HBM as per-window
 // base tables, the five MSMs and the witness map run on separate HIP streams, and only the few
 // scalar multiplications by r, s and the final additions run on the host.
+#include <condition_variable>
 #include <memory>
 #include <mutex>
 #include <chrono>
 
 #include "msm.hpp"
 #include "ntt.hpp"
+#include "wmap29.hpp"
 
 namespace cg {
 
@@ -106,9 +108,27 @@ using namespace cg;
 // ---------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------
+// Per-proof working set: everything a proof in flight writes.  A context owns `n_slots` of them so that
+// several proofs can overlap on one GPU (the latency-bound tails of one proof hide under the bulk kernels
+// of another); the key tables, matrices and NTT tables are shared and read-only.
+struct ProofSlot {
+    std::mutex busy;
+    MsmEngine<Fq> eh, el, ea, eb1;
+    MsmEngine<Fq2> eb2;
+    DevBuf<Fr> w_canon, h_canon;
+    Wm29Buffers wm;
+    hipStream_t st[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // 0: witness map + h, 1: l, 2: a, 3: b1, 4: b2
+    hipEvent_t ev_w = nullptr;
+    hipEvent_t ev_t[2] = {nullptr, nullptr};
+    ~ProofSlot() {
+        for (auto& s : st) if (s) (void)hipStreamDestroy(s);
+        if (ev_w) (void)hipEventDestroy(ev_w);
+        for (auto& e : ev_t) if (e) (void)hipEventDestroy(e);
+    }
+};
+
 struct cg_ctx {
     int device = 0;
-    std::mutex mu;
     uint64_t l = 0, m = 0, M = 0, D = 0;
     int logD = 0;
     int shard_rank = 0, shard_count = 1;
@@ -119,19 +139,33 @@ struct cg_ctx {
     Range rh, rl, ra;   // h: [0, D-1), l: [0, M-l), a/b: [0, M-1)
     MsmBases<Fq> bh, bl, ba, bb1;
     MsmBases<Fq2> bb2;
-    MsmEngine<Fq> eh, el, ea, eb1;
-    MsmEngine<Fq2> eb2;
     DevCsr A, B, C;
+    Csr29 dA, dB, dC;
     NttDomain dom;
-    DevBuf<Fr> w_canon, w_mont, va, vb, vc, h_canon;
-    hipStream_t st[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // 0: witness map + h, 1: l, 2: a, 3: b1, 4: b2
-    hipEvent_t ev_w = nullptr;
-    hipEvent_t ev_t[8] = {nullptr};
-    ~cg_ctx() {
-        for (auto& s : st) if (s) (void)hipStreamDestroy(s);
-        if (ev_w) (void)hipEventDestroy(ev_w);
-        for (auto& e : ev_t) if (e) (void)hipEventDestroy(e);
+    Wm29Domain wdom;
+    std::vector<std::unique_ptr<ProofSlot>> slots;
+    std::mutex pick_mu;
+    std::condition_variable pick_cv;
+    // blocks until a slot is free; returns it locked
+    ProofSlot* acquire() {
+        std::unique_lock<std::mutex> lk(pick_mu);
+        for (;;) {
+            for (auto& sp : slots)
+                if (sp->busy.try_lock()) return sp.get();
+            pick_cv.wait(lk);
+        }
     }
+    void release(ProofSlot* sl) {
+        sl->busy.unlock();
+        std::lock_guard<std::mutex> lk(pick_mu);
+        pick_cv.notify_one();
+    }
+};
+struct SlotGuard {
+    cg_ctx* c;
+    ProofSlot* s;
+    explicit SlotGuard(cg_ctx* ctx) : c(ctx), s(ctx->acquire()) {}
+    ~SlotGuard() { c->release(s); }
 };
 
 namespace cg {
@@ -169,7 +203,7 @@ extern "C" int cg_init(int n_devices, const int* device_ids) {
 extern "C" uint64_t cg_domain_size(const cg_ctx* ctx) { return ctx ? ctx->D : 0; }
 
 template <class F>
-static void load_query(MsmBases<F>& bases, MsmEngine<F>& eng, const uint8_t* bytes, uint32_t form, uint64_t first,
+static void load_query(MsmBases<F>& bases, const uint8_t* bytes, uint32_t form, uint64_t first,
                        uint64_t count, int window_bits, hipStream_t st) {
     constexpr size_t PT = sizeof(Affine<F>);
     DevBuf<Affine<F>> tmp(count ? count : 1);
@@ -177,7 +211,6 @@ static void load_query(MsmBases<F>& bases, MsmEngine<F>& eng, const uint8_t* byt
     int c = window_bits > 0 ? window_bits : msm_default_window(count ? count : 1, true);
     bases.build(tmp.p, count, c, true, st);
     CG_HIP(hipStreamSynchronize(st));
-    eng.init(&bases);
 }
 
 extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_csr abc[3], uint64_t num_inputs,
@@ -206,9 +239,10 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         c->shard_rank = (opt && c->shard_count > 1) ? opt->shard_rank : 0;
         if (c->shard_rank < 0 || c->shard_rank >= c->shard_count) return fail(CG_ERR_INVALID_ARGUMENT, "shard_rank out of range");
         const int wb = opt ? opt->window_bits : 0;
-        for (auto& s : c->st) CG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        CG_HIP(hipEventCreateWithFlags(&c->ev_w, hipEventDisableTiming));
-        for (auto& e : c->ev_t) CG_HIP(hipEventCreate(&e));
+        int n_slots = (opt && opt->proof_slots > 0) ? opt->proof_slots : 1;
+        if (n_slots > 16) n_slots = 16;
+        hipStream_t s0;
+        CG_HIP(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking));
         const uint32_t form = pk->coord_form;
         c->alpha_g1 = g1_import(pk->alpha_g1, form);
         c->beta_g1 = g1_import(pk->beta_g1, form);
@@ -221,19 +255,32 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         c->rh = shard_range(D - 1, c->shard_rank, c->shard_count);
         c->rl = shard_range(M - l, c->shard_rank, c->shard_count);
         c->ra = shard_range(M - 1, c->shard_rank, c->shard_count);
-        hipStream_t s0 = c->st[0];
-        load_query<Fq>(c->bh, c->eh, pk->h_query, form, c->rh.lo, c->rh.hi - c->rh.lo, wb, s0);
-        load_query<Fq>(c->bl, c->el, pk->l_query, form, c->rl.lo, c->rl.hi - c->rl.lo, wb, s0);
-        load_query<Fq>(c->ba, c->ea, pk->a_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, s0);    // query[1..] (prover.rs:266)
-        load_query<Fq>(c->bb1, c->eb1, pk->b_g1_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, s0);
-        load_query<Fq2>(c->bb2, c->eb2, pk->b_g2_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, s0);
+        load_query<Fq>(c->bh, pk->h_query, form, c->rh.lo, c->rh.hi - c->rh.lo, wb, s0);
+        load_query<Fq>(c->bl, pk->l_query, form, c->rl.lo, c->rl.hi - c->rl.lo, wb, s0);
+        load_query<Fq>(c->ba, pk->a_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, s0);    // query[1..] (prover.rs:266)
+        load_query<Fq>(c->bb1, pk->b_g1_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, s0);
+        load_query<Fq2>(c->bb2, pk->b_g2_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, s0);
         c->A.upload(abc[0], m, M);
         c->B.upload(abc[1], m, M);
         c->C.upload(abc[2], m, M);
         c->dom.build(logD, true, s0);
-        c->w_canon.alloc(M); c->w_mont.alloc(M);
-        c->va.alloc(D); c->vb.alloc(D); c->vc.alloc(D); c->h_canon.alloc(D);
+        c->wdom.build(c->dom, s0);
+        c->dA.build(c->A, s0); c->dB.build(c->B, s0); c->dC.build(c->C, s0);
         CG_HIP(hipStreamSynchronize(s0));
+        (void)hipStreamDestroy(s0);
+        // the saturated-form tables were only the source of the packed ones
+        c->dom.tw_fwd.release(); c->dom.tw_inv.release(); c->dom.coset_br.release(); c->dom.icoset_br.release();
+        c->A.dict.release(); c->B.dict.release(); c->C.dict.release();
+        for (int k = 0; k < n_slots; ++k) {
+            std::unique_ptr<ProofSlot> sl(new ProofSlot());
+            for (auto& s : sl->st) CG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+            CG_HIP(hipEventCreateWithFlags(&sl->ev_w, hipEventDisableTiming));
+            for (auto& e : sl->ev_t) CG_HIP(hipEventCreate(&e));
+            sl->eh.init(&c->bh); sl->el.init(&c->bl); sl->ea.init(&c->ba); sl->eb1.init(&c->bb1); sl->eb2.init(&c->bb2);
+            sl->w_canon.alloc(M); sl->h_canon.alloc(D);
+            sl->wm.alloc(M, D);
+            c->slots.push_back(std::move(sl));
+        }
         *out = c.release();
         return CG_OK;
     } catch (...) {
@@ -252,23 +299,8 @@ extern "C" void cg_circuit_free(cg_ctx* ctx) {
 // witness map on stream st: w_mont must be ready; result h (canonical, natural order) in c->h_canon
 // (LibsnarkReduction::witness_map_from_matrices, r1cs_to_qap.rs:150-213)
 // ---------------------------------------------------------------------------------------------
-static void run_witness_map(cg_ctx* c, hipStream_t st) {
-    const uint64_t D = c->D, m = c->m, l = c->l;
-    CG_HIP(hipMemsetAsync(c->va.p, 0, D * sizeof(Fr), st));
-    CG_HIP(hipMemsetAsync(c->vb.p, 0, D * sizeof(Fr), st));
-    CG_HIP(hipMemsetAsync(c->vc.p, 0, D * sizeof(Fr), st));
-    spmv(c->A, c->w_mont.p, c->va.p, st);   // :164-171
-    spmv(c->B, c->w_mont.p, c->vb.p, st);
-    spmv(c->C, c->w_mont.p, c->vc.p, st);   // :191-196
-    CG_HIP(hipMemcpyAsync(c->va.p + m, c->w_mont.p, l * sizeof(Fr), hipMemcpyDeviceToDevice, st));  // :173-177
-    Fr* v[3] = {c->va.p, c->vb.p, c->vc.p};
-    for (int k = 0; k < 3; ++k) {
-        ntt_dif(v[k], c->dom, true, nullptr, st);                  // ifft (unscaled, bit-reversed)  :179-180,198
-        ntt_dit(v[k], c->dom, false, c->dom.coset_br.p, st);       // x g^i / D, then fft on the coset :182-185,199
-    }
-    qap_pointwise(c->va.p, c->vb.p, c->vc.p, c->va.p, c->dom.vanishing_inv, D, st);   // :187,201-208
-    ntt_dif(c->va.p, c->dom, true, nullptr, st);                   // coset ifft :210 ...
-    ntt_unbitrev_scale(c->va.p, c->h_canon.p, c->dom.icoset_br.p, c->logD, true, st);  // ... x g^-i / D, natural order, canonical
+static void run_witness_map(cg_ctx* c, ProofSlot* S, const Fr* w_canon_dev, hipStream_t st) {
+    wm29_run(c->wdom, c->A, c->B, c->C, c->dA, c->dB, c->dC, S->wm, w_canon_dev, c->M, c->m, c->l, S->h_canon.p, st);
 }
 
 struct Partials {
@@ -282,70 +314,66 @@ static float ev_ms(hipEvent_t a, hipEvent_t b) {
     return ms;
 }
 
-static int prove_partial_impl(cg_ctx* c, const void* assignment, bool on_device, bool skip_b1, Partials& P, cg_timings* tm) {
+static int prove_partial_impl(cg_ctx* c, ProofSlot* S, const void* assignment, bool on_device, bool skip_b1, Partials& P, cg_timings* tm) {
     CG_HIP(hipSetDevice(c->device));
     auto t0 = std::chrono::steady_clock::now();
     const uint64_t M = c->M, l = c->l;
-    hipStream_t s0 = c->st[0];
+    hipStream_t s0 = S->st[0];
     float upload_ms = 0;
     const Fr* w_dev;
     if (on_device) {
         w_dev = (const Fr*)assignment;
     } else {
-        CG_HIP(hipMemcpyAsync(c->w_canon.p, assignment, M * 32, hipMemcpyHostToDevice, s0));
+        CG_HIP(hipMemcpyAsync(S->w_canon.p, assignment, M * 32, hipMemcpyHostToDevice, s0));
         if (tm) {
             CG_HIP(hipStreamSynchronize(s0));
             upload_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
-        w_dev = c->w_canon.p;
+        w_dev = S->w_canon.p;
     }
-    CG_HIP(hipEventRecord(c->ev_w, s0));
-    for (int i = 1; i < 5; ++i) CG_HIP(hipStreamWaitEvent(c->st[i], c->ev_w, 0));
+    CG_HIP(hipEventRecord(S->ev_w, s0));
+    for (int i = 1; i < 5; ++i) CG_HIP(hipStreamWaitEvent(S->st[i], S->ev_w, 0));
     // assignment-driven MSMs: operands (prover.rs:70-74, 84-89, 265-266)
     //   l: l_query[i] x w[l + i];  a, b1, b2: query[1 + i] x w[1 + i]
-    if (tm) CG_HIP(hipEventRecord(c->ev_t[2], c->st[1]));
-    c->el.digits(w_dev + l + c->rl.lo, c->rl.hi - c->rl.lo, c->st[1]);
-    c->ea.digits(w_dev + 1 + c->ra.lo, c->ra.hi - c->ra.lo, c->st[2]);
-    if (!skip_b1) c->eb1.digits(w_dev + 1 + c->ra.lo, c->ra.hi - c->ra.lo, c->st[3]);
-    c->eb2.digits(w_dev + 1 + c->ra.lo, c->ra.hi - c->ra.lo, c->st[4]);
+    S->el.digits(w_dev + l + c->rl.lo, c->rl.hi - c->rl.lo, S->st[1]);
+    S->ea.digits(w_dev + 1 + c->ra.lo, c->ra.hi - c->ra.lo, S->st[2]);
+    if (!skip_b1) S->eb1.digits(w_dev + 1 + c->ra.lo, c->ra.hi - c->ra.lo, S->st[3]);
+    S->eb2.digits(w_dev + 1 + c->ra.lo, c->ra.hi - c->ra.lo, S->st[4]);
     // witness map, then h digits, on stream 0
-    if (tm) CG_HIP(hipEventRecord(c->ev_t[0], s0));
-    fr_to_mont(w_dev, c->w_mont.p, M, s0);
-    run_witness_map(c, s0);
-    if (tm) CG_HIP(hipEventRecord(c->ev_t[1], s0));
-    c->eh.digits(c->h_canon.p + c->rh.lo, c->rh.hi - c->rh.lo, s0);
+    if (tm) CG_HIP(hipEventRecord(S->ev_t[0], s0));
+    run_witness_map(c, S, w_dev, s0);
+    if (tm) CG_HIP(hipEventRecord(S->ev_t[1], s0));
+    S->eh.digits(S->h_canon.p + c->rh.lo, c->rh.hi - c->rh.lo, s0);
     // second phase (each waits for its own entry count)
-    c->el.accumulate(c->st[1]);
-    if (tm) CG_HIP(hipEventRecord(c->ev_t[3], c->st[1]));
-    c->ea.accumulate(c->st[2]);
-    if (!skip_b1) c->eb1.accumulate(c->st[3]);
-    c->eb2.accumulate(c->st[4]);
-    c->eh.accumulate(s0);
-    if (tm) CG_HIP(hipEventRecord(c->ev_t[4], s0));
-    for (int i = 0; i < 5; ++i) CG_HIP(hipStreamSynchronize(c->st[i]));
-    P.h = to_affine(c->eh.value());
-    P.l = to_affine(c->el.value());
-    P.a = to_affine(c->ea.value());
-    P.b1 = skip_b1 ? G1Affine::inf() : to_affine(c->eb1.value());
-    P.b2 = to_affine(c->eb2.value());
+    S->el.accumulate(S->st[1]);
+    S->ea.accumulate(S->st[2]);
+    if (!skip_b1) S->eb1.accumulate(S->st[3]);
+    S->eb2.accumulate(S->st[4]);
+    S->eh.accumulate(s0);
+    for (int i = 0; i < 5; ++i) CG_HIP(hipStreamSynchronize(S->st[i]));
+    P.h = to_affine(S->eh.value());
+    P.l = to_affine(S->el.value());
+    P.a = to_affine(S->ea.value());
+    P.b1 = skip_b1 ? G1Affine::inf() : to_affine(S->eb1.value());
+    P.b2 = to_affine(S->eb2.value());
     if (tm) {
         memset(tm, 0, sizeof(*tm));
         tm->upload_ms = upload_ms;
-        tm->witness_map_ms = ev_ms(c->ev_t[0], c->ev_t[1]);
-        tm->msm_h_ms = c->eh.ms_total();
-        tm->msm_l_ms = c->el.ms_total();
-        tm->msm_a_ms = c->ea.ms_total();
-        tm->msm_b1_ms = skip_b1 ? 0.f : c->eb1.ms_total();
-        tm->msm_b2_ms = c->eb2.ms_total();
-        tm->accum_g1_ms = c->eh.ms_accum() + c->el.ms_accum() + c->ea.ms_accum() + (skip_b1 ? 0.f : c->eb1.ms_accum());
-        tm->accum_g2_ms = c->eb2.ms_accum();
-        tm->sort_ms = c->eh.ms_sort() + c->el.ms_sort() + c->ea.ms_sort() + (skip_b1 ? 0.f : c->eb1.ms_sort()) + c->eb2.ms_sort();
-        tm->entries_g1 = (uint64_t)c->eh.n_entries + c->el.n_entries + c->ea.n_entries + (skip_b1 ? 0 : c->eb1.n_entries);
-        tm->entries_g2 = c->eb2.n_entries;
-        tm->accum_g1_launches = (c->eh.n_entries != 0) + (c->el.n_entries != 0) + (c->ea.n_entries != 0) + (!skip_b1 && c->eb1.n_entries != 0);
-        tm->accum_g2_launches = c->eb2.n_entries != 0;
-        tm->msm_g1_pairs = c->eh.n_scalars + c->el.n_scalars + c->ea.n_scalars + (skip_b1 ? 0 : c->eb1.n_scalars);
-        tm->msm_g2_pairs = c->eb2.n_scalars;
+        tm->witness_map_ms = ev_ms(S->ev_t[0], S->ev_t[1]);
+        tm->msm_h_ms = S->eh.ms_total();
+        tm->msm_l_ms = S->el.ms_total();
+        tm->msm_a_ms = S->ea.ms_total();
+        tm->msm_b1_ms = skip_b1 ? 0.f : S->eb1.ms_total();
+        tm->msm_b2_ms = S->eb2.ms_total();
+        tm->accum_g1_ms = S->eh.ms_accum() + S->el.ms_accum() + S->ea.ms_accum() + (skip_b1 ? 0.f : S->eb1.ms_accum());
+        tm->accum_g2_ms = S->eb2.ms_accum();
+        tm->sort_ms = S->eh.ms_sort() + S->el.ms_sort() + S->ea.ms_sort() + (skip_b1 ? 0.f : S->eb1.ms_sort()) + S->eb2.ms_sort();
+        tm->entries_g1 = (uint64_t)S->eh.n_entries + S->el.n_entries + S->ea.n_entries + (skip_b1 ? 0 : S->eb1.n_entries);
+        tm->entries_g2 = S->eb2.n_entries;
+        tm->accum_g1_launches = (S->eh.n_entries != 0) + (S->el.n_entries != 0) + (S->ea.n_entries != 0) + (!skip_b1 && S->eb1.n_entries != 0);
+        tm->accum_g2_launches = S->eb2.n_entries != 0;
+        tm->msm_g1_pairs = S->eh.n_scalars + S->el.n_scalars + S->ea.n_scalars + (skip_b1 ? 0 : S->eb1.n_scalars);
+        tm->msm_g2_pairs = S->eb2.n_scalars;
         tm->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     return CG_OK;
@@ -407,10 +435,13 @@ static int prove_common(cg_ctx* ctx, const void* assignment, bool on_device, con
     if (!ctx || !assignment || !proof_out) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
     if (int e = check_rs(r, s)) return e;
     if (ctx->shard_count != 1) return fail(CG_ERR_INVALID_ARGUMENT, "context is a shard; use cg_prove_partial + cg_assemble");
-    std::lock_guard<std::mutex> g(ctx->mu);
     try {
         Partials P;
-        int e = prove_partial_impl(ctx, assignment, on_device, scalar_is_zero(r), P, tm);
+        int e;
+        {
+            SlotGuard g(ctx);
+            e = prove_partial_impl(ctx, g.s, assignment, on_device, scalar_is_zero(r), P, tm);
+        }
         if (e) return e;
         auto t0 = std::chrono::steady_clock::now();
         assemble_impl(ctx, P, r, s, proof_out);
@@ -437,10 +468,13 @@ extern "C" int cg_prove_partial(cg_ctx* ctx, const void* full_assignment, int as
                                 uint8_t out_partials[384], cg_timings* timings) {
     if (!ctx || !full_assignment || !out_partials || !r) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
     if (!scalar_is_canonical(r)) return fail(CG_ERR_INVALID_ARGUMENT, "r not canonical");
-    std::lock_guard<std::mutex> g(ctx->mu);
     try {
         Partials P;
-        int e = prove_partial_impl(ctx, full_assignment, assignment_on_device != 0, scalar_is_zero(r), P, timings);
+        int e;
+        {
+            SlotGuard g(ctx);
+            e = prove_partial_impl(ctx, g.s, full_assignment, assignment_on_device != 0, scalar_is_zero(r), P, timings);
+        }
         if (e) return e;
         partials_to_bytes(P, out_partials);
         return CG_OK;
@@ -474,14 +508,14 @@ extern "C" int cg_assemble(cg_ctx* ctx, const uint8_t* partials, uint32_t n_shar
 
 extern "C" int cg_witness_map(cg_ctx* ctx, const uint8_t* full_assignment, uint8_t* h_out) {
     if (!ctx || !full_assignment || !h_out) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
-    std::lock_guard<std::mutex> g(ctx->mu);
     try {
         CG_HIP(hipSetDevice(ctx->device));
-        hipStream_t s0 = ctx->st[0];
-        CG_HIP(hipMemcpyAsync(ctx->w_canon.p, full_assignment, ctx->M * 32, hipMemcpyHostToDevice, s0));
-        fr_to_mont(ctx->w_canon.p, ctx->w_mont.p, ctx->M, s0);
-        run_witness_map(ctx, s0);
-        CG_HIP(hipMemcpyAsync(h_out, ctx->h_canon.p, ctx->D * 32, hipMemcpyDeviceToHost, s0));
+        SlotGuard g(ctx);
+        ProofSlot* S = g.s;
+        hipStream_t s0 = S->st[0];
+        CG_HIP(hipMemcpyAsync(S->w_canon.p, full_assignment, ctx->M * 32, hipMemcpyHostToDevice, s0));
+        run_witness_map(ctx, S, S->w_canon.p, s0);
+        CG_HIP(hipMemcpyAsync(h_out, S->h_canon.p, ctx->D * 32, hipMemcpyDeviceToHost, s0));
         CG_HIP(hipStreamSynchronize(s0));
         return CG_OK;
     } catch (...) {

@@ -1,0 +1,275 @@
+// R1CS -> QAP witness map on 29-bit-limb arithmetic (see wmap29.hpp).
+//
+// Restates LibsnarkReduction::witness_map_from_matrices (forks/groth16/src/r1cs_to_qap.rs:150-213):
+//   a, b, c = A·w, B·w, C·w (rows m..m+l of a hold w[0..l))            :164-177,191-196
+//   ifft; coset fft (offset g = 5)                                       :179-185,198-199
+//   ab = (a∘b - c) / Z(g)                                                :187,201-208
+//   coset ifft -> h                                                      :210
+// as seven decimation-in-time transforms of three LDS passes each, with the bit reversals, the coset
+// scalings, the 1/n factors, the pointwise step and the exit from Montgomery form all fused into the
+// loads and stores of those passes.
+#include "wmap29.hpp"
+
+namespace cg {
+
+static constexpr int TS29 = 10;            // log2 of the LDS tile (1024 elements x 9 limbs = 36 KiB + padding)
+static constexpr int STRIDED_MAX_S29 = 6;
+
+// ---- packed (8 x u32) global accesses ---------------------------------------------------------------------
+__device__ __forceinline__ Fr29 load_packed29(const uint32_t* __restrict__ base, uint64_t idx) {
+    const uint4* p = reinterpret_cast<const uint4*>(base + idx * 8);
+    uint4 a = p[0], b = p[1];
+    uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return unpack29<Fr29P>(w);
+}
+__device__ __forceinline__ void store_packed29(uint32_t* __restrict__ base, uint64_t idx, const Fr29& canonical_value) {
+    uint32_t w[8];
+    pack29(canonical_value, w);
+    uint4* p = reinterpret_cast<uint4*>(base + idx * 8);
+    p[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    p[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+__device__ __forceinline__ uint32_t brev(uint32_t x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
+
+// ---- table conversion ----------------------------------------------------------------------------------------
+// Montgomery(2^256) -> packed R' form, or (plain = 1) -> packed plain integer
+__global__ void __launch_bounds__(256) k_to_packed29(const Fr* __restrict__ in, uint32_t* __restrict__ out, uint64_t n, int plain,
+                                                     int unbitrev_logn) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr x = in[i];
+    uint64_t dst = unbitrev_logn ? brev((uint32_t)i, unbitrev_logn) : i;
+    if (plain) {
+        Fr c = from_mont(x);
+        uint4* p = reinterpret_cast<uint4*>(out + dst * 8);
+        p[0] = make_uint4(c.l[0], c.l[1], c.l[2], c.l[3]);
+        p[1] = make_uint4(c.l[4], c.l[5], c.l[6], c.l[7]);
+    } else {
+        store_packed29(out, dst, from_mont256<Fr29P>(x));
+    }
+}
+
+void Wm29Domain::build(const NttDomain& d, hipStream_t st) {
+    logn = d.logn;
+    n = d.n;
+    const uint64_t half = n > 1 ? n / 2 : 1;
+    tw_fwd.alloc(half * 8);
+    tw_inv.alloc(half * 8);
+    coset.alloc(n * 8);
+    icoset.alloc(n * 8);
+    k_to_packed29<<<ceil_div(half, 256), 256, 0, st>>>(d.tw_fwd.p, tw_fwd.p, half, 0, 0);
+    k_to_packed29<<<ceil_div(half, 256), 256, 0, st>>>(d.tw_inv.p, tw_inv.p, half, 0, 0);
+    // NttDomain keeps the coset tables at bit-reversed positions; here they are indexed naturally
+    k_to_packed29<<<ceil_div(n, 256), 256, 0, st>>>(d.coset_br.p, coset.p, n, 0, logn);
+    k_to_packed29<<<ceil_div(n, 256), 256, 0, st>>>(d.icoset_br.p, icoset.p, n, 1, logn);
+    CG_KERNEL_CHECK();
+    Fr29 v = from_mont256<Fr29P>(d.vanishing_inv);   // host arithmetic
+    pack29(v, vinv);
+}
+
+void Csr29::build(const DevCsr& m, hipStream_t st) {
+    dict.alloc(m.dict.n * 8);
+    k_to_packed29<<<ceil_div(m.dict.n, 256), 256, 0, st>>>(m.dict.p, dict.p, m.dict.n, 0, 0);
+    CG_KERNEL_CHECK();
+}
+
+// ---- witness -> R' form; sparse products --------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_w_to29(const Fr* __restrict__ w, uint32_t* __restrict__ out, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    store_packed29(out, i, from_canonical_bytes<Fr29P>(w[i]));
+}
+
+// out[rev(i)] = <M_i, w>, i < rows  (evaluate_constraint, r1cs_to_qap.rs:16-45); the output vector is the
+// bit-reversed input the first transform wants.
+__global__ void __launch_bounds__(256) k_spmv29(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+                                                const uint32_t* __restrict__ cidx, const uint32_t* __restrict__ dict,
+                                                const uint32_t* __restrict__ w29, uint32_t* __restrict__ out, uint64_t rows, int logn) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    uint32_t b = row_ptr[i], e = row_ptr[i + 1];
+    Fr29 acc = Fr29::zero();
+    uint32_t cnt = 0;
+    for (uint32_t t = b; t < e; ++t) {
+        Fr29 v = load_packed29(w29, col[t]);
+        uint32_t ci = cidx[t];
+        if (ci != 0) v = mul(v, load_packed29(dict, ci));      // index 0 is the literal one (is_one() shortcut :31-35)
+        acc = add(acc, v);
+        ++cnt;
+        if ((cnt & 3u) == 0) acc = normalize(acc);              // limbs stay below 5·2^29
+        if ((cnt & 63u) == 0) acc = mul(acc, Fr29::one());      // value back under 2N every 64 terms
+    }
+    store_packed29(out, brev((uint32_t)i, logn), canonical(normalize(acc)));
+}
+// rows m .. m+l of `a` hold the instance assignment (r1cs_to_qap.rs:173-177)
+__global__ void k_place_inputs29(const uint32_t* __restrict__ w29, uint32_t* __restrict__ out, uint64_t m, uint64_t l, int logn) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= l) return;
+    const uint4* s = reinterpret_cast<const uint4*>(w29 + i * 8);
+    uint4* d = reinterpret_cast<uint4*>(out + (uint64_t)brev((uint32_t)(m + i), logn) * 8);
+    d[0] = s[0];
+    d[1] = s[1];
+}
+
+// ---- LDS pass ---------------------------------------------------------------------------------------------------
+struct Pass29 {
+    int logn, ts, S, cbits, gbit_lo, q0;
+};
+__device__ __forceinline__ uint32_t l2g29(uint32_t e, uint32_t tile, const Pass29& pp) {
+    const int extra_bits = pp.ts - pp.S - pp.cbits;
+    uint32_t colv = e & ((1u << pp.cbits) - 1u);
+    uint32_t g = (e >> pp.cbits) & ((1u << pp.S) - 1u);
+    uint32_t extra = e >> (pp.cbits + pp.S);
+    uint32_t T = (tile << extra_bits) | extra;
+    const int lo_bits = pp.gbit_lo - pp.cbits;
+    uint32_t Tlo = T & ((1u << lo_bits) - 1u);
+    uint32_t Thi = T >> lo_bits;
+    return colv | (Tlo << pp.cbits) | (g << pp.gbit_lo) | (Thi << (pp.gbit_lo + pp.S));
+}
+// element e of the tile sits at word e*9 + e/16: the odd stride keeps both the linear and the
+// column-major (bit-reversing store) access patterns spread over the LDS banks
+__device__ __forceinline__ uint32_t lds_off(uint32_t e) { return e * 9u + (e >> 4); }
+__device__ __forceinline__ Fr29 lds_get(const uint32_t* s, uint32_t e) {
+    Fr29 r;
+    const uint32_t o = lds_off(e);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = s[o + i];
+    return r;
+}
+__device__ __forceinline__ void lds_put(uint32_t* s, uint32_t e, const Fr29& x) {
+    const uint32_t o = lds_off(e);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s[o + i] = x.l[i];
+}
+
+struct Packed8 { uint32_t w[8]; };
+
+// LOAD: 0 = one input vector; 1 = (a∘b - c)·vinv from three vectors (r1cs_to_qap.rs:187,201-208)
+// STORE: 0 = canonical R' value; 1 = multiplied by scale[natural index] (coset factor / exit from Montgomery form)
+template <int LOAD, int STORE>
+__global__ void __launch_bounds__(256) k_ntt29_pass(const uint32_t* __restrict__ in_a, const uint32_t* __restrict__ in_b,
+                                                    const uint32_t* __restrict__ in_c, uint32_t* __restrict__ out,
+                                                    const uint32_t* __restrict__ tw, const uint32_t* __restrict__ scale,
+                                                    Packed8 vinv_p, Pass29 pp, int store_bitrev) {
+    __shared__ uint32_t sm[(1 << TS29) * 9 + (1 << TS29) / 16];
+    const uint32_t tile = blockIdx.x;
+    const uint32_t tsize = 1u << pp.ts;
+    for (uint32_t e = threadIdx.x; e < tsize; e += 256) {
+        uint32_t gi = l2g29(e, tile, pp);
+        Fr29 x = load_packed29(in_a, gi);
+        if (LOAD == 1) {
+            Fr29 bb = load_packed29(in_b, gi), cc = load_packed29(in_c, gi);
+            Fr29 vinv = unpack29<Fr29P>(vinv_p.w);
+            x = mul(normalize(sub<2, 1>(mul(x, bb), cc)), vinv);
+        }
+        lds_put(sm, e, x);
+    }
+    __syncthreads();
+    const uint32_t nbf = tsize >> 1;
+    for (int j = 0; j < pp.S; ++j) {
+        const int q = pp.q0 + j;                       // DIT stage q pairs global bit q
+        const int lb = pp.cbits + (q - pp.gbit_lo);     // its position inside the tile
+        const uint32_t lmask = (1u << lb) - 1u;
+        const int tw_shift = pp.logn - 1 - q;
+        for (uint32_t b = threadIdx.x; b < nbf; b += 256) {
+            uint32_t e0 = ((b & ~lmask) << 1) | (b & lmask);
+            uint32_t e1 = e0 | (1u << lb);
+            uint32_t gi = l2g29(e0, tile, pp);
+            uint32_t k = gi & ((1u << q) - 1u);
+            Fr29 w = load_packed29(tw, (uint64_t)k << tw_shift);
+            Fr29 u = lds_get(sm, e0);
+            Fr29 v = lds_get(sm, e1);
+            Fr29 t = mul(v, w);                          // < v/169 + 1 < 1.3 N
+            lds_put(sm, e0, normalize(add(u, t)));       // values grow by at most 3 N per stage: < 40 N over a pass
+            lds_put(sm, e1, normalize(sub<3, 1>(u, t)));
+        }
+        __syncthreads();
+    }
+    const uint32_t smask = (1u << pp.S) - 1u;
+    for (uint32_t f = threadIdx.x; f < tsize; f += 256) {
+        uint32_t e = f;
+        if (store_bitrev) {   // walk the tile so that consecutive lanes hit consecutive bit-reversed destinations
+            uint32_t gprime = f & smask, colp = f >> pp.S;
+            e = (brev(gprime, pp.S) << pp.cbits) | colp;
+        }
+        uint32_t gi = l2g29(e, tile, pp);
+        Fr29 x = lds_get(sm, e);
+        Fr29 y;
+        if (STORE == 1) y = cond_sub_n(mul(x, load_packed29(scale, gi)));
+        else y = canonical(x);
+        store_packed29(out, store_bitrev ? brev(gi, pp.logn) : gi, y);
+    }
+}
+
+template <int LOAD, int STORE>
+static void launch_pass(uint32_t tiles, const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t* out, const uint32_t* tw,
+                        const uint32_t* scale, const Packed8& vinv, const Pass29& pp, int store_bitrev, hipStream_t st) {
+    k_ntt29_pass<LOAD, STORE><<<tiles, 256, 0, st>>>(a, b, c, out, tw, scale, vinv, pp, store_bitrev);
+    CG_KERNEL_CHECK();
+}
+
+// One DIT transform.  The first pass reads `in_a` (or the three pointwise operands) and writes `work`; middle
+// passes run in place on `work`; the last pass writes `dst`.  A bit-reversing store permutes across tiles, so
+// it must not be in place: callers give dst != work (and != in_a for a single-pass transform) in that case.
+static void dit29(const Wm29Domain& d, const uint32_t* tw, const uint32_t* in_a, const uint32_t* in_b, const uint32_t* in_c,
+                  bool pointwise, uint32_t* work, uint32_t* dst, const uint32_t* scale, bool store_bitrev, hipStream_t st) {
+    const int logn = d.logn;
+    Packed8 vinv;
+    memcpy(vinv.w, d.vinv, 32);
+    std::vector<Pass29> plan;
+    const int ts = logn < TS29 ? logn : TS29;
+    plan.push_back(Pass29{logn, ts, ts, 0, 0, 0});
+    const int rest = logn - ts;
+    const int npass = rest ? (rest + STRIDED_MAX_S29 - 1) / STRIDED_MAX_S29 : 0;
+    int done = 0;
+    for (int p = 0; p < npass; ++p) {
+        int S = (rest - done + (npass - p) - 1) / (npass - p);
+        plan.push_back(Pass29{logn, ts, S, ts - S, ts + done, ts + done});
+        done += S;
+    }
+    const uint32_t tiles = (uint32_t)(d.n >> ts);
+    for (size_t i = 0; i < plan.size(); ++i) {
+        const bool first = (i == 0), last = (i + 1 == plan.size());
+        const uint32_t* a = first ? in_a : work;
+        uint32_t* o = last ? dst : work;
+        const bool pw = first && pointwise;
+        const bool sc = last && scale != nullptr;
+        const int sb = last && store_bitrev ? 1 : 0;
+        if (pw && sc) launch_pass<1, 1>(tiles, a, in_b, in_c, o, tw, scale, vinv, plan[i], sb, st);
+        else if (pw) launch_pass<1, 0>(tiles, a, in_b, in_c, o, tw, scale, vinv, plan[i], sb, st);
+        else if (sc) launch_pass<0, 1>(tiles, a, nullptr, nullptr, o, tw, scale, vinv, plan[i], sb, st);
+        else launch_pass<0, 0>(tiles, a, nullptr, nullptr, o, tw, scale, vinv, plan[i], sb, st);
+    }
+}
+
+void wm29_run(const Wm29Domain& dom, const DevCsr& A, const DevCsr& B, const DevCsr& C, const Csr29& dA, const Csr29& dB,
+              const Csr29& dC, Wm29Buffers& buf, const Fr* w_canon, uint64_t M, uint64_t m, uint64_t l, Fr* h_out,
+              hipStream_t st) {
+    const uint64_t D = dom.n;
+    const int logn = dom.logn;
+    k_w_to29<<<ceil_div(M, 256), 256, 0, st>>>(w_canon, buf.w29.p, M);
+    CG_KERNEL_CHECK();
+    uint32_t* v[3] = {buf.va.p, buf.vb.p, buf.vc.p};
+    const DevCsr* mats[3] = {&A, &B, &C};
+    const Csr29* dicts[3] = {&dA, &dB, &dC};
+    for (int k = 0; k < 3; ++k) {
+        CG_HIP(hipMemsetAsync(v[k], 0, D * 32, st));
+        if (mats[k]->rows) {
+            k_spmv29<<<ceil_div(mats[k]->rows, 256), 256, 0, st>>>(mats[k]->row_ptr.p, mats[k]->col.p, mats[k]->coef_idx.p, dicts[k]->dict.p,
+                                                                   buf.w29.p, v[k], mats[k]->rows, logn);
+            CG_KERNEL_CHECK();
+        }
+    }
+    k_place_inputs29<<<ceil_div(l, 256), 256, 0, st>>>(buf.w29.p, buf.va.p, m, l, logn);
+    CG_KERNEL_CHECK();
+    for (int k = 0; k < 3; ++k) {
+        // ifft (bit-reversed in), then x g^i / n, stored bit-reversed for the next transform      :179-185,198-199
+        dit29(dom, dom.tw_inv.p, v[k], nullptr, nullptr, false, v[k], buf.vt.p, dom.coset.p, true, st);
+        // fft on the coset; stored bit-reversed so the pointwise load below feeds the last transform directly
+        dit29(dom, dom.tw_fwd.p, buf.vt.p, nullptr, nullptr, false, buf.vt.p, v[k], nullptr, true, st);
+    }
+    // (a∘b - c)/Z(g) on load; coset ifft; x g^-i / n and out of Montgomery form on store           :187,201-210
+    dit29(dom, dom.tw_inv.p, buf.va.p, buf.vb.p, buf.vc.p, true, buf.va.p, reinterpret_cast<uint32_t*>(h_out), dom.icoset.p, false, st);
+}
+
+}  // namespace cg

@@ -1,0 +1,43 @@
+// R1CS -> QAP witness map (forks/groth16/src/r1cs_to_qap.rs:150-213) on the lazy 29-bit-limb field
+// arithmetic: the production path of cg_prove.  (ntt.hip keeps the saturated-limb transforms used by the
+// unit-level cg_ntt entry point and by cg_setup.)
+//
+// Vector elements live in HBM as 32-byte packed canonical values of x·2^261 mod r ("R' form").
+// Every transform is decimation-in-time (bit-reversed in, natural out): a DIT butterfly only ever
+// multiplies one operand and adds/subtracts, so lazy values grow linearly (+2N per stage) instead of
+// doubling.  The permutations DIT needs are free: the producer of each transform's input writes it
+// bit-reversed (the sparse product scatters its rows; the last pass of a transform scatters its output).
+#pragma once
+#include "field29.cuh"
+#include "ntt.hpp"
+
+namespace cg {
+
+struct Wm29Domain {
+    int logn = 0;
+    uint64_t n = 0;
+    DevBuf<uint32_t> tw_fwd;     // ω^e   (e < n/2), R' form, 8 words each
+    DevBuf<uint32_t> tw_inv;     // ω^-e
+    DevBuf<uint32_t> coset;      // g^i / n   at natural index i, R' form      (r1cs_to_qap.rs:182-185 + the 1/n of :179-180)
+    DevBuf<uint32_t> icoset;     // g^-i / n  at natural index i, PLAIN form (multiplying by it also leaves Montgomery form)
+    uint32_t vinv[8];            // (g^n - 1)^-1, R' form (host copy; passed by value to the kernel)
+    void build(const NttDomain& d, hipStream_t st);
+};
+
+struct Csr29 {     // the matrices' coefficient dictionary in R' form (index arrays are shared with DevCsr)
+    DevBuf<uint32_t> dict;
+    void build(const DevCsr& m, hipStream_t st);
+};
+
+struct Wm29Buffers {     // per proof slot
+    DevBuf<uint32_t> w29;            // witness in R' form, M x 8 words
+    DevBuf<uint32_t> va, vb, vc, vt; // D x 8 words each (vt: ping-pong partner of the bit-reversing stores)
+    void alloc(uint64_t M, uint64_t D) { w29.alloc(M * 8); va.alloc(D * 8); vb.alloc(D * 8); vc.alloc(D * 8); vt.alloc(D * 8); }
+};
+
+// w_canon: M canonical scalars on the device.  h_out: D canonical scalars (natural order), on the device.
+void wm29_run(const Wm29Domain& dom, const DevCsr& A, const DevCsr& B, const DevCsr& C, const Csr29& dA, const Csr29& dB,
+              const Csr29& dC, Wm29Buffers& buf, const Fr* w_canon, uint64_t M, uint64_t m, uint64_t l, Fr* h_out,
+              hipStream_t st);
+
+}  // namespace cg

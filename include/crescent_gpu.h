@@ -23,7 +23,8 @@
  *     thread-local human-readable message for the last failure on the calling thread.
  *   - The caller owns every host buffer; the library copies what it keeps.
  *   - A cg_ctx is bound to one GPU.  Calls on different contexts are independent and may run
- *     concurrently from different threads; calls on one context are serialised internally.
+ *     concurrently from different threads; calls on one context take one of its `proof_slots`
+ *     working sets each (blocking while none is free), so up to that many proofs overlap on the GPU.
  */
 #ifndef CRESCENT_GPU_H
 #define CRESCENT_GPU_H
@@ -89,7 +90,9 @@ typedef struct cg_options {
     int32_t window_bits;   /* Pippenger window c; 0 = library default for the size */
     int32_t shard_rank;    /* multi-GPU MSM range sharding: this context's rank ... */
     int32_t shard_count;   /* ... of shard_count; 0 or 1 = unsharded */
-    int32_t reserved[4];
+    int32_t proof_slots;   /* proofs that may be in flight on this context at once (each has its own working
+                              set and streams; cg_prove* from different threads overlap on the GPU); 0 = 1 */
+    int32_t reserved[3];
 } cg_options;
 
 /* Per-phase wall/GPU times of one cg_prove call, mirroring the reference's `print-trace` phases
