@@ -24,6 +24,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Several proofs are kept in flight per GPU, each on five HIP streams; the runtime maps streams onto this many
+# hardware queues (default 4), and kernels of streams that share a queue cannot overlap.  Must be set before
+# the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -32,6 +36,18 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (guides/MI355X_MICROARCH.md)
 G1_PAIR_BYTES = 96             # 64 B affine base + 32 B scalar   
 G2_PAIR_BYTES = 160
+
+
+def pmc_traffic(launches_per_proof):
+    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
+    separate runs of this same command, FETCH_SIZE doubled per guides/MI355X_MICROARCH.md §HBM).  The counters cannot be
+    read from inside this process, so the figure comes from the committed measurement in profiles/ (None if absent)."""
+    path = os.path.join(ROOT, "profiles", "pmc_accum_affine_g1.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def parse():
@@ -46,7 +62,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-uniform", action="store_true", help="skip the secondary uniform-witness measurement")
     ap.add_argument("--window", type=int, default=0)
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for plumbing tests)")
+    ap.add_argument("--inflight", type=int, default=4,
                     help="proofs in flight per GPU (throughput mode): host threads x context proof_slots")
     return ap.parse_args()
 
@@ -60,11 +77,15 @@ def main():
         print("bench.py --gpus %d must be launched under torch.distributed.run" % a.gpus, file=sys.stderr)
         sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path to measure)"
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
 
     import crescent_credentials_amd as cc
     from crescent_credentials_amd import workloads as wl
@@ -147,7 +168,7 @@ def main():
         alg_bytes = G1_PAIR_BYTES * g1_pairs                       # all four G1 MSMs' operands, touched once
         achieved = alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
         roof = {"kernel": "k_accum_affine<Fq> (G1 bucket accumulation)", "bound": "hbm", "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(launches),
                 "launches_per_proof": launches, "avg_launch_ms": round(acc_ms / launches, 4),
                 "algorithmic_bytes_per_launch": int(alg_bytes / launches),
                 "mixed_adds_per_s": round(tm["entries_g1"] / (acc_ms * 1e-3), 1) if acc_ms > 0 else None,

@@ -38,6 +38,8 @@ def barrier_sync(world: int) -> None:
 def max_over_ranks(x: float, world: int, device) -> float:
     if world <= 1:
         return x
+    if dist.get_backend() == "gloo":
+        device = torch.device("cpu")
     t = torch.tensor([x], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
@@ -46,6 +48,8 @@ def max_over_ranks(x: float, world: int, device) -> float:
 def gather_partials(partial: bytes, device, group=None) -> bytes:
     """all_gather of one rank's 384-byte partial-sum record -> world x 384 bytes, rank order."""
     world = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo":
+        device = torch.device("cpu")
     mine = torch.frombuffer(bytearray(partial), dtype=torch.uint8).to(device)
     out = [torch.empty(PARTIAL_BYTES, dtype=torch.uint8, device=device) for _ in range(world)]
     dist.all_gather(out, mine, group=group)

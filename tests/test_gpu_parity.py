@@ -291,6 +291,47 @@ def test_sharded_partials_assemble_to_same_proof(cc, oracle):
                 p.close()
 
 
+@pytest.mark.parametrize("shape,bit_fraction", [("medium", 0.9), ("medium", 0.0), ("large18", 0.9)])
+def test_prove_equals_cpu_restatement(cc, oracle, shape, bit_fraction):
+    """Full proofs at D = 2^16 / 2^18 (too large for the Python oracle): byte-identical to oracle/cpu_ref.c, the C
+    restatement that tests/test_cpu_ref.py pins to the golden vectors; exercises every NTT pass plan and the
+    production window size."""
+    import cpu_ref
+    from crescent_credentials_amd import workloads as wl
+    l, m, M = (20, 60_000, 61_000) if shape == "medium" else (26, 250_000, 255_000)
+    cm, w = wl.synthetic_circuit(2024, l, m, M, bit_fraction, 3)
+    rng = random.Random(11)
+    tau, alpha, beta, delta = (rng.randrange(1, oracle.R) for _ in range(4))
+    pk = cc.generate_parameters_with_qap(cm, alpha, beta, delta, tau)
+    prover = cc.Prover(pk, cm, proof_slots=2)
+    try:
+        assert bytes(prover.witness_map(w)) == bytes(cpu_ref.witness_map((cm.a, cm.b, cm.c), l, m, M, w, nthreads=8))
+        for r, s in ((0, 0), (rng.randrange(oracle.R), rng.randrange(oracle.R))):
+            assert prover.prove(w, r, s).data == cpu_ref.prove(pk, (cm.a, cm.b, cm.c), l, m, M, w, r, s, nthreads=8)
+    finally:
+        prover.close()
+
+
+def test_proofs_in_flight_are_independent(cc, oracle):
+    """several host threads on one context (proof_slots) give the same bytes as serial proving"""
+    from concurrent.futures import ThreadPoolExecutor
+    from crescent_credentials_amd import workloads as wl
+    l, m, M = 6, 3_000, 3_100
+    cm, w = wl.synthetic_circuit(77, l, m, M, 0.5, 3)
+    rng = random.Random(5)
+    pk = cc.generate_parameters_with_qap(cm, *(rng.randrange(1, oracle.R) for _ in range(4)))
+    rs = [(rng.randrange(oracle.R), rng.randrange(oracle.R)) for _ in range(12)]
+    serial = cc.Prover(pk, cm)
+    par = cc.Prover(pk, cm, proof_slots=3)
+    try:
+        expect = [serial.prove(w, r, s).data for r, s in rs]
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            got = list(ex.map(lambda x: par.prove(w, x[0], x[1]).data, rs))
+        assert got == expect
+    finally:
+        serial.close(); par.close()
+
+
 @pytest.mark.parametrize("bit_fraction", [0.0, 0.9])
 def test_prove_medium_properties(cc, oracle, bit_fraction):
     """D = 2^16: no oracle proof at this size in seconds, so check structure-independent properties:
