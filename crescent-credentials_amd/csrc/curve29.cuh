@@ -65,6 +65,36 @@ CG_HD Affine29<F> load_table_point(const uint32_t* __restrict__ table, uint32_t 
     return a;
 }
 
+// the same in two steps, so that the (random, HBM-latency) read can be issued an iteration early
+template <class F>
+struct RawPoint29 {
+    uint4 q[Words29<F>::AFF / 4];
+};
+template <class F>
+CG_HD RawPoint29<F> load_raw_point(const uint32_t* __restrict__ table, uint32_t idx) {
+    constexpr int AFF = Words29<F>::AFF;
+    const uint4* p = reinterpret_cast<const uint4*>(table + (size_t)idx * AFF);
+    RawPoint29<F> r;
+#pragma unroll
+    for (int i = 0; i < AFF / 4; ++i) r.q[i] = p[i];
+    return r;
+}
+template <class F>
+CG_HD Affine29<F> unpack_point(const RawPoint29<F>& r, bool negate) {
+    constexpr int AFF = Words29<F>::AFF;
+    uint32_t w[AFF];
+#pragma unroll
+    for (int i = 0; i < AFF / 4; ++i) {
+        w[4 * i] = r.q[i].x; w[4 * i + 1] = r.q[i].y; w[4 * i + 2] = r.q[i].z; w[4 * i + 3] = r.q[i].w;
+    }
+    Affine29<F> a;
+    load_coord(a.x, w);
+    load_coord(a.y, w + AFF / 2);
+    F ny = normalize(sub<2, 1>(F::zero(), a.y));
+    if (negate) a.y = ny;
+    return a;
+}
+
 // accumulator <-> memory (ACC words; identity = zz all zero)
 template <class F>
 CG_HD void store_acc(uint32_t* __restrict__ dst, const XYZZ29<F>& a, bool inf) {

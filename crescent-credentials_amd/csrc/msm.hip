@@ -45,6 +45,19 @@ int msm_default_window(uint64_t n, bool precomputed) {
     return best_c;
 }
 
+int msm_best_window(uint64_t n_bases, double nz_small, double nz_full) {
+    double best = 1e300;
+    int best_c = 4;
+    for (int c = 6; c <= 22; ++c) {
+        int W = (SCALAR_BITS + c - 1) / c;
+        if ((double)W * (double)n_bases >= 2147483648.0) continue;
+        double entries = nz_small + nz_full * W;
+        double cost = entries * 12.0 + (double)(1u << (c - 1)) * 2.0 * 16.0;
+        if (cost < best) { best = cost; best_c = c; }
+    }
+    return best_c;
+}
+
 // ---------------------------------------------------------------------------------------------
 // base import / window tables
 // ---------------------------------------------------------------------------------------------
@@ -149,6 +162,23 @@ void MsmBases<F>::build(const Affine<F>* bases_dev, uint64_t n_, int c_, bool pr
         }
 }
 
+template <class F>
+void MsmBases<F>::rebuild(int c_new, hipStream_t st) {
+    if (!precomputed || c_new == c || !n) return;
+    const int W_new = (SCALAR_BITS + c_new - 1) / c_new;
+    if ((uint64_t)W_new * n >= (1ull << 31)) return;
+    DevBuf<uint32_t> t2((uint64_t)W_new * n * AFF);
+    CG_HIP(hipMemcpyAsync(t2.p, table.p, n * AFF * 4, hipMemcpyDeviceToDevice, st));   // row 0 = the bases themselves
+    for (int j = 1; j < W_new; ++j) {
+        k_table_next<F29T><<<ceil_div(n, 256), 256, 0, st>>>(t2.p, valid.p, n, j, c_new);
+        CG_KERNEL_CHECK();
+    }
+    CG_HIP(hipStreamSynchronize(st));
+    table = std::move(t2);
+    c = c_new;
+    W = W_new;
+}
+
 // ---------------------------------------------------------------------------------------------
 // signed-digit extraction
 // ---------------------------------------------------------------------------------------------
@@ -183,15 +213,18 @@ __device__ __forceinline__ void for_each_digit(const uint32_t s[8], int c, int W
 }
 
 __global__ void __launch_bounds__(256) k_digit_count(const Fr* __restrict__ scalars, const uint8_t* __restrict__ valid,
-                                                     uint64_t n, int c, int W, uint32_t* __restrict__ counts) {
+                                                     uint64_t n, int c, int W, uint32_t* __restrict__ counts,
+                                                     uint32_t* __restrict__ nz_counter) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     uint32_t cnt = 0;
-    if (valid[i]) {
+    if (i < n && valid[i]) {
         Fr s = scalars[i];
         for_each_digit(s.l, c, W, [&](int, int32_t d) { cnt += (d != 0); });
     }
-    counts[i] = cnt;
+    if (i < n) counts[i] = cnt;
+    // one atomic per wave: how many scalars contribute at all (statistics for the window choice)
+    unsigned long long m = __ballot(cnt != 0);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(nz_counter, (uint32_t)__popcll(m));
 }
 
 __global__ void __launch_bounds__(256) k_digit_emit(const Fr* __restrict__ scalars, const uint8_t* __restrict__ valid,
@@ -475,10 +508,13 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
         cols_buf.alloc((size_t)(1u << cbits) * wins * ACC);
     }
     result.alloc((size_t)wins * 2 * ACC);      // per window: rows part, columns part
-    h_count.alloc(1);
+    nz_counter.alloc(1);
+    h_count.alloc(2);
     h_result.alloc((size_t)wins * 2 * ACC);
-    CG_HIP(hipEventCreateWithFlags(&ev_count, hipEventDisableTiming));
-    for (auto& e : ev_t) CG_HIP(hipEventCreate(&e));
+    if (!ev_count) {
+        CG_HIP(hipEventCreateWithFlags(&ev_count, hipEventDisableTiming));
+        for (auto& e : ev_t) CG_HIP(hipEventCreate(&e));
+    }
 }
 
 static float elapsed_ms(hipEvent_t a, hipEvent_t b) {
@@ -501,14 +537,17 @@ void MsmEngine<F>::digits(const Fr* scalars_dev, uint64_t n, hipStream_t st) {
     if (n > bases->n) n = bases->n;  // msm_bigint zips and truncates to the shorter operand
     n_scalars = n;
     h_count.p[0] = 0;
+    h_count.p[1] = 0;
     CG_HIP(hipEventRecord(ev_t[0], st));
     if (!n) return;
     const int c = bases->c, W = bases->W;
-    k_digit_count<<<ceil_div(n, 256), 256, 0, st>>>(scalars_dev, bases->valid.p, n, c, W, thread_counts.p);
+    CG_HIP(hipMemsetAsync(nz_counter.p, 0, 4, st));
+    k_digit_count<<<ceil_div(n, 256), 256, 0, st>>>(scalars_dev, bases->valid.p, n, c, W, thread_counts.p, nz_counter.p);
     CG_KERNEL_CHECK();
     size_t tmp = sort_tmp_bytes;
     CG_HIP(rocprim::inclusive_scan(sort_tmp.p, tmp, thread_counts.p, thread_counts.p, (size_t)n, rocprim::plus<uint32_t>(), st));
     CG_HIP(hipMemcpyAsync(h_count.p, thread_counts.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    CG_HIP(hipMemcpyAsync(h_count.p + 1, nz_counter.p, 4, hipMemcpyDeviceToHost, st));
     CG_HIP(hipEventRecord(ev_count, st));
     k_digit_emit<<<ceil_div(n, 256), 256, 0, st>>>(scalars_dev, bases->valid.p, n, c, W, thread_counts.p, keys_a.p, vals_a.p,
                                                   bases->precomputed ? 1 : 0);
@@ -520,9 +559,11 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
     const uint32_t wins = bases->precomputed ? 1u : (uint32_t)bases->W;
     const uint32_t nb = 1u << (bases->c - 1);
     n_entries = 0;
+    n_nonzero = 0;
     if (n_scalars) {
         CG_HIP(hipEventSynchronize(ev_count));
         n_entries = h_count.p[0];
+        n_nonzero = h_count.p[1];
     }
     CG_HIP(hipMemsetAsync(bucket_sums.p, 0, bucket_sums.bytes(), st));
     if (n_entries) {

@@ -24,9 +24,15 @@ struct MsmBases {
     DevBuf<uint8_t> valid;     // 1 = base is not the identity
     // bases_dev: n affine points in Montgomery(2^256) form on the device (identity = all zero)
     void build(const Affine<F>* bases_dev, uint64_t n, int c, bool precompute, hipStream_t st);
+    // re-expand the same bases (row 0 of the table) for another window size
+    void rebuild(int c_new, hipStream_t st);
 };
 
 int msm_default_window(uint64_t n, bool precomputed);
+// window minimising (mixed additions + bucket-reduction additions) for a scalar population observed on a proof:
+// `nz_small` scalars that contribute a single non-zero digit (0/1-like wires) and `nz_full` full-width scalars.
+// g2 = the additions are over Fq2 (the ratio of the two addition kinds is the same, so only the bucket term's weight differs).
+int msm_best_window(uint64_t n_bases, double nz_small, double nz_full);
 
 // Per-MSM working set; reusable across proofs.
 template <class F>
@@ -46,10 +52,12 @@ struct MsmEngine {
     DevBuf<uint32_t> red_a, red_b;
     DevBuf<uint32_t> rows_buf, cols_buf;   // row / column sums of the bucket matrix (bucket reduction)
     DevBuf<uint32_t> result;          // W_keyspace accumulators (1 when precomputed)
-    PinnedBuf<uint32_t> h_count;
+    DevBuf<uint32_t> nz_counter;      // scalars with at least one non-zero digit (device)
+    PinnedBuf<uint32_t> h_count;      // [0] entries, [1] non-zero scalars
     PinnedBuf<uint32_t> h_result;
     uint64_t n_scalars = 0;
     uint32_t n_entries = 0;
+    uint32_t n_nonzero = 0;
     hipEvent_t ev_count = nullptr;
     // timing events (recorded on the MSM's own stream): digits start, sort begin/end, level-1
     // accumulation kernel begin/end, result ready

@@ -6,6 +6,7 @@
 // base tables, the five MSMs and the witness map run on separate HIP streams, and only the few
 // scalar multiplications by r, s and the final additions run on the host.
 #include <condition_variable>
+#include <shared_mutex>
 #include <memory>
 #include <mutex>
 #include <chrono>
@@ -144,6 +145,11 @@ struct cg_ctx {
     NttDomain dom;
     Wm29Domain wdom;
     std::vector<std::unique_ptr<ProofSlot>> slots;
+    // window tuning: the window of each assignment-driven query is re-chosen once from the digit statistics of
+    // the first proof (circom witnesses are mostly 0/1 wires, for which the size-based default is far too wide)
+    bool fixed_window = false;
+    bool tuned = false;
+    std::shared_mutex tune_mu;   // proofs hold it shared; a retune holds it exclusively
     std::mutex pick_mu;
     std::condition_variable pick_cv;
     // blocks until a slot is free; returns it locked
@@ -239,6 +245,7 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         c->shard_rank = (opt && c->shard_count > 1) ? opt->shard_rank : 0;
         if (c->shard_rank < 0 || c->shard_rank >= c->shard_count) return fail(CG_ERR_INVALID_ARGUMENT, "shard_rank out of range");
         const int wb = opt ? opt->window_bits : 0;
+        c->fixed_window = wb > 0;
         int n_slots = (opt && opt->proof_slots > 0) ? opt->proof_slots : 1;
         if (n_slots > 16) n_slots = 16;
         hipStream_t s0;
@@ -424,6 +431,43 @@ static void partials_to_bytes(const Partials& P, uint8_t out[384]) {
     g2_export_canonical(P.b2, out + 256);
 }
 
+// One-time window re-tuning from the statistics of a finished proof (held in slot S's engines).
+template <class F>
+static bool retune_query(cg_ctx* c, MsmBases<F>& bases, MsmEngine<F> ProofSlot::*eng, ProofSlot* S, hipStream_t st) {
+    MsmEngine<F>& e = S->*eng;
+    if (!e.n_scalars || !bases.n) return false;
+    const int W0 = bases.W;
+    double nz = e.n_nonzero, N = e.n_entries;
+    double nz_full = W0 > 1 ? (N - nz) / (double)(W0 - 1) : 0.0;
+    if (nz_full < 0) nz_full = 0;
+    if (nz_full > nz) nz_full = nz;
+    int best = msm_best_window(bases.n, nz - nz_full, nz_full);
+    if (best == bases.c) return false;
+    bases.rebuild(best, st);
+    for (auto& sl : c->slots) ((*sl).*eng).init(&bases);
+    return true;
+}
+static void maybe_retune(cg_ctx* c) {
+    if (c->fixed_window || c->tuned) return;
+    std::unique_lock<std::shared_mutex> lk(c->tune_mu);     // waits for the proofs in flight to drain
+    if (c->tuned) return;
+    ProofSlot* S = nullptr;
+    for (auto& sl : c->slots) if (sl->el.n_scalars || sl->ea.n_scalars) { S = sl.get(); break; }
+    if (!S) return;
+    CG_HIP(hipSetDevice(c->device));
+    hipStream_t st = S->st[0];
+    retune_query<Fq>(c, c->bl, &ProofSlot::el, S, st);
+    retune_query<Fq>(c, c->ba, &ProofSlot::ea, S, st);
+    if (S->eb1.n_scalars) retune_query<Fq>(c, c->bb1, &ProofSlot::eb1, S, st);
+    else if (c->bb1.c != c->ba.c) { /* b1 was skipped (r = 0): follow b2's statistics below */ }
+    retune_query<Fq2>(c, c->bb2, &ProofSlot::eb2, S, st);
+    if (!S->eb1.n_scalars && c->bb1.c != c->bb2.c) {         // same scalars and same identity pattern as b2
+        c->bb1.rebuild(c->bb2.c, st);
+        for (auto& sl : c->slots) sl->eb1.init(&c->bb1);
+    }
+    c->tuned = true;
+}
+
 static int check_rs(const uint8_t r[32], const uint8_t s[32]) {
     if (!r || !s) return fail(CG_ERR_INVALID_ARGUMENT, "null r/s");
     if (!scalar_is_canonical(r) || !scalar_is_canonical(s)) return fail(CG_ERR_INVALID_ARGUMENT, "r/s not canonical (>= field modulus)");
@@ -439,9 +483,11 @@ static int prove_common(cg_ctx* ctx, const void* assignment, bool on_device, con
         Partials P;
         int e;
         {
+            std::shared_lock<std::shared_mutex> tl(ctx->tune_mu);
             SlotGuard g(ctx);
             e = prove_partial_impl(ctx, g.s, assignment, on_device, scalar_is_zero(r), P, tm);
         }
+        if (!e) maybe_retune(ctx);
         if (e) return e;
         auto t0 = std::chrono::steady_clock::now();
         assemble_impl(ctx, P, r, s, proof_out);
@@ -472,9 +518,11 @@ extern "C" int cg_prove_partial(cg_ctx* ctx, const void* full_assignment, int as
         Partials P;
         int e;
         {
+            std::shared_lock<std::shared_mutex> tl(ctx->tune_mu);
             SlotGuard g(ctx);
             e = prove_partial_impl(ctx, g.s, full_assignment, assignment_on_device != 0, scalar_is_zero(r), P, timings);
         }
+        if (!e) maybe_retune(ctx);
         if (e) return e;
         partials_to_bytes(P, out_partials);
         return CG_OK;

@@ -51,7 +51,36 @@ static float timeit(K kern, dim3 g, dim3 b, A... args) {
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); return ms;
 }
 
+// random gathers from a table of `npts` points (64 B each): isolates the memory side of the accumulation kernel
+__global__ void __launch_bounds__(256) k_madd_gather(const uint32_t* table, uint32_t* out, int iters, uint32_t npts, int do_math) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    XYZZ29<Fq29> acc; bool inf = true;
+    uint32_t h = t * 2654435761u + 12345u;
+    uint32_t sink = 0;
+    for (int i = 0; i < iters; ++i) {
+        h = h * 1664525u + 1013904223u;
+        uint32_t idx = (uint32_t)(((uint64_t)h * npts) >> 32);
+        Affine29<Fq29> p = load_table_point<Fq29>(table, idx, (i & 1) != 0);
+        if (do_math) madd29(acc, inf, p); else sink += p.x.l[0] + p.y.l[3];
+    }
+    if (!do_math) { acc.x.l[0] = sink; inf = false; }
+    store_acc(out + (size_t)t * 36, acc, inf);
+}
+
 int main(int argc, char** argv) {
+    {
+        uint32_t* big; uint32_t *o2;
+        const uint32_t NP = 27u * 1000 * 1000;   // 1.7 GB: the h-query table at c = 20
+        CHECK(hipMalloc(&big, (size_t)NP * 64)); CHECK(hipMemset(big, 0x11, (size_t)NP * 64));
+        CHECK(hipMalloc(&o2, (size_t)256 * 16 * 256 * 36 * 4));
+        for (uint32_t np : {4096u, NP}) for (int math : {0, 1}) {
+            int blocks = 256 * 8, it = 52;
+            float ms = timeit(k_madd_gather, dim3(blocks), dim3(256), (const uint32_t*)big, o2, it, np, math);
+            double n = (double)blocks * 256 * it;
+            printf("gather table=%u pts math=%d: %.3f ms  %.2f G pts/s  (%.2f TB/s of 128-B lines)\n", np, math, ms, n / ms / 1e6, n * 128 / ms / 1e9);
+        }
+        CHECK(hipFree(big)); CHECK(hipFree(o2));
+    }
     const int NPTS = 4096;
     // table of valid points is not needed for timing: use random canonical-looking data (formulas are branch-free except rare paths)
     std::vector<uint32_t> h(NPTS * 72);
