@@ -49,16 +49,56 @@ __global__ void __launch_bounds__(256) k_to_packed29(const Fr* __restrict__ in, 
     }
 }
 
+// twiddles are kept unpacked: nine 29-bit limbs in a 48-byte record (three 16-byte loads, no unpacking per butterfly)
+__global__ void __launch_bounds__(256) k_to_limbs12(const Fr* __restrict__ in, uint32_t* __restrict__ out, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr29 x = from_mont256<Fr29P>(in[i]);
+    uint4* p = reinterpret_cast<uint4*>(out + i * 12);
+    p[0] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
+    p[1] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
+    p[2] = make_uint4(x.l[8], 0u, 0u, 0u);
+}
+__device__ __forceinline__ Fr29 load_tw(const uint32_t* __restrict__ tw, uint64_t idx) {
+    const uint4* p = reinterpret_cast<const uint4*>(tw + idx * 12);
+    uint4 a = p[0], b = p[1], c = p[2];
+    Fr29 r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = c.x;
+    return r;
+}
+
+// v (normalised, value < 2^261) -> r ≡ v (mod N), normalised, r < 3N < 2^256: a one-word quotient estimate instead of
+// a full Montgomery product; used where a value only has to fit the packed 32-byte form again.
+__device__ __forceinline__ Fr29 weak_reduce(const Fr29& v) {
+    // q = floor(l[8] * MU / 2^48) with MU = floor(2^280 / N) and l[8] = floor(v / 2^232): never above v / N,
+    // short of it by less than 2
+    constexpr uint32_t MU = 88753990u;   // floor(2^280 / r), r = BN254 scalar modulus
+    const uint32_t q = (uint32_t)(((uint64_t)v.l[8] * MU) >> 48);
+    const int32_t nq = -(int32_t)q;
+    Fr29 r;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        c += (int64_t)v.l[i];
+        c += (int64_t)nq * (int64_t)(int32_t)Fr29P::N[i];
+        if (i < 8) { r.l[i] = (uint32_t)c & M29; c >>= 29; }
+        else r.l[i] = (uint32_t)c;
+    }
+    return r;
+}
+
 void Wm29Domain::build(const NttDomain& d, hipStream_t st) {
     logn = d.logn;
     n = d.n;
     const uint64_t half = n > 1 ? n / 2 : 1;
-    tw_fwd.alloc(half * 8);
-    tw_inv.alloc(half * 8);
+    tw_fwd.alloc(half * 12);
+    tw_inv.alloc(half * 12);
     coset.alloc(n * 8);
     icoset.alloc(n * 8);
-    k_to_packed29<<<ceil_div(half, 256), 256, 0, st>>>(d.tw_fwd.p, tw_fwd.p, half, 0, 0);
-    k_to_packed29<<<ceil_div(half, 256), 256, 0, st>>>(d.tw_inv.p, tw_inv.p, half, 0, 0);
+    k_to_limbs12<<<ceil_div(half, 256), 256, 0, st>>>(d.tw_fwd.p, tw_fwd.p, half);
+    k_to_limbs12<<<ceil_div(half, 256), 256, 0, st>>>(d.tw_inv.p, tw_inv.p, half);
     // NttDomain keeps the coset tables at bit-reversed positions; here they are indexed naturally
     k_to_packed29<<<ceil_div(n, 256), 256, 0, st>>>(d.coset_br.p, coset.p, n, 0, logn);
     k_to_packed29<<<ceil_div(n, 256), 256, 0, st>>>(d.icoset_br.p, icoset.p, n, 1, logn);
@@ -144,8 +184,20 @@ __device__ __forceinline__ void lds_put(uint32_t* s, uint32_t e, const Fr29& x) 
 
 struct Packed8 { uint32_t w[8]; };
 
+// DIT butterfly on lazy values: t = v·w;  (u, v) <- (u + t, u - t + 3N).  Limbs are NOT renormalised here.
+__device__ __forceinline__ void bfly(Fr29& u, Fr29& v, const Fr29& w) {
+    Fr29 t = mul(v, w);
+    v = sub<3, 1>(u, t);
+    u = add(u, t);
+}
+
 // LOAD: 0 = one input vector; 1 = (a∘b - c)·vinv from three vectors (r1cs_to_qap.rs:187,201-208)
-// STORE: 0 = canonical R' value; 1 = multiplied by scale[natural index] (coset factor / exit from Montgomery form)
+// STORE: 0 = value reduced just enough to pack; 1 = multiplied by scale[natural index] and made canonical
+//        (coset factor, or the exit from Montgomery form)
+// Stages are taken two at a time as radix-4 groups held in registers (three twiddle loads and ONE carry
+// propagation per element for two stages, half the barriers); an odd last stage runs radix-2.
+// Lazy-value bounds: a pass starts below 6N (packed inputs are < 2^256 = 5.3N), every stage adds at most 3N,
+// so after ten stages values stay under 36N and limbs, renormalised every second stage, under 2^32.
 template <int LOAD, int STORE>
 __global__ void __launch_bounds__(256) k_ntt29_pass(const uint32_t* __restrict__ in_a, const uint32_t* __restrict__ in_b,
                                                     const uint32_t* __restrict__ in_c, uint32_t* __restrict__ out,
@@ -160,28 +212,51 @@ __global__ void __launch_bounds__(256) k_ntt29_pass(const uint32_t* __restrict__
         if (LOAD == 1) {
             Fr29 bb = load_packed29(in_b, gi), cc = load_packed29(in_c, gi);
             Fr29 vinv = unpack29<Fr29P>(vinv_p.w);
-            x = mul(normalize(sub<2, 1>(mul(x, bb), cc)), vinv);
+            x = mul(normalize(sub<7, 1>(mul(x, bb), cc)), vinv);     // inputs < 5.3N each
         }
         lds_put(sm, e, x);
     }
     __syncthreads();
-    const uint32_t nbf = tsize >> 1;
-    for (int j = 0; j < pp.S; ++j) {
-        const int q = pp.q0 + j;                       // DIT stage q pairs global bit q
-        const int lb = pp.cbits + (q - pp.gbit_lo);     // its position inside the tile
+    int j = 0;
+    for (; j + 1 < pp.S; j += 2) {                      // radix-4: stages q and q+1
+        const int q = pp.q0 + j;
+        const int lb = pp.cbits + (q - pp.gbit_lo);
+        const uint32_t lmask = (1u << lb) - 1u;
+        const int sh1 = pp.logn - 1 - q, sh2 = pp.logn - 2 - q;
+        for (uint32_t b = threadIdx.x; b < (tsize >> 2); b += 256) {
+            const uint32_t e00 = ((b & ~lmask) << 2) | (b & lmask);
+            const uint32_t e01 = e00 | (1u << lb), e10 = e00 | (2u << lb), e11 = e00 | (3u << lb);
+            const uint32_t gi = l2g29(e00, tile, pp);
+            const uint32_t k = gi & ((1u << q) - 1u);
+            Fr29 x0 = lds_get(sm, e00), x1 = lds_get(sm, e01), x2 = lds_get(sm, e10), x3 = lds_get(sm, e11);
+            const Fr29 w1 = load_tw(tw, (uint64_t)k << sh1);
+            bfly(x0, x1, w1);
+            bfly(x2, x3, w1);
+            const Fr29 w2a = load_tw(tw, (uint64_t)k << sh2);
+            const Fr29 w2b = load_tw(tw, (uint64_t)(k + (1u << q)) << sh2);
+            bfly(x0, x2, w2a);
+            bfly(x1, x3, w2b);
+            lds_put(sm, e00, normalize(x0));
+            lds_put(sm, e01, normalize(x1));
+            lds_put(sm, e10, normalize(x2));
+            lds_put(sm, e11, normalize(x3));
+        }
+        __syncthreads();
+    }
+    if (j < pp.S) {                                     // odd stage count: one radix-2 stage
+        const int q = pp.q0 + j;
+        const int lb = pp.cbits + (q - pp.gbit_lo);
         const uint32_t lmask = (1u << lb) - 1u;
         const int tw_shift = pp.logn - 1 - q;
-        for (uint32_t b = threadIdx.x; b < nbf; b += 256) {
+        for (uint32_t b = threadIdx.x; b < (tsize >> 1); b += 256) {
             uint32_t e0 = ((b & ~lmask) << 1) | (b & lmask);
             uint32_t e1 = e0 | (1u << lb);
             uint32_t gi = l2g29(e0, tile, pp);
             uint32_t k = gi & ((1u << q) - 1u);
-            Fr29 w = load_packed29(tw, (uint64_t)k << tw_shift);
-            Fr29 u = lds_get(sm, e0);
-            Fr29 v = lds_get(sm, e1);
-            Fr29 t = mul(v, w);                          // < v/169 + 1 < 1.3 N
-            lds_put(sm, e0, normalize(add(u, t)));       // values grow by at most 3 N per stage: < 40 N over a pass
-            lds_put(sm, e1, normalize(sub<3, 1>(u, t)));
+            Fr29 u = lds_get(sm, e0), v = lds_get(sm, e1);
+            bfly(u, v, load_tw(tw, (uint64_t)k << tw_shift));
+            lds_put(sm, e0, normalize(u));
+            lds_put(sm, e1, normalize(v));
         }
         __syncthreads();
     }
@@ -196,7 +271,7 @@ __global__ void __launch_bounds__(256) k_ntt29_pass(const uint32_t* __restrict__
         Fr29 x = lds_get(sm, e);
         Fr29 y;
         if (STORE == 1) y = cond_sub_n(mul(x, load_packed29(scale, gi)));
-        else y = canonical(x);
+        else y = weak_reduce(x);
         store_packed29(out, store_bitrev ? brev(gi, pp.logn) : gi, y);
     }
 }

@@ -16,7 +16,7 @@ namespace cg {
 struct Wm29Domain {
     int logn = 0;
     uint64_t n = 0;
-    DevBuf<uint32_t> tw_fwd;     // ω^e   (e < n/2), R' form, 8 words each
+    DevBuf<uint32_t> tw_fwd;     // ω^e   (e < n/2), R' form, nine 29-bit limbs in a 12-word record
     DevBuf<uint32_t> tw_inv;     // ω^-e
     DevBuf<uint32_t> coset;      // g^i / n   at natural index i, R' form      (r1cs_to_qap.rs:182-185 + the 1/n of :179-180)
     DevBuf<uint32_t> icoset;     // g^-i / n  at natural index i, PLAIN form (multiplying by it also leaves Montgomery form)
