@@ -213,28 +213,26 @@ __device__ __forceinline__ void for_each_digit(const uint32_t s[8], int c, int W
 }
 
 __global__ void __launch_bounds__(256) k_digit_count(const Fr* __restrict__ scalars, const uint8_t* __restrict__ valid,
-                                                     uint64_t n, int c, int W, uint32_t* __restrict__ counts,
-                                                     uint32_t* __restrict__ nz_counter) {
+                                                     uint64_t n, int c, int W, uint64_t* __restrict__ counts) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
     uint32_t cnt = 0;
-    if (i < n && valid[i]) {
+    if (valid[i]) {
         Fr s = scalars[i];
         for_each_digit(s.l, c, W, [&](int, int32_t d) { cnt += (d != 0); });
     }
-    if (i < n) counts[i] = cnt;
-    // one atomic per wave: how many scalars contribute at all (statistics for the window choice)
-    unsigned long long m = __ballot(cnt != 0);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(nz_counter, (uint32_t)__popcll(m));
+    // the high word counts the scalars that contribute at all (statistics for the window choice); one scan sums both
+    counts[i] = (uint64_t)cnt | ((uint64_t)(cnt != 0) << 32);
 }
 
 __global__ void __launch_bounds__(256) k_digit_emit(const Fr* __restrict__ scalars, const uint8_t* __restrict__ valid,
-                                                    uint64_t n, int c, int W, const uint32_t* __restrict__ incl,
+                                                    uint64_t n, int c, int W, const uint64_t* __restrict__ incl,
                                                     uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
                                                     int precomputed) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (!valid[i]) return;
-    uint32_t pos = i ? incl[i - 1] : 0u;
+    uint32_t pos = i ? (uint32_t)incl[i - 1] : 0u;
     Fr s = scalars[i];
     const uint32_t nb = 1u << (c - 1);
     for_each_digit(s.l, c, W, [&](int j, int32_t d) {
@@ -485,7 +483,7 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
     thread_counts.alloc(n ? n : 1);
     // rocPRIM temp sizes for the worst case
     size_t scan_bytes = 0, sort_bytes = 0;
-    (void)rocprim::inclusive_scan(nullptr, scan_bytes, thread_counts.p, thread_counts.p, (size_t)(n ? n : 1), rocprim::plus<uint32_t>());
+    (void)rocprim::inclusive_scan(nullptr, scan_bytes, thread_counts.p, thread_counts.p, (size_t)(n ? n : 1), rocprim::plus<uint64_t>());
     (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, keys_a.p, keys_b.p, vals_a.p, vals_b.p, (size_t)cap_entries, 0u, 32u);
     sort_tmp_bytes = scan_bytes > sort_bytes ? scan_bytes : sort_bytes;
     sort_tmp.alloc(sort_tmp_bytes ? sort_tmp_bytes : 1);
@@ -508,8 +506,7 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
         cols_buf.alloc((size_t)(1u << cbits) * wins * ACC);
     }
     result.alloc((size_t)wins * 2 * ACC);      // per window: rows part, columns part
-    nz_counter.alloc(1);
-    h_count.alloc(2);
+    h_count.alloc(1);
     h_result.alloc((size_t)wins * 2 * ACC);
     if (!ev_count) {
         CG_HIP(hipEventCreateWithFlags(&ev_count, hipEventDisableTiming));
@@ -537,17 +534,14 @@ void MsmEngine<F>::digits(const Fr* scalars_dev, uint64_t n, hipStream_t st) {
     if (n > bases->n) n = bases->n;  // msm_bigint zips and truncates to the shorter operand
     n_scalars = n;
     h_count.p[0] = 0;
-    h_count.p[1] = 0;
     CG_HIP(hipEventRecord(ev_t[0], st));
     if (!n) return;
     const int c = bases->c, W = bases->W;
-    CG_HIP(hipMemsetAsync(nz_counter.p, 0, 4, st));
-    k_digit_count<<<ceil_div(n, 256), 256, 0, st>>>(scalars_dev, bases->valid.p, n, c, W, thread_counts.p, nz_counter.p);
+    k_digit_count<<<ceil_div(n, 256), 256, 0, st>>>(scalars_dev, bases->valid.p, n, c, W, thread_counts.p);
     CG_KERNEL_CHECK();
     size_t tmp = sort_tmp_bytes;
-    CG_HIP(rocprim::inclusive_scan(sort_tmp.p, tmp, thread_counts.p, thread_counts.p, (size_t)n, rocprim::plus<uint32_t>(), st));
-    CG_HIP(hipMemcpyAsync(h_count.p, thread_counts.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    CG_HIP(hipMemcpyAsync(h_count.p + 1, nz_counter.p, 4, hipMemcpyDeviceToHost, st));
+    CG_HIP(rocprim::inclusive_scan(sort_tmp.p, tmp, thread_counts.p, thread_counts.p, (size_t)n, rocprim::plus<uint64_t>(), st));
+    CG_HIP(hipMemcpyAsync(h_count.p, thread_counts.p + (n - 1), 8, hipMemcpyDeviceToHost, st));
     CG_HIP(hipEventRecord(ev_count, st));
     k_digit_emit<<<ceil_div(n, 256), 256, 0, st>>>(scalars_dev, bases->valid.p, n, c, W, thread_counts.p, keys_a.p, vals_a.p,
                                                   bases->precomputed ? 1 : 0);
@@ -562,8 +556,8 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
     n_nonzero = 0;
     if (n_scalars) {
         CG_HIP(hipEventSynchronize(ev_count));
-        n_entries = h_count.p[0];
-        n_nonzero = h_count.p[1];
+        n_entries = (uint32_t)h_count.p[0];
+        n_nonzero = (uint32_t)(h_count.p[0] >> 32);
     }
     CG_HIP(hipMemsetAsync(bucket_sums.p, 0, bucket_sums.bytes(), st));
     if (n_entries) {

@@ -43,7 +43,7 @@ struct MsmEngine {
     uint64_t cap_entries = 0;
     uint32_t nbuckets_total = 0;  // buckets per window * windows-in-key-space
     DevBuf<uint32_t> keys_a, keys_b, vals_a, vals_b;
-    DevBuf<uint32_t> thread_counts;   // per-scalar non-zero digit count, then inclusive offsets
+    DevBuf<uint64_t> thread_counts;   // per scalar: non-zero digit count (low word) + "has any" flag (high word); then their inclusive scan
     DevBuf<uint8_t> sort_tmp;
     size_t sort_tmp_bytes = 0;
     DevBuf<uint32_t> bucket_sums;     // nbuckets_total * ACC
@@ -52,8 +52,7 @@ struct MsmEngine {
     DevBuf<uint32_t> red_a, red_b;
     DevBuf<uint32_t> rows_buf, cols_buf;   // row / column sums of the bucket matrix (bucket reduction)
     DevBuf<uint32_t> result;          // W_keyspace accumulators (1 when precomputed)
-    DevBuf<uint32_t> nz_counter;      // scalars with at least one non-zero digit (device)
-    PinnedBuf<uint32_t> h_count;      // [0] entries, [1] non-zero scalars
+    PinnedBuf<uint64_t> h_count;      // low word: entries, high word: scalars with a non-zero digit
     PinnedBuf<uint32_t> h_result;
     uint64_t n_scalars = 0;
     uint32_t n_entries = 0;
