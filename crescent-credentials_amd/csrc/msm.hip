@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(256) k_sum_points(const uint32_t* __restrict__
 // ---------------------------------------------------------------------------------------------
 // engine
 // ---------------------------------------------------------------------------------------------
-static constexpr uint32_t ACC_TARGET_THREADS = 256u * 4u * 4u * 64u * 2u;  // CUs x SIMDs x waves x lanes x rounds
+static constexpr uint32_t ACC_TARGET_THREADS = 256u * 4u * 4u * 64u;  // CUs x SIMDs x waves x lanes: one fully resident round
 static constexpr uint32_t ACC_MIN_L = 16;
 static constexpr uint32_t ACC_LEVEL_L = 8;   // segment length of the partial-combining levels
 static constexpr uint32_t RED_F_BIG = 4;     // fan-in of a row/column-sum step while the step still fills the GPU ...
@@ -559,7 +559,7 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
         n_entries = (uint32_t)h_count.p[0];
         n_nonzero = (uint32_t)(h_count.p[0] >> 32);
     }
-    CG_HIP(hipMemsetAsync(bucket_sums.p, 0, bucket_sums.bytes(), st));
+    fill_zero(bucket_sums.p, bucket_sums.bytes(), st);
     if (n_entries) {
         const uint32_t N = n_entries;
         int key_bits = bases->c - 1;

@@ -95,6 +95,20 @@ __global__ void __launch_bounds__(256) k_unbitrev_scale(const Fr* in, Fr* out, c
 
 static inline dim3 grid_for(uint64_t n) { return dim3(ceil_div(n, 256)); }
 
+__global__ void __launch_bounds__(256) k_fill_zero(uint4* __restrict__ p, uint64_t n16) {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) p[i] = z;
+}
+void fill_zero(void* dst, size_t bytes, hipStream_t st) {
+    if (!bytes) return;
+    if (bytes % 16) { CG_HIP(hipMemsetAsync(dst, 0, bytes, st)); return; }
+    const uint64_t n16 = bytes / 16;
+    uint32_t blocks = ceil_div(n16, 256 * 8);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    k_fill_zero<<<blocks ? blocks : 1, 256, 0, st>>>(reinterpret_cast<uint4*>(dst), n16);
+    CG_KERNEL_CHECK();
+}
+
 void fr_to_mont(const Fr* in, Fr* out, uint64_t n, hipStream_t st) {
     if (!n) return;
     k_to_mont<<<grid_for(n), 256, 0, st>>>(in, out, n);

@@ -328,7 +328,7 @@ void wm29_run(const Wm29Domain& dom, const DevCsr& A, const DevCsr& B, const Dev
     const DevCsr* mats[3] = {&A, &B, &C};
     const Csr29* dicts[3] = {&dA, &dB, &dC};
     for (int k = 0; k < 3; ++k) {
-        CG_HIP(hipMemsetAsync(v[k], 0, D * 32, st));
+        fill_zero(v[k], D * 32, st);
         if (mats[k]->rows) {
             k_spmv29<<<ceil_div(mats[k]->rows, 256), 256, 0, st>>>(mats[k]->row_ptr.p, mats[k]->col.p, mats[k]->coef_idx.p, dicts[k]->dict.p,
                                                                    buf.w29.p, v[k], mats[k]->rows, logn);
