@@ -14,6 +14,8 @@ from .api import (  # noqa: F401
     Prover,
     ProvingKey,
     R1CSFile,
+    proving_key_from_bytes,
+    proving_key_to_bytes,
     VerifyingKey,
     fft_in_place,
     ifft_in_place,

@@ -93,6 +93,11 @@ _SIGNATURES = {
     "cg_r1cs_parse": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "cg_r1cs_get": (C.c_int, [C.c_void_p, C.POINTER(_CgR1csHeader), C.POINTER(_CgCsr), C.POINTER(C.c_void_p)]),
     "cg_r1cs_free": (None, [C.c_void_p]),
+    "cg_pk_parse": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    "cg_pk_get": (C.c_int, [C.c_void_p, C.POINTER(_CgProvingKey), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    "cg_pk_free": (None, [C.c_void_p]),
+    "cg_pk_serialized_size": (C.c_uint64, [C.POINTER(_CgProvingKey), C.c_uint64]),
+    "cg_pk_serialize": (C.c_int, [C.POINTER(_CgProvingKey), C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
 }
 
 _lib = None
@@ -422,6 +427,45 @@ def fft_in_place(data, coset: bool = False) -> np.ndarray:
 def ifft_in_place(data, coset: bool = False) -> np.ndarray:
     """EvaluationDomain::ifft_in_place (r1cs_to_qap.rs:179-180,210)."""
     return _ntt(data, True, coset)
+
+
+def proving_key_from_bytes(data) -> Tuple["ProvingKey", int]:
+    """`ProvingKey::deserialize_uncompressed_unchecked` (what creds/src/utils.rs:179-189 does to the head of
+    prover_params.bin).  Returns (key with canonical packed arrays, bytes consumed)."""
+    L = lib()
+    buf = _u8(data)
+    h = C.c_void_p()
+    used = C.c_uint64()
+    _check(L.cg_pk_parse(_ptr(buf), buf.size, C.byref(h), C.byref(used)))
+    try:
+        v = _CgProvingKey()
+        g2 = C.c_void_p(); gabc = C.c_void_p(); ngabc = C.c_uint64()
+        _check(L.cg_pk_get(h, C.byref(v), C.byref(g2), C.byref(gabc), C.byref(ngabc)))
+
+        def arr(ptr, nbytes):
+            if not nbytes:
+                return np.zeros(0, np.uint8)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(nbytes,)).copy()
+        vk = VerifyingKey(alpha_g1=arr(v.alpha_g1, 64), beta_g2=arr(v.beta_g2, 128), gamma_g2=arr(g2, 128),
+                          delta_g1=arr(v.delta_g1, 64), delta_g2=arr(v.delta_g2, 128), gamma_abc_g1=arr(gabc, 64 * ngabc.value))
+        pk = ProvingKey(vk=vk, beta_g1=arr(v.beta_g1, 64), delta_g1=arr(v.delta_g1, 64), a_query=arr(v.a_query, 64 * v.a_len),
+                        b_g1_query=arr(v.b_g1_query, 64 * v.b_g1_len), b_g2_query=arr(v.b_g2_query, 128 * v.b_g2_len),
+                        h_query=arr(v.h_query, 64 * v.h_len), l_query=arr(v.l_query, 64 * v.l_len))
+    finally:
+        L.cg_pk_free(h)
+    return pk, int(used.value)
+
+
+def proving_key_to_bytes(pk: "ProvingKey") -> bytes:
+    """`ProvingKey::serialize_uncompressed` (creds/src/utils.rs:140-152)."""
+    L = lib()
+    cpk = pk._c()
+    n = pk.vk.gamma_abc_g1.size // 64
+    size = int(L.cg_pk_serialized_size(C.byref(cpk), n))
+    out = np.zeros(size, np.uint8)
+    gabc = pk.vk.gamma_abc_g1 if n else np.zeros(64, np.uint8)
+    _check(L.cg_pk_serialize(C.byref(cpk), _ptr(pk.vk.gamma_g2), _ptr(gabc), n, _ptr(out), size))
+    return out.tobytes()
 
 
 class R1CSFile:

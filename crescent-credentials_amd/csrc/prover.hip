@@ -358,6 +358,7 @@ static int prove_partial_impl(cg_ctx* c, ProofSlot* S, const void* assignment, b
     S->eb2.accumulate(S->st[4]);
     S->eh.accumulate(s0);
     for (int i = 0; i < 5; ++i) CG_HIP(hipStreamSynchronize(S->st[i]));
+    if (S->wm.h_bad_input.p[0]) return fail(CG_ERR_INVALID_ARGUMENT, "full_assignment holds a value >= the scalar field modulus");
     P.h = to_affine(S->eh.value());
     P.l = to_affine(S->el.value());
     P.a = to_affine(S->ea.value());
@@ -565,6 +566,7 @@ extern "C" int cg_witness_map(cg_ctx* ctx, const uint8_t* full_assignment, uint8
         run_witness_map(ctx, S, S->w_canon.p, s0);
         CG_HIP(hipMemcpyAsync(h_out, S->h_canon.p, ctx->D * 32, hipMemcpyDeviceToHost, s0));
         CG_HIP(hipStreamSynchronize(s0));
+        if (S->wm.h_bad_input.p[0]) return fail(CG_ERR_INVALID_ARGUMENT, "full_assignment holds a value >= the scalar field modulus");
         return CG_OK;
     } catch (...) {
         return translate_exception();

@@ -114,10 +114,19 @@ void Csr29::build(const DevCsr& m, hipStream_t st) {
 }
 
 // ---- witness -> R' form; sparse products --------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_w_to29(const Fr* __restrict__ w, uint32_t* __restrict__ out, uint64_t n) {
+__global__ void __launch_bounds__(256) k_w_to29(const Fr* __restrict__ w, uint32_t* __restrict__ out, uint64_t n,
+                                                uint32_t* __restrict__ bad_input) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    store_packed29(out, i, from_canonical_bytes<Fr29P>(w[i]));
+    Fr x = w[i];
+    // the reference's scalars are field elements by type; across a C ABI they are bytes, so check (x < r)
+    bool lt = false, decided = false;
+#pragma unroll
+    for (int k = 7; k >= 0; --k) {
+        if (!decided && x.l[k] != FrP::N[k]) { lt = x.l[k] < FrP::N[k]; decided = true; }
+    }
+    if (!lt) *bad_input = 1u;
+    store_packed29(out, i, from_canonical_bytes<Fr29P>(x));
 }
 
 // out[rev(i)] = <M_i, w>, i < rows  (evaluate_constraint, r1cs_to_qap.rs:16-45); the output vector is the
@@ -322,8 +331,10 @@ void wm29_run(const Wm29Domain& dom, const DevCsr& A, const DevCsr& B, const Dev
               hipStream_t st) {
     const uint64_t D = dom.n;
     const int logn = dom.logn;
-    k_w_to29<<<ceil_div(M, 256), 256, 0, st>>>(w_canon, buf.w29.p, M);
+    CG_HIP(hipMemsetAsync(buf.bad_input.p, 0, 4, st));
+    k_w_to29<<<ceil_div(M, 256), 256, 0, st>>>(w_canon, buf.w29.p, M, buf.bad_input.p);
     CG_KERNEL_CHECK();
+    CG_HIP(hipMemcpyAsync(buf.h_bad_input.p, buf.bad_input.p, 4, hipMemcpyDeviceToHost, st));
     uint32_t* v[3] = {buf.va.p, buf.vb.p, buf.vc.p};
     const DevCsr* mats[3] = {&A, &B, &C};
     const Csr29* dicts[3] = {&dA, &dB, &dC};

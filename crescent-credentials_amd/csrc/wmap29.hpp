@@ -32,7 +32,12 @@ struct Csr29 {     // the matrices' coefficient dictionary in R' form (index arr
 struct Wm29Buffers {     // per proof slot
     DevBuf<uint32_t> w29;            // witness in R' form, M x 8 words
     DevBuf<uint32_t> va, vb, vc, vt; // D x 8 words each (vt: ping-pong partner of the bit-reversing stores)
-    void alloc(uint64_t M, uint64_t D) { w29.alloc(M * 8); va.alloc(D * 8); vb.alloc(D * 8); vc.alloc(D * 8); vt.alloc(D * 8); }
+    DevBuf<uint32_t> bad_input;      // set to 1 when a witness element is not a canonical field element
+    PinnedBuf<uint32_t> h_bad_input;
+    void alloc(uint64_t M, uint64_t D) {
+        w29.alloc(M * 8); va.alloc(D * 8); vb.alloc(D * 8); vc.alloc(D * 8); vt.alloc(D * 8);
+        bad_input.alloc(1); h_bad_input.alloc(1);
+    }
 };
 
 // w_canon: M canonical scalars on the device.  h_out: D canonical scalars (natural order), on the device.

@@ -213,6 +213,23 @@ int cg_r1cs_parse(const uint8_t* data, uint64_t len, cg_r1cs** out);
 int cg_r1cs_get(const cg_r1cs* r, cg_r1cs_header* header, cg_csr abc[3], const uint64_t** wire_mapping);
 void cg_r1cs_free(cg_r1cs* r);
 
+/* ark-serialize (uncompressed) proving key <-> packed arrays.
+ * Replaces: `read_from_file::<ProverParams>` / `write_to_file` for the `groth16_params: ProvingKey<Bn254>` that
+ *           leads creds' prover_params.bin (creds/src/utils.rs:140-152,179-189; creds/src/lib.rs:58-63;
+ *           field order forks/groth16/src/data_structures.rs:31-44,101-118).  Parsing is the reference's
+ *           `deserialize_uncompressed_unchecked`: flags stripped, no curve / subgroup checks.
+ * cg_pk_parse reads one ProvingKey from the start of `data` (bytes_consumed, optional, tells where the
+ * PreparedVerifyingKey / config string that follow in prover_params.bin begin); cg_pk_get fills a view valid
+ * until cg_pk_free, plus the verifying-key members the prover itself does not need. */
+typedef struct cg_pk cg_pk;
+int cg_pk_parse(const uint8_t* data, uint64_t len, cg_pk** out, uint64_t* bytes_consumed);
+int cg_pk_get(const cg_pk* k, cg_proving_key* view, const uint8_t** gamma_g2, const uint8_t** gamma_abc_g1,
+              uint64_t* gamma_abc_len);
+void cg_pk_free(cg_pk* k);
+uint64_t cg_pk_serialized_size(const cg_proving_key* pk, uint64_t gamma_abc_len);
+int cg_pk_serialize(const cg_proving_key* pk, const uint8_t* gamma_g2, const uint8_t* gamma_abc_g1,
+                    uint64_t gamma_abc_len, uint8_t* out, uint64_t out_len);
+
 /* Library / device description for logs ("crescent_gpu 0.1 gfx950 ..."). */
 const char* cg_version(void);
 

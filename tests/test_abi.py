@@ -107,3 +107,64 @@ def test_no_cpu_fallback_in_product():
             elif fn.endswith((".hip", ".cuh", ".hpp", ".cpp", ".h")):
                 txt = open(path, errors="replace").read()
                 assert not re.search(r'#include\s+"[^"]*oracle', txt), "%s includes oracle code" % fn
+
+
+# ---- ark-serialize proving key reader / writer (host-only) --------------------------------------
+def _oracle_pk(oracle, j):
+    g1s = lambda h: [oracle.g1_unpack(bytes.fromhex(h)[i:i + 64]) for i in range(0, len(h) // 2, 64)]
+    g2s = lambda h: [oracle.g2_unpack(bytes.fromhex(h)[i:i + 128]) for i in range(0, len(h) // 2, 128)]
+    vk = dict(alpha_g1=g1s(j["alpha_g1"])[0], beta_g2=g2s(j["beta_g2"])[0], gamma_g2=g2s(j["gamma_g2"])[0],
+              delta_g1=g1s(j["delta_g1"])[0], delta_g2=g2s(j["delta_g2"])[0], gamma_abc_g1=g1s(j["gamma_abc_g1"]))
+    return dict(vk=vk, beta_g1=g1s(j["beta_g1"])[0], delta_g1=vk["delta_g1"], a_query=g1s(j["a_query"]),
+                b_g1_query=g1s(j["b_g1_query"]), b_g2_query=g2s(j["b_g2_query"]), h_query=g1s(j["h_query"]),
+                l_query=g1s(j["l_query"]))
+
+
+def test_proving_key_ark_serialize_roundtrip(cc, oracle):
+    """bytes written by the oracle's ark-serialize encoder (data_structures.rs field order, SWFlags) parse into the
+    golden packed arrays, and serialise back to the same bytes (flags recomputed by the library)."""
+    g = load_golden("groth16_d8.json")
+    blob = oracle.pk_uncompressed(_oracle_pk(oracle, g["pk"]))
+    # prover_params.bin carries more after the key (PreparedVerifyingKey, config string): trailing bytes are left alone
+    pk, used = cc.proving_key_from_bytes(blob + b"\x07" * 100)
+    assert used == len(blob)
+    j = g["pk"]
+    for name in ("a_query", "b_g1_query", "b_g2_query", "h_query", "l_query"):
+        assert getattr(pk, name).tobytes().hex() == j[name], name
+    assert pk.vk.gamma_abc_g1.tobytes().hex() == j["gamma_abc_g1"]
+    assert pk.vk.alpha_g1.tobytes().hex() == j["alpha_g1"] and pk.vk.gamma_g2.tobytes().hex() == j["gamma_g2"]
+    assert pk.beta_g1.tobytes().hex() == j["beta_g1"] and pk.delta_g1.tobytes().hex() == j["delta_g1"]
+    # the d8 key has identity points (zero QAP columns): they travel as the infinity flag, not as coordinates
+    assert any(blob[i + 63] & 0x40 for i in range(0, 64, 64)) or bytes(64) in [pk.a_query[k:k + 64].tobytes() for k in range(0, pk.a_query.size, 64)]
+    assert cc.proving_key_to_bytes(pk) == blob
+
+
+def test_proving_key_parse_rejects_truncation(cc, oracle):
+    g = load_golden("groth16_d8.json")
+    blob = oracle.pk_uncompressed(_oracle_pk(oracle, g["pk"]))
+    with pytest.raises(cc.CrescentGpuError) as ei:
+        cc.proving_key_from_bytes(blob[:-10])
+    assert ei.value.code == -7
+    bad = bytearray(blob)
+    off = 64 + 128 + 128 + 64 + 128          # gamma_abc_g1 length field
+    bad[off:off + 8] = (1 << 40).to_bytes(8, "little")
+    with pytest.raises(cc.CrescentGpuError):
+        cc.proving_key_from_bytes(bytes(bad))
+
+
+def test_circuit_load_validates_before_touching_the_gpu(cc):
+    """argument errors are reported by the C ABI with the reference's vocabulary (no GPU needed)"""
+    L = cc.lib()
+    assert L.cg_circuit_load(None, None, None, 1, 1, 2, None) == -1
+    from crescent_credentials_amd import api
+    pk = api._CgProvingKey()
+    pk.coord_form = 0
+    pk.a_len = pk.b_g1_len = pk.b_g2_len = 7
+    pk.l_len = 4
+    pk.h_len = 5                     # must be D - 1 = 7 for m = 4, l = 3
+    abc = (api._CgCsr * 3)()
+    h = ctypes.c_void_p()
+    rc = L.cg_circuit_load(ctypes.byref(h), ctypes.byref(pk), abc, 3, 4, 7, None)
+    assert rc == -6 and b"h_query" in L.cg_last_error()
+    rc = L.cg_circuit_load(ctypes.byref(h), ctypes.byref(pk), abc, 3, (1 << 28) + 5, (1 << 28) + 9, None)
+    assert rc == -5            # PolynomialDegreeTooLarge (r1cs_to_qap.rs:156-157)

@@ -360,3 +360,23 @@ def test_prove_medium_properties(cc, oracle, bit_fraction):
         # A(0) itself against the trapdoor closed form: [alpha + Σ w_i a_i(tau)]·G, with a_i(tau) recomputed sparsely
     finally:
         p1.close(); p2.close()
+
+
+def test_non_canonical_witness_is_rejected(cc, oracle):
+    g = load_golden("groth16_d8.json")
+    cm, _ = _case_matrices(cc, oracle, g)
+    pk = _pk_from_json(cc, g["pk"])
+    w = [int(x, 16) for x in g["witness"]]
+    prover = cc.Prover(pk, cm)
+    try:
+        bad = list(w); bad[3] = oracle.R          # = modulus: not a canonical field element
+        with pytest.raises(cc.CrescentGpuError) as ei:
+            prover.prove(_scalars(bad), 1, 2)
+        assert ei.value.code == -1 and "modulus" in str(ei.value)
+        with pytest.raises(cc.CrescentGpuError):
+            prover.witness_map(_scalars(bad))
+        # the context stays usable
+        case = g["proofs"][1]
+        assert prover.prove(_scalars(w), int(case["r"], 16), int(case["s"], 16)).data.hex() == case["proof"]
+    finally:
+        prover.close()
