@@ -227,8 +227,7 @@ __global__ void __launch_bounds__(256) k_digit_count(const Fr* __restrict__ scal
 
 __global__ void __launch_bounds__(256) k_digit_emit(const Fr* __restrict__ scalars, const uint8_t* __restrict__ valid,
                                                     uint64_t n, int c, int W, const uint64_t* __restrict__ incl,
-                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                    int precomputed) {
+                                                    uint64_t* __restrict__ entries, int precomputed) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (!valid[i]) return;
@@ -239,13 +238,8 @@ __global__ void __launch_bounds__(256) k_digit_emit(const Fr* __restrict__ scala
         if (d != 0) {
             uint32_t mag = (uint32_t)(d < 0 ? -d : d);
             uint32_t sign = d < 0 ? 0x80000000u : 0u;
-            if (precomputed) {
-                keys[pos] = mag - 1u;
-                vals[pos] = (uint32_t)((uint64_t)j * n + i) | sign;
-            } else {
-                keys[pos] = (uint32_t)j * nb + (mag - 1u);
-                vals[pos] = (uint32_t)i | sign;
-            }
+            if (precomputed) entries[pos] = ((uint64_t)(mag - 1u) << 32) | ((uint32_t)((uint64_t)j * n + i) | sign);
+            else entries[pos] = ((uint64_t)((uint32_t)j * nb + (mag - 1u)) << 32) | ((uint32_t)i | sign);
             ++pos;
         }
     });
@@ -268,7 +262,7 @@ __device__ __forceinline__ void flush_run(uint32_t key, const XYZZ29<F29T>& acc,
 }
 
 template <class F29T>
-__global__ void __launch_bounds__(256) k_accum_affine(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+__global__ void __launch_bounds__(256) k_accum_affine(const uint64_t* __restrict__ entries,
                                                       uint32_t N, uint32_t L, uint32_t T, const uint32_t* __restrict__ table,
                                                       uint32_t* __restrict__ bucket_sums, uint32_t* __restrict__ part_keys,
                                                       uint32_t* __restrict__ part_pts) {
@@ -280,11 +274,11 @@ __global__ void __launch_bounds__(256) k_accum_affine(const uint32_t* __restrict
     uint32_t end = beg + L < N ? beg + L : N;
     XYZZ29<F29T> acc;
     bool inf = true;
-    uint32_t cur = keys[beg];
+    uint32_t cur = (uint32_t)(entries[beg] >> 32);
     bool first = true;
     for (uint32_t k = beg; k < end; ++k) {
-        uint32_t key = keys[k];
-        uint32_t v = vals[k];
+        const uint64_t ent = entries[k];
+        const uint32_t key = (uint32_t)(ent >> 32), v = (uint32_t)ent;
         if (key != cur) {
             flush_run(cur, acc, inf, first, final_level, t, bucket_sums, part_keys, part_pts);
             first = false;
@@ -478,13 +472,12 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
     if (cap_entries == 0) cap_entries = 1;
     const uint32_t nb = 1u << (b->c - 1);
     nbuckets_total = b->precomputed ? nb : nb * (uint32_t)W;
-    keys_a.alloc(cap_entries); keys_b.alloc(cap_entries);
-    vals_a.alloc(cap_entries); vals_b.alloc(cap_entries);
+    ent_a.alloc(cap_entries); ent_b.alloc(cap_entries);
     thread_counts.alloc(n ? n : 1);
     // rocPRIM temp sizes for the worst case
     size_t scan_bytes = 0, sort_bytes = 0;
     (void)rocprim::inclusive_scan(nullptr, scan_bytes, thread_counts.p, thread_counts.p, (size_t)(n ? n : 1), rocprim::plus<uint64_t>());
-    (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, keys_a.p, keys_b.p, vals_a.p, vals_b.p, (size_t)cap_entries, 0u, 32u);
+    (void)rocprim::radix_sort_keys(nullptr, sort_bytes, ent_a.p, ent_b.p, (size_t)cap_entries, 32u, 64u);
     sort_tmp_bytes = scan_bytes > sort_bytes ? scan_bytes : sort_bytes;
     sort_tmp.alloc(sort_tmp_bytes ? sort_tmp_bytes : 1);
     bucket_sums.alloc((size_t)nbuckets_total * ACC);
@@ -543,7 +536,7 @@ void MsmEngine<F>::digits(const Fr* scalars_dev, uint64_t n, hipStream_t st) {
     CG_HIP(rocprim::inclusive_scan(sort_tmp.p, tmp, thread_counts.p, thread_counts.p, (size_t)n, rocprim::plus<uint64_t>(), st));
     CG_HIP(hipMemcpyAsync(h_count.p, thread_counts.p + (n - 1), 8, hipMemcpyDeviceToHost, st));
     CG_HIP(hipEventRecord(ev_count, st));
-    k_digit_emit<<<ceil_div(n, 256), 256, 0, st>>>(scalars_dev, bases->valid.p, n, c, W, thread_counts.p, keys_a.p, vals_a.p,
+    k_digit_emit<<<ceil_div(n, 256), 256, 0, st>>>(scalars_dev, bases->valid.p, n, c, W, thread_counts.p, ent_a.p,
                                                   bases->precomputed ? 1 : 0);
     CG_KERNEL_CHECK();
 }
@@ -567,14 +560,14 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
         if (key_bits < 1) key_bits = 1;
         size_t tmp = sort_tmp_bytes;
         CG_HIP(hipEventRecord(ev_t[1], st));
-        CG_HIP(rocprim::radix_sort_pairs(sort_tmp.p, tmp, keys_a.p, keys_b.p, vals_a.p, vals_b.p, (size_t)N, 0u,
-                                         (unsigned)key_bits, st));
+        // one 64-bit record per entry, sorted on the key bits only (stable: ties keep emission order)
+        CG_HIP(rocprim::radix_sort_keys(sort_tmp.p, tmp, ent_a.p, ent_b.p, (size_t)N, 32u, 32u + (unsigned)key_bits, st));
         CG_HIP(hipEventRecord(ev_t[2], st));
         // level 1
         uint32_t L = level1_L(N);
         uint32_t T = ceil_div(N, L);
         CG_HIP(hipEventRecord(ev_t[3], st));
-        k_accum_affine<F29T><<<ceil_div(T, 256), 256, 0, st>>>(keys_b.p, vals_b.p, N, L, T, bases->table.p, bucket_sums.p,
+        k_accum_affine<F29T><<<ceil_div(T, 256), 256, 0, st>>>(ent_b.p, N, L, T, bases->table.p, bucket_sums.p,
                                                                part_keys_a.p, part_pts_a.p);
         CG_KERNEL_CHECK();
         CG_HIP(hipEventRecord(ev_t[4], st));

@@ -42,7 +42,7 @@ struct MsmEngine {
     const MsmBases<F>* bases = nullptr;
     uint64_t cap_entries = 0;
     uint32_t nbuckets_total = 0;  // buckets per window * windows-in-key-space
-    DevBuf<uint32_t> keys_a, keys_b, vals_a, vals_b;
+    DevBuf<uint64_t> ent_a, ent_b;    // digit entries: bucket key in the high word, table index | sign<<31 in the low word
     DevBuf<uint64_t> thread_counts;   // per scalar: non-zero digit count (low word) + "has any" flag (high word); then their inclusive scan
     DevBuf<uint8_t> sort_tmp;
     size_t sort_tmp_bytes = 0;
