@@ -186,7 +186,7 @@ def main():
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u32 limbs (BN254 Fq/Fr, 254-bit modular integers)",
         "data": "synthetic",
-        "config": {"workload": "%s shape S21: D=2^%d, m=%d, M=%d, l=%d; witness=%s; pk from seeded trapdoor (GPU setup)" %
+        "config": {"workload": "%s shape: D=2^%d, m=%d, M=%d, l=%d; witness=%s; pk from seeded trapdoor (GPU setup)" %
                    (a.shape, prover.domain_size.bit_length() - 1, m, M, l, a.witness),
                    "mode": a.mode, "proofs_per_rank": a.steps, "proofs_in_flight_per_gpu": inflight,
                    "inputs": "witness resident in HBM; (r,s) fresh per proof"},
