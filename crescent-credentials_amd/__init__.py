@@ -10,6 +10,8 @@ from .api import (  # noqa: F401
     ConstraintMatrices,
     Groth16,
     LibsnarkReduction,
+    MsmContext,
+    NttContext,
     Proof,
     Prover,
     ProvingKey,
@@ -18,6 +20,8 @@ from .api import (  # noqa: F401
     proving_key_to_bytes,
     VerifyingKey,
     fft_in_place,
+    fixed_base_g1,
+    fixed_base_g2,
     ifft_in_place,
     generate_parameters_with_qap,
     lib,

@@ -89,6 +89,15 @@ _SIGNATURES = {
     "cg_msm_g1": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p]),
     "cg_msm_g2": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p]),
     "cg_ntt": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_int]),
+    "cg_msm_load_g1": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(_CgOptions)]),
+    "cg_msm_load_g2": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(_CgOptions)]),
+    "cg_msm_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.POINTER(CgTimings)]),
+    "cg_msm_free": (None, [C.c_void_p]),
+    "cg_ntt_load": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.c_int32]),
+    "cg_ntt_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "cg_ntt_free": (None, [C.c_void_p]),
+    "cg_fixed_base_g1": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
+    "cg_fixed_base_g2": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     "cg_setup": (C.c_int, [C.POINTER(_CgCsr), C.c_uint64, C.c_uint64, C.c_uint64] + [C.c_void_p] * 11),
     "cg_r1cs_parse": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "cg_r1cs_get": (C.c_int, [C.c_void_p, C.POINTER(_CgR1csHeader), C.POINTER(_CgCsr), C.POINTER(C.c_void_p)]),
@@ -427,6 +436,96 @@ def fft_in_place(data, coset: bool = False) -> np.ndarray:
 def ifft_in_place(data, coset: bool = False) -> np.ndarray:
     """EvaluationDomain::ifft_in_place (r1cs_to_qap.rs:179-180,210)."""
     return _ntt(data, True, coset)
+
+
+class MsmContext:
+    """A fixed set of G1 (group=1) or G2 (group=2) bases resident on the GPU with its window tables; `run` is
+    msm_bigint against them (cg_msm_load_* / cg_msm_run)."""
+
+    def __init__(self, bases, group: int = 1, coord_form: int = CG_FORM_CANONICAL, window_bits: int = 0, device: int = -1):
+        if group not in (1, 2):
+            raise ValueError("group must be 1 or 2")
+        self.group = group
+        self.point_bytes = 64 * group
+        b = _u8(bases)
+        if b.size % self.point_bytes:
+            raise ValueError("bases length is not a multiple of %d bytes" % self.point_bytes)
+        self.n = b.size // self.point_bytes
+        opt = _CgOptions(device=device, window_bits=window_bits)
+        self._h = C.c_void_p()
+        load = lib().cg_msm_load_g1 if group == 1 else lib().cg_msm_load_g2
+        _check(load(C.byref(self._h), _ptr(b) if b.size else None, coord_form, self.n, C.byref(opt)))
+
+    def run(self, scalars, timings: bool = False):
+        s = _u8(scalars)
+        return self._run(_ptr(s) if s.size else None, 0, s.size // 32, timings)
+
+    def run_dev(self, d_ptr: int, n_scalars: int, timings: bool = False):
+        """scalars already on this context's GPU (device pointer, n_scalars x 32 B canonical)"""
+        return self._run(d_ptr, 1, n_scalars, timings)
+
+    def _run(self, ptr, on_device, n, timings):
+        out = np.zeros(self.point_bytes, np.uint8)
+        tm = CgTimings()
+        _check(lib().cg_msm_run(self._h, ptr, on_device, n, _ptr(out), C.byref(tm) if timings else None))
+        return (out.tobytes(), tm.as_dict()) if timings else out.tobytes()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().cg_msm_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NttContext:
+    """A radix-2 domain of size 2^log_n resident on the GPU (cg_ntt_load / cg_ntt_run)."""
+
+    def __init__(self, log_n: int, device: int = -1):
+        self.log_n = log_n
+        self._h = C.c_void_p()
+        _check(lib().cg_ntt_load(C.byref(self._h), log_n, device))
+
+    def run(self, data, inverse: bool = False, coset: bool = False) -> np.ndarray:
+        a = _u8(data, 32 << self.log_n).copy()
+        _check(lib().cg_ntt_run(self._h, _ptr(a), 0, 1 if inverse else 0, 1 if coset else 0, None))
+        return a
+
+    def run_dev(self, d_ptr: int, inverse: bool = False, coset: bool = False) -> float:
+        """in place on device memory (2^log_n x 32 B canonical); returns the HIP-event time of the kernels in ms"""
+        ms = C.c_float(0)
+        _check(lib().cg_ntt_run(self._h, d_ptr, 1, 1 if inverse else 0, 1 if coset else 0, C.byref(ms)))
+        return float(ms.value)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().cg_ntt_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def fixed_base_g1(scalars) -> bytes:
+    """scalars[i]·G1 (FixedBase::msm, generator.rs:162-194) -> n x 64 B affine canonical"""
+    s = _u8(scalars)
+    out = np.zeros(s.size * 2, np.uint8)
+    _check(lib().cg_fixed_base_g1(_ptr(s) if s.size else None, s.size // 32, _ptr(out) if out.size else None))
+    return out.tobytes()
+
+
+def fixed_base_g2(scalars) -> bytes:
+    s = _u8(scalars)
+    out = np.zeros(s.size * 4, np.uint8)
+    _check(lib().cg_fixed_base_g2(_ptr(s) if s.size else None, s.size // 32, _ptr(out) if out.size else None))
+    return out.tobytes()
 
 
 def proving_key_from_bytes(data) -> Tuple["ProvingKey", int]:

@@ -107,4 +107,32 @@ inline bool fp_is_canonical(const Fp<P>& a) {  // a < N
     return false;
 }
 
+// ---- canonical byte <-> Montgomery point conversions (host) ----------------------------------------
+inline Fq fq_import(const uint8_t* b, uint32_t form) {
+    Fq a = fp_from_bytes<Fq>(b);
+    return form == CG_FORM_CANONICAL ? to_mont(a) : a;
+}
+inline G1Affine g1_import(const uint8_t* b, uint32_t form) { return {fq_import(b, form), fq_import(b + 32, form)}; }
+inline G2Affine g2_import(const uint8_t* b, uint32_t form) {
+    return {{fq_import(b, form), fq_import(b + 32, form)}, {fq_import(b + 64, form), fq_import(b + 96, form)}};
+}
+inline void g1_export_canonical(const G1Affine& p, uint8_t* out) {  // identity -> zeros
+    fp_to_bytes(from_mont(p.x), out);
+    fp_to_bytes(from_mont(p.y), out + 32);
+}
+inline void g2_export_canonical(const G2Affine& p, uint8_t* out) {
+    fp_to_bytes(from_mont(p.x.c0), out);
+    fp_to_bytes(from_mont(p.x.c1), out + 32);
+    fp_to_bytes(from_mont(p.y.c0), out + 64);
+    fp_to_bytes(from_mont(p.y.c1), out + 96);
+}
+
+inline bool scalar_is_zero(const uint8_t s[32]) {
+    for (int i = 0; i < 32; ++i) if (s[i]) return false;
+    return true;
+}
+inline bool scalar_is_canonical(const uint8_t s[32]) { return fp_is_canonical(fp_from_bytes<Fr>(s)); }
+
+int translate_current_exception();   // HipError / bad_alloc / std::exception in flight -> cg_status + last_error()
+
 }  // namespace cg

@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(256) k_digit_count(const Fr* __restrict__ scal
 
 __global__ void __launch_bounds__(256) k_digit_emit(const Fr* __restrict__ scalars, const uint8_t* __restrict__ valid,
                                                     uint64_t n, int c, int W, const uint64_t* __restrict__ incl,
-                                                    uint64_t* __restrict__ entries, int precomputed) {
+                                                    uint64_t* __restrict__ entries, int precomputed, uint64_t row_stride) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (!valid[i]) return;
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(256) k_digit_emit(const Fr* __restrict__ scala
         if (d != 0) {
             uint32_t mag = (uint32_t)(d < 0 ? -d : d);
             uint32_t sign = d < 0 ? 0x80000000u : 0u;
-            if (precomputed) entries[pos] = ((uint64_t)(mag - 1u) << 32) | ((uint32_t)((uint64_t)j * n + i) | sign);
+            if (precomputed) entries[pos] = ((uint64_t)(mag - 1u) << 32) | ((uint32_t)((uint64_t)j * row_stride + i) | sign);
             else entries[pos] = ((uint64_t)((uint32_t)j * nb + (mag - 1u)) << 32) | ((uint32_t)i | sign);
             ++pos;
         }
@@ -537,7 +537,7 @@ void MsmEngine<F>::digits(const Fr* scalars_dev, uint64_t n, hipStream_t st) {
     CG_HIP(hipMemcpyAsync(h_count.p, thread_counts.p + (n - 1), 8, hipMemcpyDeviceToHost, st));
     CG_HIP(hipEventRecord(ev_count, st));
     k_digit_emit<<<ceil_div(n, 256), 256, 0, st>>>(scalars_dev, bases->valid.p, n, c, W, thread_counts.p, ent_a.p,
-                                                  bases->precomputed ? 1 : 0);
+                                                  bases->precomputed ? 1 : 0, bases->n);   // table row j starts at j * bases->n
     CG_KERNEL_CHECK();
 }
 

@@ -1,19 +1,12 @@
-// Radix-2 NTT over BN254 Fr + R1CS->QAP witness-map kernels for gfx950.
-//
-// Restates (does not translate) ark-poly's radix-2 domain as driven by
-// forks/groth16/src/r1cs_to_qap.rs:150-213.  A transform of size n = 2^logn runs as a few LDS
-// passes: each workgroup stages a 1024-element tile (32 KiB) in LDS and performs up to ten
-// butterfly stages on it before the tile goes back to HBM, so a 2^21 transform moves the array
-// through HBM three times instead of twenty-one.  Strided passes gather 16 adjacent columns per
-// group so every global access is a 512-byte contiguous run.
+// Saturated-limb (8 x 32-bit, R = 2^256) Fr plumbing around the transforms: the domain constants
+// (twiddles, coset powers, vanishing-polynomial inverse) of ark-poly's radix-2 domain as driven by
+// forks/groth16/src/r1cs_to_qap.rs:150-213, the CSR upload with its coefficient dictionary, and the
+// saturated sparse product used by cg_setup.  The transforms themselves run on 29-bit limbs: csrc/wmap29.hip.
 #include <unordered_map>
 
 #include "ntt.hpp"
 
 namespace cg {
-
-static constexpr int TS_MAX = 10;        // log2 of the LDS tile
-static constexpr int STRIDED_MAX_S = 6;  // stages per strided pass (16 columns of 32 B)
 
 // ---------------------------------------------------------------------------------------------
 // host-side Fr helpers
@@ -54,18 +47,6 @@ Fr fr_root_of_unity(int logn) {
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t bitrev32(uint32_t x, int bits) { return __brev(x) >> (32 - bits); }
 
-__global__ void __launch_bounds__(256) k_to_mont(const Fr* in, Fr* out, uint64_t n) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = to_mont(in[i]);
-}
-__global__ void __launch_bounds__(256) k_from_mont(const Fr* in, Fr* out, uint64_t n) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = from_mont(in[i]);
-}
-__global__ void __launch_bounds__(256) k_mul_vec(Fr* a, const Fr* b, uint64_t n) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) a[i] = mul(a[i], b[i]);
-}
 // out[p] = scale * base^(bitrev ? rev(p) : p)
 __global__ void __launch_bounds__(256) k_pow_table(Fr* out, Fr base, Fr scale, uint64_t n, int bitrev, int logn) {
     uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -80,19 +61,6 @@ __global__ void __launch_bounds__(256) k_pow_table(Fr* out, Fr base, Fr scale, u
     }
     out[p] = r;
 }
-__global__ void __launch_bounds__(256) k_pointwise(const Fr* a, const Fr* b, const Fr* c, Fr* out, Fr vinv, uint64_t n) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = mul(sub(mul(a[i], b[i]), c[i]), vinv);
-}
-__global__ void __launch_bounds__(256) k_unbitrev_scale(const Fr* in, Fr* out, const Fr* scale, int logn, int to_canonical) {
-    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= (1ull << logn)) return;
-    Fr x = in[p];
-    if (scale) x = mul(x, scale[p]);
-    if (to_canonical) x = from_mont(x);
-    out[bitrev32((uint32_t)p, logn)] = x;
-}
-
 static inline dim3 grid_for(uint64_t n) { return dim3(ceil_div(n, 256)); }
 
 __global__ void __launch_bounds__(256) k_fill_zero(uint4* __restrict__ p, uint64_t n16) {
@@ -109,35 +77,11 @@ void fill_zero(void* dst, size_t bytes, hipStream_t st) {
     CG_KERNEL_CHECK();
 }
 
-void fr_to_mont(const Fr* in, Fr* out, uint64_t n, hipStream_t st) {
-    if (!n) return;
-    k_to_mont<<<grid_for(n), 256, 0, st>>>(in, out, n);
-    CG_KERNEL_CHECK();
-}
-void fr_from_mont(const Fr* in, Fr* out, uint64_t n, hipStream_t st) {
-    if (!n) return;
-    k_from_mont<<<grid_for(n), 256, 0, st>>>(in, out, n);
-    CG_KERNEL_CHECK();
-}
-void fr_mul_vec(Fr* a, const Fr* b, uint64_t n, hipStream_t st) {
-    if (!n) return;
-    k_mul_vec<<<grid_for(n), 256, 0, st>>>(a, b, n);
-    CG_KERNEL_CHECK();
-}
 void fr_pow_table(Fr* out, const Fr& base, const Fr& scale, uint64_t n, bool bitrev, int logn, hipStream_t st) {
     if (!n) return;
     k_pow_table<<<grid_for(n), 256, 0, st>>>(out, base, scale, n, bitrev ? 1 : 0, logn);
     CG_KERNEL_CHECK();
 }
-void qap_pointwise(const Fr* a, const Fr* b, const Fr* c, Fr* out, const Fr& vinv, uint64_t n, hipStream_t st) {
-    k_pointwise<<<grid_for(n), 256, 0, st>>>(a, b, c, out, vinv, n);
-    CG_KERNEL_CHECK();
-}
-void ntt_unbitrev_scale(const Fr* in, Fr* out, const Fr* scale, int logn, bool to_canonical, hipStream_t st) {
-    k_unbitrev_scale<<<grid_for(1ull << logn), 256, 0, st>>>(in, out, scale, logn, to_canonical ? 1 : 0);
-    CG_KERNEL_CHECK();
-}
-
 // ---------------------------------------------------------------------------------------------
 // domain tables
 // ---------------------------------------------------------------------------------------------
@@ -163,147 +107,6 @@ void NttDomain::build(int logn_, bool with_coset, hipStream_t st) {
     // (g^n - 1)^-1
     Fr gn = fr_pow_u64(g, n);
     vanishing_inv = inv(sub(gn, Fr::one()));
-}
-
-// ---------------------------------------------------------------------------------------------
-// LDS pass kernel
-//   local element e (ts bits) = [extra | g (S bits) | col (cbits)],  ts = extra_bits + S + cbits
-//   global index  = col | (Tlo << cbits) | (g << gbit_lo) | (Thi << (gbit_lo + S))
-//   with T = tile * 2^extra_bits + extra,  Tlo = low (gbit_lo - cbits) bits of T, Thi the rest.
-// ---------------------------------------------------------------------------------------------
-struct PassParams {
-    int logn, ts, S, cbits, gbit_lo;
-    int q0;  // first stage index of the pass (DIF: stage q pairs bit logn-1-q; DIT: stage q pairs bit q)
-};
-
-__device__ __forceinline__ uint32_t local_to_global(uint32_t e, uint32_t tile, const PassParams& pp) {
-    const int extra_bits = pp.ts - pp.S - pp.cbits;
-    uint32_t col = e & ((1u << pp.cbits) - 1u);
-    uint32_t g = (e >> pp.cbits) & ((1u << pp.S) - 1u);
-    uint32_t extra = e >> (pp.cbits + pp.S);
-    uint32_t T = (tile << extra_bits) | extra;
-    const int lo_bits = pp.gbit_lo - pp.cbits;
-    uint32_t Tlo = T & ((1u << lo_bits) - 1u);
-    uint32_t Thi = T >> lo_bits;
-    return col | (Tlo << pp.cbits) | (g << pp.gbit_lo) | (Thi << (pp.gbit_lo + pp.S));
-}
-
-struct alignas(16) Half { uint32_t w[4]; };
-
-__device__ __forceinline__ Fr lds_load(const Half* lo, const Half* hi, uint32_t e) {
-    Fr r;
-    Half a = lo[e], b = hi[e];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { r.l[i] = a.w[i]; r.l[4 + i] = b.w[i]; }
-    return r;
-}
-__device__ __forceinline__ void lds_store(Half* lo, Half* hi, uint32_t e, const Fr& x) {
-    Half a, b;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { a.w[i] = x.l[i]; b.w[i] = x.l[4 + i]; }
-    lo[e] = a;
-    hi[e] = b;
-}
-
-template <bool DIT>
-__global__ void __launch_bounds__(256) k_ntt_pass(Fr* __restrict__ data, const Fr* __restrict__ tw,
-                                                  const Fr* __restrict__ premul, PassParams pp) {
-    __shared__ Half s_lo[1 << TS_MAX];
-    __shared__ Half s_hi[1 << TS_MAX];
-    const uint32_t tile = blockIdx.x;
-    const uint32_t tsize = 1u << pp.ts;
-    // load (coalesced: consecutive e -> consecutive col -> consecutive addresses within a run)
-    for (uint32_t e = threadIdx.x; e < tsize; e += 256) {
-        uint32_t gi = local_to_global(e, tile, pp);
-        Fr x = data[gi];
-        if (premul) x = mul(x, premul[gi]);
-        lds_store(s_lo, s_hi, e, x);
-    }
-    __syncthreads();
-    const uint32_t nbf = tsize >> 1;
-    for (int j = 0; j < pp.S; ++j) {
-        // DIF walks the pass's bits from the top, DIT from the bottom
-        const int q = pp.q0 + j;
-        const int gb = DIT ? q : (pp.logn - 1 - q);       // global bit paired by this stage
-        const int lb = pp.cbits + (gb - pp.gbit_lo);        // its position inside the tile
-        const uint32_t lmask = (1u << lb) - 1u;
-        const int tw_shift = DIT ? (pp.logn - 1 - q) : q;
-        for (uint32_t b = threadIdx.x; b < nbf; b += 256) {
-            uint32_t e0 = ((b & ~lmask) << 1) | (b & lmask);
-            uint32_t e1 = e0 | (1u << lb);
-            uint32_t gi = local_to_global(e0, tile, pp);
-            uint32_t k = gi & ((1u << gb) - 1u);
-            Fr u = lds_load(s_lo, s_hi, e0);
-            Fr v = lds_load(s_lo, s_hi, e1);
-            Fr w = tw[(uint64_t)k << tw_shift];
-            if (DIT) {
-                v = mul(v, w);
-                lds_store(s_lo, s_hi, e0, add(u, v));
-                lds_store(s_lo, s_hi, e1, sub(u, v));
-            } else {
-                lds_store(s_lo, s_hi, e0, add(u, v));
-                lds_store(s_lo, s_hi, e1, mul(sub(u, v), w));
-            }
-        }
-        __syncthreads();
-    }
-    for (uint32_t e = threadIdx.x; e < tsize; e += 256) {
-        uint32_t gi = local_to_global(e, tile, pp);
-        data[gi] = lds_load(s_lo, s_hi, e);
-    }
-}
-
-// Pass plan: DIF = strided passes over the high bits, then one contiguous pass over the low
-// min(ts, logn) bits; DIT is the mirror image.
-static void run_passes(Fr* data, const NttDomain& d, bool dit, bool inverse, const Fr* premul, hipStream_t st) {
-    const int logn = d.logn;
-    if (logn == 0) {
-        if (premul) fr_mul_vec(data, premul, 1, st);
-        return;
-    }
-    const Fr* tw = inverse ? d.tw_inv.p : d.tw_fwd.p;
-    const int ts = logn < TS_MAX ? logn : TS_MAX;
-    const int s_cont = ts;            // stages in the contiguous pass
-    const int rest = logn - s_cont;   // stages left for strided passes
-    const int npass = rest ? (rest + STRIDED_MAX_S - 1) / STRIDED_MAX_S : 0;
-    std::vector<PassParams> plan;
-    // contiguous pass parameters (pairs global bits [0, s_cont))
-    PassParams cont{logn, ts, s_cont, 0, 0, dit ? 0 : logn - s_cont};
-    // strided passes cover global bits [s_cont, logn), split evenly
-    std::vector<PassParams> strided;
-    {
-        int done = 0;
-        for (int p = 0; p < npass; ++p) {
-            int S = (rest - done + (npass - p) - 1) / (npass - p);
-            PassParams pp;
-            pp.logn = logn; pp.ts = ts; pp.S = S; pp.cbits = ts - S;
-            pp.gbit_lo = s_cont + done;             // lowest global bit of this group (DIT order)
-            pp.q0 = dit ? pp.gbit_lo : (logn - (pp.gbit_lo + S));
-            strided.push_back(pp);
-            done += S;
-        }
-    }
-    if (dit) {
-        plan.push_back(cont);
-        for (auto& p : strided) plan.push_back(p);
-    } else {
-        for (int i = (int)strided.size() - 1; i >= 0; --i) plan.push_back(strided[i]);
-        plan.push_back(cont);
-    }
-    const uint32_t tiles = (uint32_t)(d.n >> ts);
-    for (size_t i = 0; i < plan.size(); ++i) {
-        const Fr* pm = (i == 0) ? premul : nullptr;
-        if (dit) k_ntt_pass<true><<<tiles, 256, 0, st>>>(data, tw, pm, plan[i]);
-        else k_ntt_pass<false><<<tiles, 256, 0, st>>>(data, tw, pm, plan[i]);
-        CG_KERNEL_CHECK();
-    }
-}
-
-void ntt_dif(Fr* data, const NttDomain& d, bool inverse, const Fr* premul, hipStream_t st) {
-    run_passes(data, d, false, inverse, premul, st);
-}
-void ntt_dit(Fr* data, const NttDomain& d, bool inverse, const Fr* premul, hipStream_t st) {
-    run_passes(data, d, true, inverse, premul, st);
 }
 
 // ---------------------------------------------------------------------------------------------

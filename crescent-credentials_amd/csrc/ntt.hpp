@@ -1,6 +1,6 @@
-// Radix-2 NTT over BN254 Fr and the R1CS->QAP witness map on the GPU (internal C++ interface).
-// Restates ark-poly's Radix2EvaluationDomain as used by
-// forks/groth16/src/r1cs_to_qap.rs:150-213 (ω = 5^((r-1)/2^k), coset offset g = 5).
+// Domain constants of ark-poly's Radix2EvaluationDomain as used by forks/groth16/src/r1cs_to_qap.rs:150-213
+// (ω = 5^((r-1)/2^k), coset offset g = 5), CSR matrices on the device, and saturated-limb Fr helpers
+// (internal C++ interface).  The transforms run on 29-bit limbs (wmap29.hpp).
 #pragma once
 #include "common.hpp"
 
@@ -22,22 +22,8 @@ Fr fr_from_u64(uint64_t v);
 Fr fr_pow_u64(const Fr& a, uint64_t e);
 Fr fr_root_of_unity(int logn);  // primitive 2^logn-th root, = 5^((r-1)/2^28) ^ 2^(28-logn)
 
-// natural order in -> bit-reversed order out (decimation in frequency).  `premul` (optional) is
-// multiplied into element p as it is first loaded.
-void ntt_dif(Fr* data, const NttDomain& d, bool inverse, const Fr* premul, hipStream_t st);
-// bit-reversed order in -> natural order out (decimation in time)
-void ntt_dit(Fr* data, const NttDomain& d, bool inverse, const Fr* premul, hipStream_t st);
-
-// out[rev(p)] = in[p] * scale[p] (scale optional), optionally leaving Montgomery form
-void ntt_unbitrev_scale(const Fr* in, Fr* out, const Fr* scale, int logn, bool to_canonical, hipStream_t st);
-
-// elementwise helpers (n elements)
-void fr_to_mont(const Fr* in, Fr* out, uint64_t n, hipStream_t st);      // canonical -> Montgomery
-void fr_from_mont(const Fr* in, Fr* out, uint64_t n, hipStream_t st);    // Montgomery -> canonical
-void fr_mul_vec(Fr* a, const Fr* b, uint64_t n, hipStream_t st);          // a[i] *= b[i]
+// out[p] = scale * base^(bitrev ? rev(p) : p), p < n (Montgomery form)
 void fr_pow_table(Fr* out, const Fr& base, const Fr& scale, uint64_t n, bool bitrev, int logn, hipStream_t st);
-// ab[i] = (a[i]*b[i] - c[i]) * vinv     (r1cs_to_qap.rs:187,205-208)
-void qap_pointwise(const Fr* a, const Fr* b, const Fr* c, Fr* out, const Fr& vinv, uint64_t n, hipStream_t st);
 
 // CSR sparse matrix (device) with a coefficient dictionary: coef_idx 0 is the literal one
 // (the reference's `coeff.is_one()` shortcut, r1cs_to_qap.rs:31-35).

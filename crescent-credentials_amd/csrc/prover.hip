@@ -10,6 +10,7 @@
 #include <memory>
 #include <mutex>
 #include <chrono>
+#include <cstdlib>
 
 #include "msm.hpp"
 #include "ntt.hpp"
@@ -29,26 +30,6 @@ int fail(int code, const char* fmt, ...) {
     va_end(ap);
     last_error() = buf;
     return code;
-}
-
-// ---- canonical byte <-> Montgomery point conversions (host) ----------------------------------------
-static Fq fq_import(const uint8_t* b, uint32_t form) {
-    Fq a = fp_from_bytes<Fq>(b);
-    return form == CG_FORM_CANONICAL ? to_mont(a) : a;
-}
-static G1Affine g1_import(const uint8_t* b, uint32_t form) { return {fq_import(b, form), fq_import(b + 32, form)}; }
-static G2Affine g2_import(const uint8_t* b, uint32_t form) {
-    return {{fq_import(b, form), fq_import(b + 32, form)}, {fq_import(b + 64, form), fq_import(b + 96, form)}};
-}
-static void g1_export_canonical(const G1Affine& p, uint8_t* out) {  // identity -> zeros
-    fp_to_bytes(from_mont(p.x), out);
-    fp_to_bytes(from_mont(p.y), out + 32);
-}
-static void g2_export_canonical(const G2Affine& p, uint8_t* out) {
-    fp_to_bytes(from_mont(p.x.c0), out);
-    fp_to_bytes(from_mont(p.x.c1), out + 32);
-    fp_to_bytes(from_mont(p.y.c0), out + 64);
-    fp_to_bytes(from_mont(p.y.c1), out + 96);
 }
 
 // a > b as 256-bit integers (canonical limbs)
@@ -77,11 +58,6 @@ static void g2_serialize_uncompressed(const G2Affine& p, uint8_t out[128]) {
     if (gt) out[127] |= 0x80;
 }
 
-static bool scalar_is_zero(const uint8_t s[32]) {
-    for (int i = 0; i < 32; ++i) if (s[i]) return false;
-    return true;
-}
-static bool scalar_is_canonical(const uint8_t s[32]) { return fp_is_canonical(fp_from_bytes<Fr>(s)); }
 
 template <class F>
 static XYZZ<F> scalar_mul_bytes(const Affine<F>& p, const uint8_t k[32]) {
@@ -122,7 +98,8 @@ struct ProofSlot {
     hipEvent_t ev_w = nullptr;
     hipEvent_t ev_t[2] = {nullptr, nullptr};
     ~ProofSlot() {
-        for (auto& s : st) if (s) (void)hipStreamDestroy(s);
+        for (int i = 0; i < 5; ++i)
+            if (st[i] && (i == 0 || st[i] != st[0])) (void)hipStreamDestroy(st[i]);
         if (ev_w) (void)hipEventDestroy(ev_w);
         for (auto& e : ev_t) if (e) (void)hipEventDestroy(e);
     }
@@ -280,7 +257,12 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         c->A.dict.release(); c->B.dict.release(); c->C.dict.release();
         for (int k = 0; k < n_slots; ++k) {
             std::unique_ptr<ProofSlot> sl(new ProofSlot());
-            for (auto& s : sl->st) CG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+            // CG_SERIAL_STREAMS=1 (profiling aid): one stream per slot, so a kernel trace shows stand-alone durations
+            const bool serial = getenv("CG_SERIAL_STREAMS") && getenv("CG_SERIAL_STREAMS")[0] == '1';
+            for (int i = 0; i < 5; ++i) {
+                if (serial && i) sl->st[i] = sl->st[0];
+                else CG_HIP(hipStreamCreateWithFlags(&sl->st[i], hipStreamNonBlocking));
+            }
             CG_HIP(hipEventCreateWithFlags(&sl->ev_w, hipEventDisableTiming));
             for (auto& e : sl->ev_t) CG_HIP(hipEventCreate(&e));
             sl->eh.init(&c->bh); sl->el.init(&c->bl); sl->ea.init(&c->ba); sl->eb1.init(&c->bb1); sl->eb2.init(&c->bb2);
@@ -567,115 +549,6 @@ extern "C" int cg_witness_map(cg_ctx* ctx, const uint8_t* full_assignment, uint8
         CG_HIP(hipMemcpyAsync(h_out, S->h_canon.p, ctx->D * 32, hipMemcpyDeviceToHost, s0));
         CG_HIP(hipStreamSynchronize(s0));
         if (S->wm.h_bad_input.p[0]) return fail(CG_ERR_INVALID_ARGUMENT, "full_assignment holds a value >= the scalar field modulus");
-        return CG_OK;
-    } catch (...) {
-        return translate_exception();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// unit-level MSM / NTT
-// ---------------------------------------------------------------------------------------------
-template <class F>
-static int msm_unit(const uint8_t* bases, uint32_t form, uint64_t n_bases, const uint8_t* scalars, uint64_t n_scalars,
-                    int window_bits, Affine<F>& out) {
-    uint64_t n = n_bases < n_scalars ? n_bases : n_scalars;
-    out = Affine<F>::inf();
-    if (n == 0) return CG_OK;
-    if (!bases || !scalars) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
-    hipStream_t st;
-    CG_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    try {
-        DevBuf<Affine<F>> pts(n);
-        import_bases<F>(bases, form, n, pts.p, st);
-        DevBuf<Fr> sc(n);
-        CG_HIP(hipMemcpyAsync(sc.p, scalars, n * 32, hipMemcpyHostToDevice, st));
-        MsmBases<F> mb;
-        int c = window_bits > 0 ? window_bits : msm_default_window(n, false);
-        if (c < 2 || c > 22) throw HipError(CG_ERR_INVALID_ARGUMENT, "window_bits must be in [2, 22]");
-        mb.build(pts.p, n, c, false, st);
-        MsmEngine<F> eng;
-        eng.init(&mb);
-        eng.digits(sc.p, n, st);
-        eng.accumulate(st);
-        CG_HIP(hipStreamSynchronize(st));
-        out = to_affine(eng.value());
-    } catch (...) {
-        (void)hipStreamDestroy(st);
-        throw;
-    }
-    (void)hipStreamDestroy(st);
-    return CG_OK;
-}
-
-static int check_scalars_canonical(const uint8_t* scalars, uint64_t n) {
-    for (uint64_t i = 0; i < n; ++i)
-        if (!scalar_is_canonical(scalars + 32 * i)) return fail(CG_ERR_INVALID_ARGUMENT, "scalar %llu not canonical", (unsigned long long)i);
-    return CG_OK;
-}
-
-extern "C" int cg_msm_g1(const uint8_t* bases, uint32_t coord_form, uint64_t n_bases, const uint8_t* scalars,
-                         uint64_t n_scalars, int32_t window_bits, uint8_t out[64]) {
-    if (!out) return fail(CG_ERR_INVALID_ARGUMENT, "null out");
-    try {
-        uint64_t n = n_bases < n_scalars ? n_bases : n_scalars;
-        if (n && scalars) if (int e = check_scalars_canonical(scalars, n)) return e;
-        G1Affine r;
-        int e = msm_unit<Fq>(bases, coord_form, n_bases, scalars, n_scalars, window_bits, r);
-        if (e) return e;
-        g1_export_canonical(r, out);
-        return CG_OK;
-    } catch (...) {
-        return translate_exception();
-    }
-}
-extern "C" int cg_msm_g2(const uint8_t* bases, uint32_t coord_form, uint64_t n_bases, const uint8_t* scalars,
-                         uint64_t n_scalars, int32_t window_bits, uint8_t out[128]) {
-    if (!out) return fail(CG_ERR_INVALID_ARGUMENT, "null out");
-    try {
-        uint64_t n = n_bases < n_scalars ? n_bases : n_scalars;
-        if (n && scalars) if (int e = check_scalars_canonical(scalars, n)) return e;
-        G2Affine r;
-        int e = msm_unit<Fq2>(bases, coord_form, n_bases, scalars, n_scalars, window_bits, r);
-        if (e) return e;
-        g2_export_canonical(r, out);
-        return CG_OK;
-    } catch (...) {
-        return translate_exception();
-    }
-}
-
-extern "C" int cg_ntt(uint8_t* data, uint32_t log_n, int inverse, int coset) {
-    if (!data) return fail(CG_ERR_INVALID_ARGUMENT, "null data");
-    if (log_n > 28) return fail(CG_ERR_POLY_DEGREE_TOO_LARGE, "log_n > 28");
-    try {
-        const uint64_t n = 1ull << log_n;
-        hipStream_t st = nullptr;  // default stream
-        NttDomain dom;
-        dom.build((int)log_n, false, st);
-        DevBuf<Fr> a(n), b(n), scale;
-        CG_HIP(hipMemcpyAsync(a.p, data, n * 32, hipMemcpyHostToDevice, st));
-        fr_to_mont(a.p, a.p, n, st);
-        Fr g = fr_from_u64(5);
-        if (!inverse) {
-            // out[k] = Σ a[j] (g^j) ω^{jk}: pre-scale in natural order, DIF, undo the bit reversal
-            if (coset) {
-                scale.alloc(n);
-                fr_pow_table(scale.p, g, Fr::one(), n, false, (int)log_n, st);
-                fr_mul_vec(a.p, scale.p, n, st);
-            }
-            ntt_dif(a.p, dom, false, nullptr, st);
-            ntt_unbitrev_scale(a.p, b.p, nullptr, (int)log_n, true, st);
-        } else {
-            // coefficients = (1/n) DFT^-1, then x g^-i for the coset variant
-            scale.alloc(n);
-            Fr ninv = inv(fr_from_u64(n));
-            fr_pow_table(scale.p, coset ? inv(g) : Fr::one(), ninv, n, true, (int)log_n, st);
-            ntt_dif(a.p, dom, true, nullptr, st);
-            ntt_unbitrev_scale(a.p, b.p, scale.p, (int)log_n, true, st);
-        }
-        CG_HIP(hipMemcpyAsync(data, b.p, n * 32, hipMemcpyDeviceToHost, st));
-        CG_HIP(hipStreamSynchronize(st));
         return CG_OK;
     } catch (...) {
         return translate_exception();

@@ -243,3 +243,30 @@ extern "C" int cg_setup(const cg_csr abc[3], uint64_t num_inputs, uint64_t num_c
         return translate_current_exception();
     }
 }
+
+// out[i] = scalars[i] * G (canonical affine), G the standard generator of G1 / G2.
+template <class F>
+static int fixed_base_export(const Affine<F>& gen, const uint8_t* scalars, uint64_t n, uint8_t* out) {
+    if (n == 0) return CG_OK;
+    if (!scalars || !out) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
+    try {
+        hipStream_t st = nullptr;
+        std::vector<Fr> host(n);
+        for (uint64_t i = 0; i < n; ++i) {
+            Fr a = fp_from_bytes<Fr>(scalars + 32 * i);
+            if (!fp_is_canonical(a)) return fail(CG_ERR_INVALID_ARGUMENT, "scalar %llu not canonical", (unsigned long long)i);
+            host[i] = to_mont(a);
+        }
+        DevBuf<Fr> sc(n);
+        CG_HIP(hipMemcpyAsync(sc.p, host.data(), n * sizeof(Fr), hipMemcpyHostToDevice, st));
+        DevBuf<Affine<F>> table(FB_NWIN * 256);
+        k_fb_table<F><<<FB_NWIN, 256, 0, st>>>(gen, table.p);
+        CG_KERNEL_CHECK();
+        fixed_base_to_host<F>(table.p, sc.p, n, out, st);
+        return CG_OK;
+    } catch (...) {
+        return translate_current_exception();
+    }
+}
+extern "C" int cg_fixed_base_g1(const uint8_t* scalars, uint64_t n, uint8_t* out) { return fixed_base_export<Fq>(g1_generator(), scalars, n, out); }
+extern "C" int cg_fixed_base_g2(const uint8_t* scalars, uint64_t n, uint8_t* out) { return fixed_base_export<Fq2>(g2_generator(), scalars, n, out); }

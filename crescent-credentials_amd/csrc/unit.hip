@@ -1,0 +1,315 @@
+// libcrescent_gpu: unit-level MSM and NTT entry points of include/crescent_gpu.h.
+//
+// The one-shot forms mirror the reference's own call shapes (`msm_bigint(bases, scalars)`,
+// `domain.fft_in_place(&mut v)`; call sites forks/groth16/src/prover.rs:66,74,266 and
+// r1cs_to_qap.rs:179-185,198-199,210).  The handle forms keep what a caller reuses - the expanded base
+// tables of a fixed set of bases, the twiddle tables of a domain - resident in HBM, and accept operands that
+// already live on the device; they run the same kernels as cg_prove (csrc/msm.hip, csrc/wmap29.hip).
+#include <chrono>
+#include <memory>
+#include <mutex>
+
+#include "msm.hpp"
+#include "wmap29.hpp"
+
+using namespace cg;
+
+// ---------------------------------------------------------------------------------------------
+// MSM over a resident set of bases
+// ---------------------------------------------------------------------------------------------
+struct cg_msm_ctx {
+    int device = 0;
+    int group = 1;
+    uint64_t n = 0;
+    MsmBases<Fq> b1;
+    MsmBases<Fq2> b2;
+    MsmEngine<Fq> e1;
+    MsmEngine<Fq2> e2;
+    DevBuf<Fr> scalars;
+    DevBuf<uint32_t> bad;
+    PinnedBuf<uint32_t> h_bad;
+    hipStream_t st = nullptr;
+    std::mutex mu;
+    ~cg_msm_ctx() { if (st) (void)hipStreamDestroy(st); }
+};
+
+__global__ void __launch_bounds__(256) k_check_canonical(const Fr* __restrict__ s, uint64_t n, uint32_t* __restrict__ bad) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr x = s[i];
+    bool lt = false, decided = false;
+#pragma unroll
+    for (int k = 7; k >= 0; --k) {
+        if (!decided && x.l[k] != FrP::N[k]) { lt = x.l[k] < FrP::N[k]; decided = true; }
+    }
+    if (!lt) *bad = 1u;
+}
+
+static int msm_load(cg_msm_ctx** out, int group, const uint8_t* bases, uint32_t form, uint64_t n, const cg_options* opt) {
+    if (!out) return fail(CG_ERR_INVALID_ARGUMENT, "null out");
+    *out = nullptr;
+    if (n && !bases) return fail(CG_ERR_INVALID_ARGUMENT, "null bases");
+    if (form != CG_FORM_CANONICAL && form != CG_FORM_MONTGOMERY) return fail(CG_ERR_INVALID_ARGUMENT, "bad coord_form");
+    if (n >= (1ull << 31)) return fail(CG_ERR_INVALID_ARGUMENT, "more than 2^31 - 1 bases");
+    try {
+        int dev = (opt && opt->device >= 0) ? opt->device : -1;
+        if (dev < 0) CG_HIP(hipGetDevice(&dev));
+        CG_HIP(hipSetDevice(dev));
+        std::unique_ptr<cg_msm_ctx> c(new cg_msm_ctx());
+        c->device = dev;
+        c->group = group;
+        c->n = n;
+        CG_HIP(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+        int wb = opt ? opt->window_bits : 0;
+        if (wb < 0 || wb == 1 || wb > 22) return fail(CG_ERR_INVALID_ARGUMENT, "window_bits must be 0 or in [2, 22]");
+        if (n) {
+            const int cbits = wb > 0 ? wb : msm_default_window(n, true);
+            if (group == 1) {
+                DevBuf<G1Affine> tmp(n);
+                import_bases<Fq>(bases, form, n, tmp.p, c->st);
+                c->b1.build(tmp.p, n, cbits, true, c->st);
+                CG_HIP(hipStreamSynchronize(c->st));
+                c->e1.init(&c->b1);
+            } else {
+                DevBuf<G2Affine> tmp(n);
+                import_bases<Fq2>(bases, form, n, tmp.p, c->st);
+                c->b2.build(tmp.p, n, cbits, true, c->st);
+                CG_HIP(hipStreamSynchronize(c->st));
+                c->e2.init(&c->b2);
+            }
+            c->scalars.alloc(n);
+            c->bad.alloc(1);
+            c->h_bad.alloc(1);
+        }
+        *out = c.release();
+        return CG_OK;
+    } catch (...) {
+        return translate_current_exception();
+    }
+}
+
+extern "C" int cg_msm_load_g1(cg_msm_ctx** out, const uint8_t* bases, uint32_t coord_form, uint64_t n_bases, const cg_options* opt) {
+    return msm_load(out, 1, bases, coord_form, n_bases, opt);
+}
+extern "C" int cg_msm_load_g2(cg_msm_ctx** out, const uint8_t* bases, uint32_t coord_form, uint64_t n_bases, const cg_options* opt) {
+    return msm_load(out, 2, bases, coord_form, n_bases, opt);
+}
+
+extern "C" void cg_msm_free(cg_msm_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    delete ctx;
+}
+
+template <class F>
+static void fill_msm_timings(const MsmEngine<F>& e, bool g2, cg_timings* tm) {
+    memset(tm, 0, sizeof(*tm));
+    (g2 ? tm->msm_b2_ms : tm->msm_h_ms) = e.ms_total();
+    (g2 ? tm->accum_g2_ms : tm->accum_g1_ms) = e.ms_accum();
+    tm->sort_ms = e.ms_sort();
+    (g2 ? tm->msm_g2_pairs : tm->msm_g1_pairs) = e.n_scalars;
+    (g2 ? tm->entries_g2 : tm->entries_g1) = e.n_entries;
+    (g2 ? tm->accum_g2_launches : tm->accum_g1_launches) = e.n_entries != 0;
+}
+
+extern "C" int cg_msm_run(cg_msm_ctx* ctx, const void* scalars, int scalars_on_device, uint64_t n_scalars, uint8_t* out,
+                          cg_timings* timings) {
+    if (!ctx || !out) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
+    const size_t out_bytes = ctx->group == 1 ? 64 : 128;
+    const uint64_t n = n_scalars < ctx->n ? n_scalars : ctx->n;     // msm_bigint zips bases with scalars
+    if (timings) memset(timings, 0, sizeof(*timings));
+    if (n == 0) { memset(out, 0, out_bytes); return CG_OK; }
+    if (!scalars) return fail(CG_ERR_INVALID_ARGUMENT, "null scalars");
+    try {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        CG_HIP(hipSetDevice(ctx->device));
+        auto t0 = std::chrono::steady_clock::now();
+        hipStream_t st = ctx->st;
+        const Fr* sc = (const Fr*)scalars;
+        if (!scalars_on_device) {
+            CG_HIP(hipMemcpyAsync(ctx->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, st));
+            sc = ctx->scalars.p;
+        }
+        CG_HIP(hipMemsetAsync(ctx->bad.p, 0, 4, st));
+        k_check_canonical<<<ceil_div(n, 256), 256, 0, st>>>(sc, n, ctx->bad.p);
+        CG_KERNEL_CHECK();
+        CG_HIP(hipMemcpyAsync(ctx->h_bad.p, ctx->bad.p, 4, hipMemcpyDeviceToHost, st));
+        if (ctx->group == 1) {
+            ctx->e1.digits(sc, n, st);
+            ctx->e1.accumulate(st);
+            CG_HIP(hipStreamSynchronize(st));
+            if (ctx->h_bad.p[0]) return fail(CG_ERR_INVALID_ARGUMENT, "a scalar is not canonical (>= the scalar field modulus)");
+            g1_export_canonical(to_affine(ctx->e1.value()), out);
+            if (timings) fill_msm_timings(ctx->e1, false, timings);
+        } else {
+            ctx->e2.digits(sc, n, st);
+            ctx->e2.accumulate(st);
+            CG_HIP(hipStreamSynchronize(st));
+            if (ctx->h_bad.p[0]) return fail(CG_ERR_INVALID_ARGUMENT, "a scalar is not canonical (>= the scalar field modulus)");
+            g2_export_canonical(to_affine(ctx->e2.value()), out);
+            if (timings) fill_msm_timings(ctx->e2, true, timings);
+        }
+        if (timings) timings->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return CG_OK;
+    } catch (...) {
+        return translate_current_exception();
+    }
+}
+
+// one-shot: bases used once, so only window 0 is tabulated and the keys carry the window index
+template <class F>
+static int msm_unit(const uint8_t* bases, uint32_t form, uint64_t n_bases, const uint8_t* scalars, uint64_t n_scalars,
+                    int window_bits, Affine<F>& out) {
+    uint64_t n = n_bases < n_scalars ? n_bases : n_scalars;
+    out = Affine<F>::inf();
+    if (n == 0) return CG_OK;
+    if (!bases || !scalars) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
+    if (form != CG_FORM_CANONICAL && form != CG_FORM_MONTGOMERY) return fail(CG_ERR_INVALID_ARGUMENT, "bad coord_form");
+    for (uint64_t i = 0; i < n; ++i)
+        if (!scalar_is_canonical(scalars + 32 * i)) return fail(CG_ERR_INVALID_ARGUMENT, "scalar %llu not canonical", (unsigned long long)i);
+    hipStream_t st;
+    CG_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    try {
+        DevBuf<Affine<F>> pts(n);
+        import_bases<F>(bases, form, n, pts.p, st);
+        DevBuf<Fr> sc(n);
+        CG_HIP(hipMemcpyAsync(sc.p, scalars, n * 32, hipMemcpyHostToDevice, st));
+        MsmBases<F> mb;
+        int c = window_bits > 0 ? window_bits : msm_default_window(n, false);
+        if (c < 2 || c > 22) throw HipError(CG_ERR_INVALID_ARGUMENT, "window_bits must be in [2, 22]");
+        mb.build(pts.p, n, c, false, st);
+        MsmEngine<F> eng;
+        eng.init(&mb);
+        eng.digits(sc.p, n, st);
+        eng.accumulate(st);
+        CG_HIP(hipStreamSynchronize(st));
+        out = to_affine(eng.value());
+    } catch (...) {
+        (void)hipStreamDestroy(st);
+        throw;
+    }
+    (void)hipStreamDestroy(st);
+    return CG_OK;
+}
+
+extern "C" int cg_msm_g1(const uint8_t* bases, uint32_t coord_form, uint64_t n_bases, const uint8_t* scalars,
+                         uint64_t n_scalars, int32_t window_bits, uint8_t out[64]) {
+    if (!out) return fail(CG_ERR_INVALID_ARGUMENT, "null out");
+    try {
+        G1Affine r;
+        int e = msm_unit<Fq>(bases, coord_form, n_bases, scalars, n_scalars, window_bits, r);
+        if (e) return e;
+        g1_export_canonical(r, out);
+        return CG_OK;
+    } catch (...) {
+        return translate_current_exception();
+    }
+}
+extern "C" int cg_msm_g2(const uint8_t* bases, uint32_t coord_form, uint64_t n_bases, const uint8_t* scalars,
+                         uint64_t n_scalars, int32_t window_bits, uint8_t out[128]) {
+    if (!out) return fail(CG_ERR_INVALID_ARGUMENT, "null out");
+    try {
+        G2Affine r;
+        int e = msm_unit<Fq2>(bases, coord_form, n_bases, scalars, n_scalars, window_bits, r);
+        if (e) return e;
+        g2_export_canonical(r, out);
+        return CG_OK;
+    } catch (...) {
+        return translate_current_exception();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NTT over a resident domain
+// ---------------------------------------------------------------------------------------------
+struct cg_ntt_ctx {
+    int device = 0;
+    uint32_t log_n = 0;
+    Ntt29Unit unit;           // unused for log_n = 0
+    DevBuf<Fr> staging;       // for host-resident data
+    hipStream_t st = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    std::mutex mu;
+    ~cg_ntt_ctx() {
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        if (st) (void)hipStreamDestroy(st);
+    }
+};
+
+extern "C" int cg_ntt_load(cg_ntt_ctx** out, uint32_t log_n, int32_t device) {
+    if (!out) return fail(CG_ERR_INVALID_ARGUMENT, "null out");
+    *out = nullptr;
+    if (log_n > 28) return fail(CG_ERR_POLY_DEGREE_TOO_LARGE, "log_n > 28 (the two-adicity of the BN254 scalar field)");
+    try {
+        int dev = device;
+        if (dev < 0) CG_HIP(hipGetDevice(&dev));
+        CG_HIP(hipSetDevice(dev));
+        std::unique_ptr<cg_ntt_ctx> c(new cg_ntt_ctx());
+        c->device = dev;
+        c->log_n = log_n;
+        CG_HIP(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+        for (auto& e : c->ev) CG_HIP(hipEventCreate(&e));
+        if (log_n > 0) c->unit.build((int)log_n, c->st);
+        *out = c.release();
+        return CG_OK;
+    } catch (...) {
+        return translate_current_exception();
+    }
+}
+
+extern "C" void cg_ntt_free(cg_ntt_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    delete ctx;
+}
+
+extern "C" int cg_ntt_run(cg_ntt_ctx* ctx, void* data, int data_on_device, int inverse, int coset, float* kernel_ms) {
+    if (!ctx || !data) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
+    if (kernel_ms) *kernel_ms = 0.f;
+    const uint64_t n = 1ull << ctx->log_n;
+    if (ctx->log_n == 0) {     // the size-1 transform is the identity (g^0 = 1, 1/n = 1); only the operand check remains
+        uint8_t x[32];
+        if (data_on_device) {
+            try { CG_HIP(hipMemcpy(x, data, 32, hipMemcpyDeviceToHost)); } catch (...) { return translate_current_exception(); }
+        } else {
+            memcpy(x, data, 32);
+        }
+        if (!scalar_is_canonical(x)) return fail(CG_ERR_INVALID_ARGUMENT, "an element is not canonical (>= the scalar field modulus)");
+        return CG_OK;
+    }
+    try {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        CG_HIP(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->st;
+        Fr* d = (Fr*)data;
+        if (!data_on_device) {
+            if (!ctx->staging.p) ctx->staging.alloc(n);
+            CG_HIP(hipMemcpyAsync(ctx->staging.p, data, n * 32, hipMemcpyHostToDevice, st));
+            d = ctx->staging.p;
+        }
+        CG_HIP(hipEventRecord(ctx->ev[0], st));
+        const bool ok = ctx->unit.run(d, inverse != 0, coset != 0, st);
+        CG_HIP(hipEventRecord(ctx->ev[1], st));
+        if (!ok) {
+            CG_HIP(hipStreamSynchronize(st));
+            return fail(CG_ERR_INVALID_ARGUMENT, "an element is not canonical (>= the scalar field modulus)");
+        }
+        if (!data_on_device) CG_HIP(hipMemcpyAsync(data, d, n * 32, hipMemcpyDeviceToHost, st));
+        CG_HIP(hipStreamSynchronize(st));
+        if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, ctx->ev[0], ctx->ev[1]);
+        return CG_OK;
+    } catch (...) {
+        return translate_current_exception();
+    }
+}
+
+extern "C" int cg_ntt(uint8_t* data, uint32_t log_n, int inverse, int coset) {
+    cg_ntt_ctx* c = nullptr;
+    int e = cg_ntt_load(&c, log_n, -1);
+    if (e) return e;
+    e = cg_ntt_run(c, data, 0, inverse, coset, nullptr);
+    cg_ntt_free(c);
+    return e;
+}

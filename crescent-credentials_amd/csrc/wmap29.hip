@@ -113,6 +113,15 @@ void Csr29::build(const DevCsr& m, hipStream_t st) {
     CG_KERNEL_CHECK();
 }
 
+__device__ __forceinline__ bool fr_lt_modulus(const Fr& x) {
+    bool lt = false, decided = false;
+#pragma unroll
+    for (int k = 7; k >= 0; --k) {
+        if (!decided && x.l[k] != FrP::N[k]) { lt = x.l[k] < FrP::N[k]; decided = true; }
+    }
+    return lt;
+}
+
 // ---- witness -> R' form; sparse products --------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_w_to29(const Fr* __restrict__ w, uint32_t* __restrict__ out, uint64_t n,
                                                 uint32_t* __restrict__ bad_input) {
@@ -120,12 +129,7 @@ __global__ void __launch_bounds__(256) k_w_to29(const Fr* __restrict__ w, uint32
     if (i >= n) return;
     Fr x = w[i];
     // the reference's scalars are field elements by type; across a C ABI they are bytes, so check (x < r)
-    bool lt = false, decided = false;
-#pragma unroll
-    for (int k = 7; k >= 0; --k) {
-        if (!decided && x.l[k] != FrP::N[k]) { lt = x.l[k] < FrP::N[k]; decided = true; }
-    }
-    if (!lt) *bad_input = 1u;
+    if (!fr_lt_modulus(x)) *bad_input = 1u;
     store_packed29(out, i, from_canonical_bytes<Fr29P>(x));
 }
 
@@ -202,7 +206,8 @@ __device__ __forceinline__ void bfly(Fr29& u, Fr29& v, const Fr29& w) {
 
 // LOAD: 0 = one input vector; 1 = (a∘b - c)·vinv from three vectors (r1cs_to_qap.rs:187,201-208)
 // STORE: 0 = value reduced just enough to pack; 1 = multiplied by scale[natural index] and made canonical
-//        (coset factor, or the exit from Montgomery form)
+//        (coset factor, or the exit from Montgomery form); 2 = multiplied by the constant passed in `vinv_p`
+//        and made canonical (unit-level transforms: plain 1 or plain 1/n; never combined with LOAD = 1)
 // Stages are taken two at a time as radix-4 groups held in registers (three twiddle loads and ONE carry
 // propagation per element for two stages, half the barriers); an odd last stage runs radix-2.
 // Lazy-value bounds: a pass starts below 6N (packed inputs are < 2^256 = 5.3N), every stage adds at most 3N,
@@ -280,6 +285,7 @@ __global__ void __launch_bounds__(256) k_ntt29_pass(const uint32_t* __restrict__
         Fr29 x = lds_get(sm, e);
         Fr29 y;
         if (STORE == 1) y = cond_sub_n(mul(x, load_packed29(scale, gi)));
+        else if (STORE == 2) y = cond_sub_n(mul(x, unpack29<Fr29P>(vinv_p.w)));   // one constant for every element
         else y = weak_reduce(x);
         store_packed29(out, store_bitrev ? brev(gi, pp.logn) : gi, y);
     }
@@ -296,10 +302,11 @@ static void launch_pass(uint32_t tiles, const uint32_t* a, const uint32_t* b, co
 // passes run in place on `work`; the last pass writes `dst`.  A bit-reversing store permutes across tiles, so
 // it must not be in place: callers give dst != work (and != in_a for a single-pass transform) in that case.
 static void dit29(const Wm29Domain& d, const uint32_t* tw, const uint32_t* in_a, const uint32_t* in_b, const uint32_t* in_c,
-                  bool pointwise, uint32_t* work, uint32_t* dst, const uint32_t* scale, bool store_bitrev, hipStream_t st) {
+                  bool pointwise, uint32_t* work, uint32_t* dst, const uint32_t* scale, bool store_bitrev, hipStream_t st,
+                  const uint32_t* const_scale = nullptr) {
     const int logn = d.logn;
     Packed8 vinv;
-    memcpy(vinv.w, d.vinv, 32);
+    memcpy(vinv.w, const_scale ? const_scale : d.vinv, 32);
     std::vector<Pass29> plan;
     const int ts = logn < TS29 ? logn : TS29;
     plan.push_back(Pass29{logn, ts, ts, 0, 0, 0});
@@ -319,7 +326,8 @@ static void dit29(const Wm29Domain& d, const uint32_t* tw, const uint32_t* in_a,
         const bool pw = first && pointwise;
         const bool sc = last && scale != nullptr;
         const int sb = last && store_bitrev ? 1 : 0;
-        if (pw && sc) launch_pass<1, 1>(tiles, a, in_b, in_c, o, tw, scale, vinv, plan[i], sb, st);
+        if (last && const_scale) launch_pass<0, 2>(tiles, a, nullptr, nullptr, o, tw, nullptr, vinv, plan[i], sb, st);
+        else if (pw && sc) launch_pass<1, 1>(tiles, a, in_b, in_c, o, tw, scale, vinv, plan[i], sb, st);
         else if (pw) launch_pass<1, 0>(tiles, a, in_b, in_c, o, tw, scale, vinv, plan[i], sb, st);
         else if (sc) launch_pass<0, 1>(tiles, a, nullptr, nullptr, o, tw, scale, vinv, plan[i], sb, st);
         else launch_pass<0, 0>(tiles, a, nullptr, nullptr, o, tw, scale, vinv, plan[i], sb, st);
@@ -356,6 +364,55 @@ void wm29_run(const Wm29Domain& dom, const DevCsr& A, const DevCsr& B, const Dev
     }
     // (a∘b - c)/Z(g) on load; coset ifft; x g^-i / n and out of Montgomery form on store           :187,201-210
     dit29(dom, dom.tw_inv.p, buf.va.p, buf.vb.p, buf.vc.p, true, buf.va.p, reinterpret_cast<uint32_t*>(h_out), dom.icoset.p, false, st);
+}
+
+// ---- unit-level transform (cg_ntt_*): canonical natural-order data in place -----------------------------------------
+// in[i] canonical -> R' form (times g^i for the forward coset transform), stored at the bit-reversed index
+__global__ void __launch_bounds__(256) k_unit_in29(const Fr* __restrict__ in, uint32_t* __restrict__ out, uint64_t n, int logn,
+                                                   const uint32_t* __restrict__ premul, uint32_t* __restrict__ bad_input) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr x = in[i];
+    if (!fr_lt_modulus(x)) *bad_input = 1u;
+    Fr29 v = from_canonical_bytes<Fr29P>(x);
+    if (premul) v = mul(v, load_packed29(premul, i));
+    store_packed29(out, brev((uint32_t)i, logn), v);
+}
+
+void Ntt29Unit::build(int logn_, hipStream_t st) {
+    logn = logn_;
+    n = 1ull << logn;
+    NttDomain d;
+    d.build(logn, true, st);
+    dom.build(d, st);
+    // g^i in R' form at natural index i (pre-scale of the forward coset transform, r1cs_to_qap.rs:182-185)
+    DevBuf<Fr> g(n);
+    fr_pow_table(g.p, fr_from_u64(5), Fr::one(), n, false, logn, st);
+    gpow.alloc(n * 8);
+    k_to_packed29<<<ceil_div(n, 256), 256, 0, st>>>(g.p, gpow.p, n, 0, 0);
+    CG_KERNEL_CHECK();
+    work.alloc(n * 8);
+    bad_input.alloc(1);
+    h_bad_input.alloc(1);
+    // plain 1 and plain 1/n as packed constants
+    memset(one_plain, 0, 32);
+    one_plain[0] = 1;
+    Fr ninv = from_mont(inv(fr_from_u64(n)));
+    memcpy(ninv_plain, ninv.l, 32);
+    CG_HIP(hipStreamSynchronize(st));   // d and g are released on return
+}
+
+bool Ntt29Unit::run(Fr* data_dev, bool inverse, bool coset, hipStream_t st) {
+    CG_HIP(hipMemsetAsync(bad_input.p, 0, 4, st));
+    k_unit_in29<<<ceil_div(n, 256), 256, 0, st>>>(data_dev, work.p, n, logn, (!inverse && coset) ? gpow.p : nullptr, bad_input.p);
+    CG_KERNEL_CHECK();
+    CG_HIP(hipMemcpyAsync(h_bad_input.p, bad_input.p, 4, hipMemcpyDeviceToHost, st));
+    uint32_t* out = reinterpret_cast<uint32_t*>(data_dev);
+    if (!inverse) dit29(dom, dom.tw_fwd.p, work.p, nullptr, nullptr, false, work.p, out, nullptr, false, st, one_plain);
+    else if (!coset) dit29(dom, dom.tw_inv.p, work.p, nullptr, nullptr, false, work.p, out, nullptr, false, st, ninv_plain);
+    else dit29(dom, dom.tw_inv.p, work.p, nullptr, nullptr, false, work.p, out, dom.icoset.p, false, st);
+    CG_HIP(hipStreamSynchronize(st));
+    return h_bad_input.p[0] == 0;
 }
 
 }  // namespace cg

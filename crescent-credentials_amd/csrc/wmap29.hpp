@@ -1,6 +1,6 @@
 // R1CS -> QAP witness map (forks/groth16/src/r1cs_to_qap.rs:150-213) on the lazy 29-bit-limb field
-// arithmetic: the production path of cg_prove.  (ntt.hip keeps the saturated-limb transforms used by the
-// unit-level cg_ntt entry point and by cg_setup.)
+// arithmetic: the transforms of cg_prove and of the unit-level cg_ntt_* entry points.  (ntt.hip keeps the
+// saturated-limb domain constants these tables are converted from, and the sparse product of cg_setup.)
 //
 // Vector elements live in HBM as 32-byte packed canonical values of x·2^261 mod r ("R' form").
 // Every transform is decimation-in-time (bit-reversed in, natural out): a DIT butterfly only ever
@@ -38,6 +38,23 @@ struct Wm29Buffers {     // per proof slot
         w29.alloc(M * 8); va.alloc(D * 8); vb.alloc(D * 8); vc.alloc(D * 8); vt.alloc(D * 8);
         bad_input.alloc(1); h_bad_input.alloc(1);
     }
+};
+
+// Unit-level transform over the same kernels (cg_ntt_*): 2^logn canonical scalars on the device, natural order in
+// and out, in place.  Replaces EvaluationDomain::{fft,ifft}_in_place and their coset forms (ark-poly; call sites
+// r1cs_to_qap.rs:179-185,198-199,210).
+struct Ntt29Unit {
+    int logn = 0;
+    uint64_t n = 0;
+    Wm29Domain dom;
+    DevBuf<uint32_t> gpow;       // g^i, R' form, natural index
+    DevBuf<uint32_t> work;       // n x 8 words
+    DevBuf<uint32_t> bad_input;
+    PinnedBuf<uint32_t> h_bad_input;
+    uint32_t one_plain[8], ninv_plain[8];
+    void build(int logn, hipStream_t st);
+    // returns false when an input element was not a canonical field element (data is then unspecified); synchronises st
+    bool run(Fr* data_dev, bool inverse, bool coset, hipStream_t st);
 };
 
 // w_canon: M canonical scalars on the device.  h_out: D canonical scalars (natural order), on the device.

@@ -187,6 +187,36 @@ int cg_msm_g2(const uint8_t* bases, uint32_t coord_form, uint64_t n_bases, const
  * inverse = 0: out[k] = Σ a[j] (g^j if coset) ω^{jk};  inverse = 1: the inverse map. */
 int cg_ntt(uint8_t* data, uint32_t log_n, int inverse, int coset);
 
+/* Unit level, resident operands: the handle forms of the two entry points above.  A caller that reuses a set
+ * of bases (a query of the key, a commitment key) or a domain keeps the expanded window tables / twiddle tables
+ * in HBM and may pass scalars / data that already live on the device; these run exactly the kernels cg_prove
+ * runs and are what `tools/sweep.py` times (SURVEY 8d "unit sweeps").
+ *   cg_msm_load_g1/g2 : opt may be NULL; opt->device and opt->window_bits are honoured (0 = size-based default).
+ *   cg_msm_run        : Σ scalars[i]·bases[i] over min(n_scalars, n_bases) pairs; scalars canonical, host or
+ *                       device memory; out = 64 B (G1) / 128 B (G2) affine canonical, zeros = identity.
+ *                       timings (optional): the h (G1) or b2 (G2) MSM fields, accum_*, sort_ms, entries_*.
+ *   cg_ntt_load/run   : in-place transform of 2^log_n canonical scalars in host or device memory, natural
+ *                       order in and out; kernel_ms (optional) = HIP-event time of the transform's kernels.
+ *                       A non-canonical element is CG_ERR_INVALID_ARGUMENT (device data is then unspecified).
+ * Calls on one handle serialise; different handles are independent. */
+typedef struct cg_msm_ctx cg_msm_ctx;
+int cg_msm_load_g1(cg_msm_ctx** out, const uint8_t* bases, uint32_t coord_form, uint64_t n_bases, const cg_options* opt);
+int cg_msm_load_g2(cg_msm_ctx** out, const uint8_t* bases, uint32_t coord_form, uint64_t n_bases, const cg_options* opt);
+int cg_msm_run(cg_msm_ctx* ctx, const void* scalars, int scalars_on_device, uint64_t n_scalars, uint8_t* out,
+               cg_timings* timings);
+void cg_msm_free(cg_msm_ctx* ctx);
+typedef struct cg_ntt_ctx cg_ntt_ctx;
+int cg_ntt_load(cg_ntt_ctx** out, uint32_t log_n, int32_t device /* -1 = current */);
+int cg_ntt_run(cg_ntt_ctx* ctx, void* data, int data_on_device, int inverse, int coset, float* kernel_ms);
+void cg_ntt_free(cg_ntt_ctx* ctx);
+
+/* out[i] = scalars[i]·G for the standard generator of G1 / G2 (canonical scalars in, canonical affine points
+ * out, 64 / 128 B each, zeros = identity).
+ * Replaces: `FixedBase::msm::<E::G1 | E::G2>(scalar_bits, window, &table, &scalars)` [ark-ec], the building block
+ *           of the generator (forks/groth16/src/generator.rs:134-140,147-148,162-194). */
+int cg_fixed_base_g1(const uint8_t* scalars, uint64_t n, uint8_t* out);
+int cg_fixed_base_g2(const uint8_t* scalars, uint64_t n, uint8_t* out);
+
 /* Trusted setup from explicit toxic waste, on the GPU.
  * Replaces: `generate_parameters_with_qap`, forks/groth16/src/generator.rs:50-228, with
  *           gamma = 1 and the standard generators as the fork fixes them (:28,:34-35).

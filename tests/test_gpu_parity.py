@@ -158,6 +158,106 @@ def test_msm_large_closed_form(cc, oracle):
         assert cc.msm_bigint_g1(b1, _scalars(sc), window_bits=wb).hex() == exp
 
 
+# ------------------------------------------------------------------------------------------- resident-operand unit entry points
+@pytest.mark.parametrize("logn", [0, 1, 2, 3, 5, 9, 10, 11])
+def test_ntt_context_all_modes_vs_oracle(cc, oracle, logn):
+    """cg_ntt_load / cg_ntt_run on the 29-bit kernels, every (inverse, coset) mode, sizes below, at and above one LDS tile"""
+    rng = random.Random(700 + logn)
+    n = 1 << logn
+    v = [rng.choice([0, 1, oracle.R - 1, rng.randrange(oracle.R)]) for _ in range(n)]
+    ctx = cc.NttContext(logn)
+    try:
+        for inverse in (False, True):
+            for coset in (False, True):
+                exp = list(v)
+                if not inverse:
+                    exp = oracle.coset_fft(exp) if coset else oracle.fft(exp)
+                else:
+                    exp = oracle.coset_ifft(exp) if coset else oracle.ifft(exp)
+                assert _ints(ctx.run(_scalars(v), inverse=inverse, coset=coset)) == exp, (logn, inverse, coset)
+    finally:
+        ctx.close()
+
+
+def test_ntt_context_device_data_and_errors(cc, oracle):
+    import torch
+    logn = 14
+    n = 1 << logn
+    rng = random.Random(5)
+    v = [rng.randrange(oracle.R) for _ in range(n)]
+    ctx = cc.NttContext(logn)
+    try:
+        host = ctx.run(_scalars(v), coset=True)
+        d = torch.from_numpy(_scalars(v)).cuda()
+        ms = ctx.run_dev(d.data_ptr(), coset=True)
+        assert ms > 0
+        assert bytes(d.cpu().numpy()) == bytes(host)
+        ctx.run_dev(d.data_ptr(), inverse=True, coset=True)          # and back, in place on the device
+        assert _ints(d.cpu().numpy()) == v
+        bad = list(v)
+        bad[77] = oracle.R                                           # not a field element
+        with pytest.raises(cc.CrescentGpuError):
+            ctx.run(_scalars(bad))
+        with pytest.raises(ValueError):
+            ctx.run(_scalars(v[:-1]))
+    finally:
+        ctx.close()
+    with pytest.raises(cc.CrescentGpuError):
+        cc.NttContext(29)                                            # beyond the two-adicity (PolynomialDegreeTooLarge)
+
+
+def test_fixed_base_vs_oracle(cc, oracle):
+    rng = random.Random(17)
+    ks = [0, 1, 2, oracle.R - 1] + [rng.randrange(oracle.R) for _ in range(20)]
+    out1 = cc.fixed_base_g1(_scalars(ks))
+    out2 = cc.fixed_base_g2(_scalars(ks))
+    for i, k in enumerate(ks):
+        e1 = oracle.g1_packed(oracle.G1.to_affine(oracle.G1.mul_affine(oracle.G1_GEN, k))) if k else bytes(64)
+        e2 = oracle.g2_packed(oracle.G2.to_affine(oracle.G2.mul_affine(oracle.G2_GEN, k))) if k else bytes(128)
+        assert out1[64 * i:64 * i + 64] == e1, i
+        assert out2[128 * i:128 * i + 128] == e2, i
+    assert cc.fixed_base_g1(b"") == b""
+    with pytest.raises(cc.CrescentGpuError):
+        cc.fixed_base_g1(_scalars([oracle.R]))
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_msm_context_matches_one_shot_and_closed_form(cc, oracle, group):
+    """resident bases (window tables precomputed) == one-shot msm_bigint == (Σ s_i k_i)·G"""
+    import torch
+    rng = random.Random(40 + group)
+    n = 5000
+    ks = [rng.randrange(1, oracle.R) for _ in range(n)]
+    ks[10] = 0                                                           # an identity base
+    bases = (cc.fixed_base_g1 if group == 1 else cc.fixed_base_g2)(_scalars(ks))
+    one_shot = cc.msm_bigint_g1 if group == 1 else cc.msm_bigint_g2
+    curve, gen, packed = (oracle.G1, oracle.G1_GEN, oracle.g1_packed) if group == 1 else (oracle.G2, oracle.G2_GEN, oracle.g2_packed)
+    for wb in (0, 7):
+        ctx = cc.MsmContext(bases, group=group, window_bits=wb)
+        try:
+            for trial in range(3):
+                if trial == 0:
+                    sc = [rng.randrange(oracle.R) for _ in range(n)]                          # uniform
+                elif trial == 1:
+                    sc = [rng.choice([0, 0, 1, 1, 1, rng.randrange(oracle.R)]) for _ in range(n)]    # 0/1-heavy
+                else:
+                    sc = [rng.randrange(oracle.R) for _ in range(n // 3)]                      # fewer scalars than bases
+                e = sum(k * s for k, s in zip(ks, sc)) % oracle.R
+                exp = packed(curve.to_affine(curve.mul_affine(gen, e))) if e else bytes(64 * group)
+                got, tm = ctx.run(_scalars(sc), timings=True)
+                assert got == exp, (group, wb, trial)
+                assert tm["msm_g%d_pairs" % group] == len(sc)
+                if trial == 0:
+                    assert one_shot(bases, _scalars(sc)) == exp
+                    d = torch.from_numpy(_scalars(sc)).cuda()
+                    assert ctx.run_dev(d.data_ptr(), len(sc)) == exp
+            assert ctx.run(b"") == bytes(64 * group)
+            with pytest.raises(cc.CrescentGpuError):
+                ctx.run(_scalars([oracle.R] + [1] * 9))
+        finally:
+            ctx.close()
+
+
 # ------------------------------------------------------------------------------------------- setup
 def _pk_from_json(cc, j):
     a = lambda h: np.frombuffer(bytes.fromhex(h), dtype=np.uint8).copy()
