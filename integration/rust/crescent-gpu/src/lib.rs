@@ -1,0 +1,206 @@
+//! Safe wrapper: a Groth16 circuit resident on one MI355X, proving through `cg_prove`.
+//!
+//! `GpuCircuit::create_proof` has the semantics of
+//! `Groth16::<Bn254, LibsnarkReduction>::create_proof_with_reduction_and_matrices`
+//! (forks/groth16/src/prover.rs:26-51): same operands, same `Proof`, byte for byte.
+pub mod sys;
+
+use ark_bn254::{Bn254, Fq, Fq2, Fr, G1Affine, G2Affine};
+use ark_ff::{BigInteger, PrimeField};
+use ark_groth16::{Proof, ProvingKey};
+use ark_relations::r1cs::{ConstraintMatrices, SynthesisError};
+use ark_serialize::CanonicalDeserialize;
+use std::ffi::CStr;
+
+// `Affine { x, y, infinity }` is repr(Rust): coordinates are packed into byte arrays, struct pointers never
+// cross the boundary.  The Montgomery limbs are copied as they are (`Fp.0` is the BigInt of x·2^256 mod p, the
+// form forks/circom-compat/src/zkey.rs:397-402 pins), so no field arithmetic happens on this side.
+fn put_fq(out: &mut [u8], x: &Fq) {
+    for (k, limb) in x.0 .0.iter().enumerate() {
+        out[k * 8..k * 8 + 8].copy_from_slice(&limb.to_le_bytes());
+    }
+}
+fn put_fq2(out: &mut [u8], x: &Fq2) {
+    put_fq(&mut out[..32], &x.c0);
+    put_fq(&mut out[32..64], &x.c1);
+}
+fn pack_g1(v: &[G1Affine]) -> Vec<u8> {
+    let mut out = vec![0u8; v.len() * 64];
+    for (i, p) in v.iter().enumerate() {
+        if p.infinity {
+            continue; // identity = 64 zero bytes
+        }
+        put_fq(&mut out[i * 64..i * 64 + 32], &p.x);
+        put_fq(&mut out[i * 64 + 32..i * 64 + 64], &p.y);
+    }
+    out
+}
+fn pack_g2(v: &[G2Affine]) -> Vec<u8> {
+    let mut out = vec![0u8; v.len() * 128];
+    for (i, p) in v.iter().enumerate() {
+        if p.infinity {
+            continue; // identity = 128 zero bytes
+        }
+        put_fq2(&mut out[i * 128..i * 128 + 64], &p.x); // x.c0 ‖ x.c1
+        put_fq2(&mut out[i * 128 + 64..i * 128 + 128], &p.y); // y.c0 ‖ y.c1
+    }
+    out
+}
+
+struct Csr {
+    row_ptr: Vec<u64>,
+    col: Vec<u32>,
+    coeff: Vec<u8>,
+}
+fn to_csr(rows: &[Vec<(Fr, usize)>]) -> Csr {
+    let mut m = Csr { row_ptr: vec![0u64], col: Vec::new(), coeff: Vec::new() };
+    for row in rows {
+        for (c, j) in row {
+            m.col.push(*j as u32);
+            m.coeff.extend_from_slice(&c.into_bigint().to_bytes_le()); // canonical, 32 bytes
+        }
+        m.row_ptr.push(m.col.len() as u64);
+    }
+    m
+}
+impl Csr {
+    fn view(&self) -> sys::cg_csr {
+        sys::cg_csr { row_ptr: self.row_ptr.as_ptr(), col: self.col.as_ptr(), coeff: self.coeff.as_ptr(), nnz: self.col.len() as u64 }
+    }
+}
+
+fn last_error() -> String {
+    unsafe { CStr::from_ptr(sys::cg_last_error()).to_string_lossy().into_owned() }
+}
+fn map_err(rc: i32) -> SynthesisError {
+    eprintln!("crescent-gpu: {} (code {})", last_error(), rc);
+    match rc {
+        sys::CG_ERR_POLY_DEGREE_TOO_LARGE => SynthesisError::PolynomialDegreeTooLarge, // r1cs_to_qap.rs:156-157
+        sys::CG_ERR_MALFORMED_KEY => SynthesisError::MalformedVerifyingKey,
+        _ => SynthesisError::AssignmentMissing, // no twin in SynthesisError; the message is on stderr
+    }
+}
+
+pub struct GpuCircuit {
+    ctx: *mut sys::cg_ctx,
+    num_variables: usize,
+}
+// calls on one context are multiplexed over its proof slots inside the library
+unsafe impl Send for GpuCircuit {}
+unsafe impl Sync for GpuCircuit {}
+
+impl GpuCircuit {
+    /// One-time: pack the key and the matrices and copy them to the GPU (`cg_circuit_load`).
+    /// `proof_slots` = proofs that may be in flight on this circuit at once (one per calling thread).
+    pub fn load(pk: &ProvingKey<Bn254>, m: &ConstraintMatrices<Fr>, device: i32, proof_slots: i32) -> Result<Self, SynthesisError> {
+        let rc = unsafe { sys::cg_init(0, std::ptr::null()) };
+        if rc != 0 {
+            return Err(map_err(rc));
+        }
+        let (alpha, beta1, delta1) = (pack_g1(&[pk.vk.alpha_g1]), pack_g1(&[pk.beta_g1]), pack_g1(&[pk.delta_g1]));
+        let (beta2, delta2) = (pack_g2(&[pk.vk.beta_g2]), pack_g2(&[pk.vk.delta_g2]));
+        let (a, b1, h, l) = (pack_g1(&pk.a_query), pack_g1(&pk.b_g1_query), pack_g1(&pk.h_query), pack_g1(&pk.l_query));
+        let b2 = pack_g2(&pk.b_g2_query);
+        let view = sys::cg_proving_key {
+            coord_form: sys::CG_FORM_MONTGOMERY,
+            alpha_g1: alpha.as_ptr(),
+            beta_g1: beta1.as_ptr(),
+            delta_g1: delta1.as_ptr(),
+            beta_g2: beta2.as_ptr(),
+            delta_g2: delta2.as_ptr(),
+            a_query: a.as_ptr(),
+            a_len: pk.a_query.len() as u64,
+            b_g1_query: b1.as_ptr(),
+            b_g1_len: pk.b_g1_query.len() as u64,
+            b_g2_query: b2.as_ptr(),
+            b_g2_len: pk.b_g2_query.len() as u64,
+            h_query: h.as_ptr(),
+            h_len: pk.h_query.len() as u64,
+            l_query: l.as_ptr(),
+            l_len: pk.l_query.len() as u64,
+        };
+        let (ca, cb, cc) = (to_csr(&m.a), to_csr(&m.b), to_csr(&m.c));
+        let abc = [ca.view(), cb.view(), cc.view()];
+        let opt = sys::cg_options { device, proof_slots, ..Default::default() };
+        let num_variables = m.num_instance_variables + m.num_witness_variables;
+        let mut ctx: *mut sys::cg_ctx = std::ptr::null_mut();
+        let rc = unsafe {
+            sys::cg_circuit_load(&mut ctx, &view, abc.as_ptr(), m.num_instance_variables as u64, m.num_constraints as u64,
+                                 num_variables as u64, &opt)
+        };
+        if rc != 0 {
+            return Err(map_err(rc));
+        }
+        Ok(GpuCircuit { ctx, num_variables })
+    }
+
+    /// forks/groth16/src/prover.rs:26-51 with the key and the matrices already resident on the GPU.
+    /// `full_assignment` = instance assignment ‖ witness assignment (element 0 is the constant one).
+    pub fn create_proof(&self, r: Fr, s: Fr, full_assignment: &[Fr]) -> Result<Proof<Bn254>, SynthesisError> {
+        if full_assignment.len() != self.num_variables {
+            return Err(SynthesisError::AssignmentMissing);
+        }
+        let mut w = Vec::with_capacity(full_assignment.len() * 32);
+        for x in full_assignment {
+            w.extend_from_slice(&x.into_bigint().to_bytes_le()); // prover.rs:64,71,86 take the same form
+        }
+        let (rb, sb) = (r.into_bigint().to_bytes_le(), s.into_bigint().to_bytes_le());
+        let mut out = [0u8; 256];
+        let rc = unsafe { sys::cg_prove(self.ctx, w.as_ptr(), rb.as_ptr(), sb.as_ptr(), out.as_mut_ptr(), std::ptr::null_mut()) };
+        if rc != 0 {
+            return Err(map_err(rc));
+        }
+        // a ‖ b ‖ c, ark-serialize uncompressed (data_structures.rs:7-14)
+        Proof::deserialize_uncompressed_unchecked(&out[..]).map_err(|_| SynthesisError::MalformedVerifyingKey)
+    }
+}
+
+impl Drop for GpuCircuit {
+    fn drop(&mut self) {
+        unsafe { sys::cg_circuit_free(self.ctx) }
+    }
+}
+
+/// `ConstraintMatrices` of a circom R1CS with column = wire id: the matrices `cs.to_matrices()` yields for
+/// `CircomCircuit::generate_constraints` (forks/circom-compat/src/circom/circuit.rs:61-86) when the wire mapping
+/// is disabled (builder.rs:63-64).  `constraints` is `circom.r1cs.constraints`.
+pub fn matrices_of(num_inputs: usize, num_variables: usize,
+                   constraints: &[(Vec<(usize, Fr)>, Vec<(usize, Fr)>, Vec<(usize, Fr)>)]) -> ConstraintMatrices<Fr> {
+    let conv = |lc: &Vec<(usize, Fr)>| lc.iter().map(|(j, c)| (*c, *j)).collect::<Vec<_>>();
+    let a: Vec<_> = constraints.iter().map(|c| conv(&c.0)).collect();
+    let b: Vec<_> = constraints.iter().map(|c| conv(&c.1)).collect();
+    let c: Vec<_> = constraints.iter().map(|c| conv(&c.2)).collect();
+    ConstraintMatrices {
+        num_instance_variables: num_inputs,
+        num_witness_variables: num_variables - num_inputs,
+        num_constraints: constraints.len(),
+        a_num_non_zero: a.iter().map(|r| r.len()).sum(),
+        b_num_non_zero: b.iter().map(|r| r.len()).sum(),
+        c_num_non_zero: c.iter().map(|r| r.len()).sum(),
+        a,
+        b,
+        c,
+    }
+}
+
+/// `<G1 as VariableBaseMSM>::msm_bigint` for the show-step sized sums (creds/src/utils.rs:124-138): one-shot.
+pub fn msm_g1(bases: &[G1Affine], scalars: &[Fr]) -> Result<G1Affine, SynthesisError> {
+    let b = pack_g1(bases);
+    let mut sc = Vec::with_capacity(scalars.len() * 32);
+    for x in scalars {
+        sc.extend_from_slice(&x.into_bigint().to_bytes_le());
+    }
+    let mut out = [0u8; 64];
+    let rc = unsafe {
+        sys::cg_msm_g1(b.as_ptr(), sys::CG_FORM_MONTGOMERY, bases.len() as u64, sc.as_ptr(), scalars.len() as u64, 0, out.as_mut_ptr())
+    };
+    if rc != 0 {
+        return Err(map_err(rc));
+    }
+    if out.iter().all(|v| *v == 0) {
+        return Ok(G1Affine::identity());
+    }
+    let x = Fq::from_le_bytes_mod_order(&out[..32]);
+    let y = Fq::from_le_bytes_mod_order(&out[32..]);
+    Ok(G1Affine::new_unchecked(x, y))
+}

@@ -1,0 +1,124 @@
+//! Raw bindings: one item per declaration of include/crescent_gpu.h that the shim uses.
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_int, c_void};
+
+pub const CG_FORM_CANONICAL: u32 = 0;
+pub const CG_FORM_MONTGOMERY: u32 = 1;
+pub const CG_ERR_POLY_DEGREE_TOO_LARGE: c_int = -5;
+pub const CG_ERR_MALFORMED_KEY: c_int = -6;
+
+#[repr(C)]
+pub struct cg_proving_key {
+    pub coord_form: u32,
+    pub alpha_g1: *const u8,
+    pub beta_g1: *const u8,
+    pub delta_g1: *const u8,
+    pub beta_g2: *const u8,
+    pub delta_g2: *const u8,
+    pub a_query: *const u8,
+    pub a_len: u64,
+    pub b_g1_query: *const u8,
+    pub b_g1_len: u64,
+    pub b_g2_query: *const u8,
+    pub b_g2_len: u64,
+    pub h_query: *const u8,
+    pub h_len: u64,
+    pub l_query: *const u8,
+    pub l_len: u64,
+}
+
+#[repr(C)]
+pub struct cg_csr {
+    pub row_ptr: *const u64,
+    pub col: *const u32,
+    pub coeff: *const u8,
+    pub nnz: u64,
+}
+
+#[repr(C)]
+#[derive(Default, Clone, Copy)]
+pub struct cg_options {
+    pub device: i32,
+    pub window_bits: i32,
+    pub shard_rank: i32,
+    pub shard_count: i32,
+    pub proof_slots: i32,
+    pub reserved: [i32; 3],
+}
+
+#[repr(C)]
+#[derive(Default, Clone, Copy, Debug)]
+pub struct cg_timings {
+    pub upload_ms: f32,
+    pub witness_map_ms: f32,
+    pub msm_h_ms: f32,
+    pub msm_l_ms: f32,
+    pub msm_a_ms: f32,
+    pub msm_b1_ms: f32,
+    pub msm_b2_ms: f32,
+    pub finish_ms: f32,
+    pub total_ms: f32,
+    pub msm_g1_pairs: u64,
+    pub msm_g2_pairs: u64,
+    pub accum_g1_ms: f32,
+    pub accum_g2_ms: f32,
+    pub sort_ms: f32,
+    pub reserved_ms: f32,
+    pub entries_g1: u64,
+    pub entries_g2: u64,
+    pub accum_g1_launches: u32,
+    pub accum_g2_launches: u32,
+}
+
+pub enum cg_ctx {}
+pub enum cg_msm_ctx {}
+
+extern "C" {
+    pub fn cg_init(n_devices: c_int, device_ids: *const c_int) -> c_int;
+    pub fn cg_last_error() -> *const c_char;
+    pub fn cg_circuit_load(
+        out: *mut *mut cg_ctx,
+        pk: *const cg_proving_key,
+        abc: *const cg_csr,
+        num_inputs: u64,
+        num_constraints: u64,
+        num_variables: u64,
+        opt: *const cg_options,
+    ) -> c_int;
+    pub fn cg_circuit_free(ctx: *mut cg_ctx);
+    pub fn cg_prove(
+        ctx: *mut cg_ctx,
+        full_assignment: *const u8,
+        r: *const u8,
+        s: *const u8,
+        proof_out: *mut u8,
+        timings: *mut cg_timings,
+    ) -> c_int;
+    pub fn cg_witness_map(ctx: *mut cg_ctx, full_assignment: *const u8, h_out: *mut u8) -> c_int;
+    pub fn cg_domain_size(ctx: *const cg_ctx) -> u64;
+    pub fn cg_msm_g1(
+        bases: *const u8,
+        coord_form: u32,
+        n_bases: u64,
+        scalars: *const u8,
+        n_scalars: u64,
+        window_bits: i32,
+        out: *mut u8,
+    ) -> c_int;
+    pub fn cg_msm_load_g1(
+        out: *mut *mut cg_msm_ctx,
+        bases: *const u8,
+        coord_form: u32,
+        n_bases: u64,
+        opt: *const cg_options,
+    ) -> c_int;
+    pub fn cg_msm_run(
+        ctx: *mut cg_msm_ctx,
+        scalars: *const c_void,
+        scalars_on_device: c_int,
+        n_scalars: u64,
+        out: *mut u8,
+        timings: *mut cg_timings,
+    ) -> c_int;
+    pub fn cg_msm_free(ctx: *mut cg_msm_ctx);
+}

@@ -168,3 +168,32 @@ def test_circuit_load_validates_before_touching_the_gpu(cc):
     assert rc == -6 and b"h_query" in L.cg_last_error()
     rc = L.cg_circuit_load(ctypes.byref(h), ctypes.byref(pk), abc, 3, (1 << 28) + 5, (1 << 28) + 9, None)
     assert rc == -5            # PolynomialDegreeTooLarge (r1cs_to_qap.rs:156-157)
+
+
+def _c_struct_fields(name):
+    src = open(os.path.join(ROOT, "include", "crescent_gpu.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), src, flags=re.S).group(1)
+    out = []
+    for decl in body.split(";"):
+        m = re.search(r"(\w+)\s*(\[\d+\])?\s*$", decl.strip())
+        if m and decl.strip():
+            out.append(m.group(1))
+    return out
+
+
+def test_rust_shim_bindings_match_header():
+    """integration/rust/crescent-gpu/src/sys.rs (compile-untested: no Rust toolchain here) declares only functions the
+    header declares, and its repr(C) structs list the header's fields in the header's order."""
+    rs = open(os.path.join(ROOT, "integration", "rust", "crescent-gpu", "src", "sys.rs")).read()
+    fns = re.findall(r"pub fn (cg_[a-z0-9_]+)\s*\(", rs)
+    assert len(fns) >= 8 and set(fns) <= set(_declared_symbols())
+    for name in ("cg_proving_key", "cg_csr", "cg_options", "cg_timings"):
+        body = re.search(r"pub struct %s \{(.*?)\n\}" % name, rs, flags=re.S).group(1)
+        fields = re.findall(r"pub (\w+):", body)
+        assert fields == _c_struct_fields(name), name
+    # the ctypes mirrors agree too
+    from crescent_credentials_amd import api
+    assert [f for f, _ in api._CgOptions._fields_] == _c_struct_fields("cg_options")
+    assert [f for f, _ in api.CgTimings._fields_] == _c_struct_fields("cg_timings")
+    assert [f for f, _ in api._CgProvingKey._fields_] == _c_struct_fields("cg_proving_key")
