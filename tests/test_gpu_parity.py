@@ -322,6 +322,52 @@ def test_prove_golden(cc, oracle, name):
         cc.Groth16.clear_cache()
 
 
+def _pk_from_oracle(cc, oracle, pk):
+    g1s = lambda pts: np.frombuffer(b"".join(oracle.g1_packed(p) for p in pts), dtype=np.uint8).copy()
+    g2s = lambda pts: np.frombuffer(b"".join(oracle.g2_packed(p) for p in pts), dtype=np.uint8).copy()
+    v = pk["vk"]
+    vk = cc.VerifyingKey(alpha_g1=g1s([v["alpha_g1"]]), beta_g2=g2s([v["beta_g2"]]), gamma_g2=g2s([v["gamma_g2"]]),
+                         delta_g1=g1s([v["delta_g1"]]), delta_g2=g2s([v["delta_g2"]]), gamma_abc_g1=g1s(v["gamma_abc_g1"]))
+    return cc.ProvingKey(vk=vk, beta_g1=g1s([pk["beta_g1"]]), delta_g1=g1s([pk["delta_g1"]]), a_query=g1s(pk["a_query"]),
+                         b_g1_query=g1s(pk["b_g1_query"]), b_g2_query=g2s(pk["b_g2_query"]), h_query=g1s(pk["h_query"]),
+                         l_query=g1s(pk["l_query"]))
+
+
+@pytest.mark.parametrize("l,m,M", [(1, 1, 1), (1, 1, 2), (3, 5, 8), (3, 6, 9), (4, 3, 4), (2, 0, 5), (1, 7, 3), (5, 11, 16)],
+                         ids=lambda v: str(v))
+def test_prove_edge_shapes(cc, oracle, l, m, M):
+    """Ragged and degenerate shapes against the Python oracle: no witness variables at all (M = l: empty l_query and
+    a one-point a/b query), m + l exactly a power of two and one past it, no constraints, more constraints than
+    variables; rows that are empty, repeat a column, or carry the coefficients 0, 1 and r - 1; witnesses that do NOT
+    satisfy the system (parity is about bytes, not about acceptance), all-zero and all-(r-1) witnesses."""
+    rng = random.Random(1000 * l + 10 * m + M)
+    def row():
+        k = rng.choice([0, 1, 1, 2, 3])
+        return [(rng.choice([0, 1, 1, oracle.R - 1, rng.randrange(oracle.R)]), rng.randrange(M)) for _ in range(k)]
+    mats = tuple([row() for _ in range(m)] for _ in range(3))
+    trap = [rng.randrange(1, oracle.R) for _ in range(4)]
+    pk_o, _ = oracle.generate_parameters(mats, l, m, M, *trap)
+    cm = cc.ConstraintMatrices.from_rows(mats[0], mats[1], mats[2], l, M)
+    pk_gpu = cc.generate_parameters_with_qap(cm, trap[1], trap[2], trap[3], trap[0])
+    pk = _pk_from_oracle(cc, oracle, pk_o)
+    assert _pk_digest(pk_gpu) == _pk_digest(pk)                       # cg_setup on the same degenerate shape
+    prover = cc.Prover(pk, cm)
+    try:
+        for wit in ("random", "zeros", "max"):
+            if wit == "random":
+                w = [1] + [rng.randrange(oracle.R) for _ in range(M - 1)]
+            elif wit == "zeros":
+                w = [1] + [0] * (M - 1)
+            else:
+                w = [1] + [oracle.R - 1] * (M - 1)
+            assert _ints(prover.witness_map(_scalars(w))) == oracle.witness_map_from_matrices(mats, l, m, w)
+            for r, s in ((0, 0), (rng.randrange(oracle.R), 0), (rng.randrange(oracle.R), rng.randrange(oracle.R))):
+                exp = oracle.proof_uncompressed(oracle.create_proof_with_reduction_and_matrices(pk_o, r, s, mats, l, m, w))
+                assert prover.prove(_scalars(w), r, s).data == exp, (wit, r != 0, s != 0)
+    finally:
+        prover.close()
+
+
 def test_prove_verifies_with_pairing(cc, oracle):
     """acceptance criterion of the reference's own tests (verify == true; verifier.rs:44-77), checked by the
     oracle's pairing on a GPU-made key + GPU-made proof, plus the trapdoor closed form."""
@@ -391,14 +437,20 @@ def test_sharded_partials_assemble_to_same_proof(cc, oracle):
                 p.close()
 
 
-@pytest.mark.parametrize("shape,bit_fraction", [("medium", 0.9), ("medium", 0.0), ("large18", 0.9)])
+_CPU_SHAPES = {"log11": (4, 1_500, 1_600), "exact12": (6, 4_090, 4_200), "log13": (10, 5_000, 5_100), "log14": (3, 9_000, 16_000),
+               "log15": (12, 20_000, 20_500), "medium": (20, 60_000, 61_000), "log17": (8, 100_000, 100_100), "large18": (26, 250_000, 255_000)}
+
+
+@pytest.mark.parametrize("shape,bit_fraction", [("log11", 0.5), ("exact12", 0.9), ("log13", 0.0), ("log14", 0.9), ("log15", 0.3),
+                                                ("medium", 0.9), ("medium", 0.0), ("log17", 0.7), ("large18", 0.9)])
 def test_prove_equals_cpu_restatement(cc, oracle, shape, bit_fraction):
-    """Full proofs at D = 2^16 / 2^18 (too large for the Python oracle): byte-identical to oracle/cpu_ref.c, the C
-    restatement that tests/test_cpu_ref.py pins to the golden vectors; exercises every NTT pass plan and the
-    production window size."""
+    """Full proofs at D = 2^11 .. 2^18 (too large for the Python oracle): byte-identical to oracle/cpu_ref.c, the C
+    restatement that tests/test_cpu_ref.py pins to the golden vectors; covers every NTT pass plan up to three passes
+    (one LDS pass + strided passes of 1..6 stages), m + l exactly a power of two, M much larger than m, and the
+    production window sizes."""
     import cpu_ref
     from crescent_credentials_amd import workloads as wl
-    l, m, M = (20, 60_000, 61_000) if shape == "medium" else (26, 250_000, 255_000)
+    l, m, M = _CPU_SHAPES[shape]
     cm, w = wl.synthetic_circuit(2024, l, m, M, bit_fraction, 3)
     rng = random.Random(11)
     tau, alpha, beta, delta = (rng.randrange(1, oracle.R) for _ in range(4))
