@@ -53,8 +53,8 @@ def pmc_traffic(launches_per_proof):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--shape", default="rs256-sd")
     ap.add_argument("--mode", default="throughput", choices=["throughput", "sharded"])
     ap.add_argument("--witness", default="circom", choices=["circom", "uniform"],
@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-uniform", action="store_true", help="skip the secondary uniform-witness measurement")
     ap.add_argument("--window", type=int, default=0)
+    ap.add_argument("--h-coefficient-basis", action="store_true",
+                    help="keep the h query as loaded and run the seventh transform per proof (A/B against the default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for plumbing tests)")
     ap.add_argument("--inflight", type=int, default=4,
                     help="proofs in flight per GPU (throughput mode): host threads x context proof_slots")
@@ -107,10 +109,12 @@ def main():
     t0 = time.time()
     sharded = a.mode == "sharded" and world > 1
     if sharded:
-        prover = cc.Prover(pk, cm, device=local_rank, window_bits=a.window, shard_rank=rank, shard_count=world)
+        prover = cc.Prover(pk, cm, device=local_rank, window_bits=a.window, shard_rank=rank, shard_count=world,
+                           h_coefficient_basis=a.h_coefficient_basis)
         sp = ShardedProver(prover, dev)
     else:
-        prover = cc.Prover(pk, cm, device=local_rank, window_bits=a.window, proof_slots=a.inflight)
+        prover = cc.Prover(pk, cm, device=local_rank, window_bits=a.window, proof_slots=a.inflight,
+                           h_coefficient_basis=a.h_coefficient_basis)
     log("circuit loaded on GPU in %.1fs (D = %d)" % (time.time() - t0, prover.domain_size))
     w_dev = torch.from_numpy(w_np).to(dev)            # the witness is resident in HBM before timing starts
     torch.cuda.synchronize()
@@ -188,7 +192,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%s shape: D=2^%d, m=%d, M=%d, l=%d; witness=%s; pk from seeded trapdoor (GPU setup)" %
                    (a.shape, prover.domain_size.bit_length() - 1, m, M, l, a.witness),
-                   "mode": a.mode, "proofs_per_rank": a.steps, "proofs_in_flight_per_gpu": inflight,
+                   "mode": a.mode, "h_query_basis": "coefficient" if a.h_coefficient_basis else "coset evaluation (transformed at load)",
+                   "proofs_per_rank": a.steps, "proofs_in_flight_per_gpu": inflight,
                    "inputs": "witness resident in HBM; (r,s) fresh per proof"},
     }
     if roof:
@@ -226,7 +231,8 @@ def main():
         cm_u, wu_np = wl.synthetic_circuit(0xC5E5CE47 + 4, l, m, M, 0.0, 3)
         pk_u = cc.generate_parameters_with_qap(cm_u, *trap)
         prover.close()
-        pu = cc.Prover(pk_u, cm_u, device=local_rank, window_bits=a.window, proof_slots=inflight)
+        pu = cc.Prover(pk_u, cm_u, device=local_rank, window_bits=a.window, proof_slots=inflight,
+                       h_coefficient_basis=a.h_coefficient_basis)
         wu = torch.from_numpy(wu_np).to(dev)
         torch.cuda.synchronize()
         ksteps = max(inflight, a.steps // 2)

@@ -19,6 +19,7 @@ _LIB_PATH = os.path.join(_HERE, "libcrescent_gpu.so")
 
 FR_MODULUS = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 CG_FORM_CANONICAL, CG_FORM_MONTGOMERY = 0, 1
+CG_FLAG_H_COEFFICIENT_BASIS = 1
 
 
 class CrescentGpuError(RuntimeError):
@@ -50,7 +51,7 @@ class _CgCsr(C.Structure):
 
 class _CgOptions(C.Structure):
     _fields_ = [("device", C.c_int32), ("window_bits", C.c_int32), ("shard_rank", C.c_int32),
-                ("shard_count", C.c_int32), ("proof_slots", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("shard_count", C.c_int32), ("proof_slots", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class CgTimings(C.Structure):
@@ -275,13 +276,14 @@ class Prover:
     """A circuit loaded on one GPU (cg_ctx): proving key tables + matrices resident in HBM."""
 
     def __init__(self, pk: ProvingKey, matrices: ConstraintMatrices, device: int = -1, window_bits: int = 0,
-                 shard_rank: int = 0, shard_count: int = 1, proof_slots: int = 1):
+                 shard_rank: int = 0, shard_count: int = 1, proof_slots: int = 1, h_coefficient_basis: bool = False):
+        """h_coefficient_basis=True keeps the h query as loaded (seven transforms per proof, CG_FLAG_H_COEFFICIENT_BASIS)."""
         L = lib()
         self.num_inputs = matrices.num_instance_variables
         self.num_constraints = matrices.num_constraints
         self.num_variables = matrices.num_variables
         opt = _CgOptions(device=device, window_bits=window_bits, shard_rank=shard_rank, shard_count=shard_count,
-                         proof_slots=proof_slots)
+                         proof_slots=proof_slots, flags=CG_FLAG_H_COEFFICIENT_BASIS if h_coefficient_basis else 0)
         self.proof_slots = max(1, proof_slots)
         cpk = pk._c()
         abc, _keep = matrices._c()

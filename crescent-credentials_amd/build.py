@@ -17,7 +17,7 @@ BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libcrescent_gpu.so")
 SYNTH_LIB = os.path.join(HERE, "libcg_synth.so")
 
-HIP_SOURCES = ["ntt.hip", "wmap29.hip", "msm.hip", "prover.hip", "unit.hip", "setup.hip", "r1cs.hip", "serialize.hip"]
+HIP_SOURCES = ["ntt.hip", "wmap29.hip", "msm.hip", "ecntt.hip", "prover.hip", "unit.hip", "setup.hip", "r1cs.hip", "serialize.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 

@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(256) k_table_next(uint32_t* __restrict__ table
 }
 
 template <class F>
-void MsmBases<F>::build(const Affine<F>* bases_dev, uint64_t n_, int c_, bool precompute, hipStream_t st) {
+void MsmBases<F>::alloc_rows(uint64_t n_, int c_, bool precompute) {
     n = n_;
     c = c_;
     W = (SCALAR_BITS + c - 1) / c;
@@ -152,14 +152,49 @@ void MsmBases<F>::build(const Affine<F>* bases_dev, uint64_t n_, int c_, bool pr
     const uint64_t rows = precompute ? (uint64_t)W : 1;
     table.alloc(n ? rows * n * AFF : 4);
     valid.alloc(n ? n : 1);
+}
+template <class F>
+void MsmBases<F>::expand_rows(hipStream_t st) {
+    if (!precomputed || !n) return;
+    for (int j = 1; j < W; ++j) {
+        k_table_next<F29T><<<ceil_div(n, 256), 256, 0, st>>>(table.p, valid.p, n, j, c);
+        CG_KERNEL_CHECK();
+    }
+}
+
+template <class F>
+void MsmBases<F>::build(const Affine<F>* bases_dev, uint64_t n_, int c_, bool precompute, hipStream_t st) {
+    alloc_rows(n_, c_, precompute);
     if (!n) return;
     k_table_first<F><<<ceil_div(n, 256), 256, 0, st>>>(bases_dev, table.p, valid.p, n);
     CG_KERNEL_CHECK();
-    if (precompute)
-        for (int j = 1; j < W; ++j) {
-            k_table_next<F29T><<<ceil_div(n, 256), 256, 0, st>>>(table.p, valid.p, n, j, c);
-            CG_KERNEL_CHECK();
-        }
+    expand_rows(st);
+}
+
+template <class F>
+void MsmBases<F>::build_from_row0(const uint32_t* row0_dev, const uint8_t* valid_dev, uint64_t n_, int c_, hipStream_t st) {
+    alloc_rows(n_, c_, true);
+    if (!n) return;
+    CG_HIP(hipMemcpyAsync(table.p, row0_dev, n * AFF * 4, hipMemcpyDeviceToDevice, st));
+    CG_HIP(hipMemcpyAsync(valid.p, valid_dev, n, hipMemcpyDeviceToDevice, st));
+    expand_rows(st);
+}
+
+// h query -> coset evaluation basis (ecntt.hip), then the usual window rows over the slice [first, first + count)
+void build_h_bases_coset(MsmBases<Fq>& out, const Affine<Fq>* bases_dev, uint64_t n_in, int logn, uint64_t first, uint64_t count,
+                         int c, hipStream_t st) {
+    constexpr int AFF = MsmBases<Fq>::AFF;
+    const uint64_t n = 1ull << logn;
+    if (first + count > n) throw HipError(CG_ERR_INVALID_ARGUMENT, "h range outside the domain");
+    DevBuf<uint32_t> row0(n_in ? n_in * AFF : 4), row0t(n * AFF);
+    DevBuf<uint8_t> valid(n_in ? n_in : 1), validt(n);
+    if (n_in) {
+        k_table_first<Fq><<<ceil_div(n_in, 256), 256, 0, st>>>(bases_dev, row0.p, valid.p, n_in);
+        CG_KERNEL_CHECK();
+    }
+    ec_transform_h_bases(row0.p, valid.p, n_in, logn, row0t.p, validt.p, st);
+    out.build_from_row0(row0t.p + first * AFF, validt.p + first, count, c, st);
+    CG_HIP(hipStreamSynchronize(st));
 }
 
 template <class F>

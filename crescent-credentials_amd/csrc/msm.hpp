@@ -24,8 +24,12 @@ struct MsmBases {
     DevBuf<uint8_t> valid;     // 1 = base is not the identity
     // bases_dev: n affine points in Montgomery(2^256) form on the device (identity = all zero)
     void build(const Affine<F>* bases_dev, uint64_t n, int c, bool precompute, hipStream_t st);
+    // the same from packed table points (row 0) and their validity flags already on the device
+    void build_from_row0(const uint32_t* row0_dev, const uint8_t* valid_dev, uint64_t n, int c, hipStream_t st);
     // re-expand the same bases (row 0 of the table) for another window size
     void rebuild(int c_new, hipStream_t st);
+    void alloc_rows(uint64_t n, int c, bool precompute);
+    void expand_rows(hipStream_t st);
 };
 
 int msm_default_window(uint64_t n, bool precomputed);
@@ -75,6 +79,20 @@ struct MsmEngine {
     // after the stream has been synchronised: the MSM value (host arithmetic, Montgomery 2^256 form)
     XYZZ<F> value() const;
 };
+
+// The h query in the evaluation basis of the coset (G1 only).  prover.rs:63-66 computes Σ_i h_i·H_i with h the
+// coefficients that the last transform of the witness map (coset ifft, r1cs_to_qap.rs:210) produces from the coset
+// values q_j = ((a∘b − c)/Z)(g·ω^j).  That transform is linear, h_i = (g^-i / n) Σ_j ω^{-ij} q_j, so the same group
+// element is Σ_j q_j·H'_j with
+//     H'_j = Σ_i ω^{-ij} · (g^-i / n) · H_i        (H_i = identity for i >= n_in: the key holds n - 1 points)
+// — an inverse DFT over group elements, done ONCE at load (n/2·log n scalar multiplications by twiddles), after
+// which every proof skips its seventh transform.  in: n_in packed table points + validity; out: n = 2^logn of each.
+void ec_transform_h_bases(const uint32_t* row0_in, const uint8_t* valid_in, uint64_t n_in, int logn, uint32_t* row0_out,
+                          uint8_t* valid_out, hipStream_t st);
+
+// bases_dev: the key's n_in h-query points; out: window tables over transformed points [first, first + count) of 2^logn
+void build_h_bases_coset(MsmBases<Fq>& out, const Affine<Fq>* bases_dev, uint64_t n_in, int logn, uint64_t first, uint64_t count,
+                         int c, hipStream_t st);
 
 // import packed affine points (64 B / 128 B each, `coord_form`) into Montgomery Affine<F> on the device
 template <class F>

@@ -110,6 +110,7 @@ struct cg_ctx {
     uint64_t l = 0, m = 0, M = 0, D = 0;
     int logD = 0;
     int shard_rank = 0, shard_count = 1;
+    bool h_coset_basis = true;   // h query held in the coset evaluation basis: six transforms per proof instead of seven
     // host copies of the single points the finishing step needs (Montgomery)
     G1Affine alpha_g1, beta_g1, delta_g1, a0, b1_0;
     G2Affine beta_g2, delta_g2, b2_0;
@@ -236,10 +237,19 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         c->a0 = g1_import(pk->a_query, form);            // query[0] of calculate_coeff (prover.rs:265)
         c->b1_0 = g1_import(pk->b_g1_query, form);
         c->b2_0 = g2_import(pk->b_g2_query, form);
-        c->rh = shard_range(D - 1, c->shard_rank, c->shard_count);
+        c->h_coset_basis = !(opt && (opt->flags & CG_FLAG_H_COEFFICIENT_BASIS));
+        c->rh = shard_range(c->h_coset_basis ? D : D - 1, c->shard_rank, c->shard_count);
         c->rl = shard_range(M - l, c->shard_rank, c->shard_count);
         c->ra = shard_range(M - 1, c->shard_rank, c->shard_count);
-        load_query<Fq>(c->bh, pk->h_query, form, c->rh.lo, c->rh.hi - c->rh.lo, wb, s0);
+        if (c->h_coset_basis) {
+            // every shard transforms the whole query (the DFT mixes all points) and keeps its own range of the result
+            DevBuf<G1Affine> tmp(D);
+            import_bases<Fq>(pk->h_query, form, D - 1, tmp.p, s0);
+            const uint64_t cnt = c->rh.hi - c->rh.lo;
+            build_h_bases_coset(c->bh, tmp.p, D - 1, logD, c->rh.lo, cnt, wb > 0 ? wb : msm_default_window(cnt ? cnt : 1, true), s0);
+        } else {
+            load_query<Fq>(c->bh, pk->h_query, form, c->rh.lo, c->rh.hi - c->rh.lo, wb, s0);
+        }
         load_query<Fq>(c->bl, pk->l_query, form, c->rl.lo, c->rl.hi - c->rl.lo, wb, s0);
         load_query<Fq>(c->ba, pk->a_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, s0);    // query[1..] (prover.rs:266)
         load_query<Fq>(c->bb1, pk->b_g1_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, s0);
@@ -288,8 +298,8 @@ extern "C" void cg_circuit_free(cg_ctx* ctx) {
 // witness map on stream st: w_mont must be ready; result h (canonical, natural order) in c->h_canon
 // (LibsnarkReduction::witness_map_from_matrices, r1cs_to_qap.rs:150-213)
 // ---------------------------------------------------------------------------------------------
-static void run_witness_map(cg_ctx* c, ProofSlot* S, const Fr* w_canon_dev, hipStream_t st) {
-    wm29_run(c->wdom, c->A, c->B, c->C, c->dA, c->dB, c->dC, S->wm, w_canon_dev, c->M, c->m, c->l, S->h_canon.p, st);
+static void run_witness_map(cg_ctx* c, ProofSlot* S, const Fr* w_canon_dev, hipStream_t st, bool coset_values) {
+    wm29_run(c->wdom, c->A, c->B, c->C, c->dA, c->dB, c->dC, S->wm, w_canon_dev, c->M, c->m, c->l, S->h_canon.p, st, coset_values);
 }
 
 struct Partials {
@@ -330,7 +340,7 @@ static int prove_partial_impl(cg_ctx* c, ProofSlot* S, const void* assignment, b
     S->eb2.digits(w_dev + 1 + c->ra.lo, c->ra.hi - c->ra.lo, S->st[4]);
     // witness map, then h digits, on stream 0
     if (tm) CG_HIP(hipEventRecord(S->ev_t[0], s0));
-    run_witness_map(c, S, w_dev, s0);
+    run_witness_map(c, S, w_dev, s0, c->h_coset_basis);   // h_canon: coefficients of h, or its coset values for a transformed h query
     if (tm) CG_HIP(hipEventRecord(S->ev_t[1], s0));
     S->eh.digits(S->h_canon.p + c->rh.lo, c->rh.hi - c->rh.lo, s0);
     // second phase (each waits for its own entry count)
@@ -545,7 +555,7 @@ extern "C" int cg_witness_map(cg_ctx* ctx, const uint8_t* full_assignment, uint8
         ProofSlot* S = g.s;
         hipStream_t s0 = S->st[0];
         CG_HIP(hipMemcpyAsync(S->w_canon.p, full_assignment, ctx->M * 32, hipMemcpyHostToDevice, s0));
-        run_witness_map(ctx, S, S->w_canon.p, s0);
+        run_witness_map(ctx, S, S->w_canon.p, s0, false);   // the reference's result: coefficients
         CG_HIP(hipMemcpyAsync(h_out, S->h_canon.p, ctx->D * 32, hipMemcpyDeviceToHost, s0));
         CG_HIP(hipStreamSynchronize(s0));
         if (S->wm.h_bad_input.p[0]) return fail(CG_ERR_INVALID_ARGUMENT, "full_assignment holds a value >= the scalar field modulus");

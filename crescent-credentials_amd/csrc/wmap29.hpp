@@ -21,6 +21,7 @@ struct Wm29Domain {
     DevBuf<uint32_t> coset;      // g^i / n   at natural index i, R' form      (r1cs_to_qap.rs:182-185 + the 1/n of :179-180)
     DevBuf<uint32_t> icoset;     // g^-i / n  at natural index i, PLAIN form (multiplying by it also leaves Montgomery form)
     uint32_t vinv[8];            // (g^n - 1)^-1, R' form (host copy; passed by value to the kernel)
+    uint32_t vinv_plain[8];      // the same as a plain integer
     void build(const NttDomain& d, hipStream_t st);
 };
 
@@ -57,9 +58,11 @@ struct Ntt29Unit {
     bool run(Fr* data_dev, bool inverse, bool coset, hipStream_t st);
 };
 
-// w_canon: M canonical scalars on the device.  h_out: D canonical scalars (natural order), on the device.
+// w_canon: M canonical scalars on the device.  h_out: D canonical scalars (natural order), on the device:
+// the coefficients of h (coset_values = false: the reference's result, seven transforms), or the values of the
+// quotient on the coset, q_j = h(g·ω^j) (coset_values = true: six transforms; for an h query held in that basis).
 void wm29_run(const Wm29Domain& dom, const DevCsr& A, const DevCsr& B, const DevCsr& C, const Csr29& dA, const Csr29& dB,
               const Csr29& dC, Wm29Buffers& buf, const Fr* w_canon, uint64_t M, uint64_t m, uint64_t l, Fr* h_out,
-              hipStream_t st);
+              hipStream_t st, bool coset_values);
 
 }  // namespace cg

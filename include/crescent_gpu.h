@@ -92,8 +92,15 @@ typedef struct cg_options {
     int32_t shard_count;   /* ... of shard_count; 0 or 1 = unsharded */
     int32_t proof_slots;   /* proofs that may be in flight on this context at once (each has its own working
                               set and streams; cg_prove* from different threads overlap on the GPU); 0 = 1 */
-    int32_t reserved[3];
+    int32_t flags;         /* CG_FLAG_* */
+    int32_t reserved[2];
 } cg_options;
+
+/* By default cg_circuit_load moves the h query into the evaluation basis of the coset (one inverse DFT over its
+ * G1 points, ~1 s at 2^21) so that a proof needs six transforms instead of seven: Σ h_i·H_i of prover.rs:63-66 is
+ * computed as Σ q_j·H'_j over the quotient's coset values q_j — the same group element, hence the same proof bytes.
+ * This flag keeps the query as loaded and runs the reference's seventh transform (r1cs_to_qap.rs:210) per proof. */
+enum { CG_FLAG_H_COEFFICIENT_BASIS = 1 };
 
 /* Per-phase wall/GPU times of one cg_prove call, mirroring the reference's `print-trace` phases
  * (forks/groth16/src/prover.rs:35-36,62,93,103,115,123). Milliseconds. */

@@ -4,6 +4,7 @@ use std::os::raw::{c_char, c_int, c_void};
 
 pub const CG_FORM_CANONICAL: u32 = 0;
 pub const CG_FORM_MONTGOMERY: u32 = 1;
+pub const CG_FLAG_H_COEFFICIENT_BASIS: i32 = 1;
 pub const CG_ERR_POLY_DEGREE_TOO_LARGE: c_int = -5;
 pub const CG_ERR_MALFORMED_KEY: c_int = -6;
 
@@ -43,7 +44,8 @@ pub struct cg_options {
     pub shard_rank: i32,
     pub shard_count: i32,
     pub proof_slots: i32,
-    pub reserved: [i32; 3],
+    pub flags: i32,
+    pub reserved: [i32; 2],
 }
 
 #[repr(C)]

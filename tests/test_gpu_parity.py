@@ -306,19 +306,24 @@ def test_prove_golden(cc, oracle, name):
         t = g["trapdoor"]
         pk = cc.generate_parameters_with_qap(cm, int(t["alpha"], 16), int(t["beta"], 16), int(t["delta"], 16), int(t["tau"], 16))
     w = _scalars([int(x, 16) for x in g["witness"]])
-    prover = cc.Prover(pk, cm)
+    # default: h query moved to the coset evaluation basis at load (six transforms per proof); and the reference's own
+    # arrangement (coefficient basis, seven transforms)
+    for coeff_basis in (False, True):
+        prover = cc.Prover(pk, cm, h_coefficient_basis=coeff_basis)
+        try:
+            assert prover.domain_size == g["domain_size"]
+            h = prover.witness_map(w)
+            assert _sha(h) == g["h_sha256"]
+            for case in g["proofs"]:
+                r, s = int(case["r"], 16), int(case["s"], 16)
+                assert prover.prove(w, r, s).serialize_uncompressed().hex() == case["proof"], coeff_basis
+        finally:
+            prover.close()
     try:
-        assert prover.domain_size == g["domain_size"]
-        h = prover.witness_map(w)
-        assert _sha(h) == g["h_sha256"]
-        for case in g["proofs"]:
-            r, s = int(case["r"], 16), int(case["s"], 16)
-            assert prover.prove(w, r, s).serialize_uncompressed().hex() == case["proof"]
         # reference call shape
         p = cc.Groth16.create_proof_with_reduction_and_matrices(pk, r, s, cm, g["num_inputs"], g["num_constraints"], w)
         assert p.data.hex() == case["proof"]
     finally:
-        prover.close()
         cc.Groth16.clear_cache()
 
 
@@ -351,7 +356,7 @@ def test_prove_edge_shapes(cc, oracle, l, m, M):
     pk_gpu = cc.generate_parameters_with_qap(cm, trap[1], trap[2], trap[3], trap[0])
     pk = _pk_from_oracle(cc, oracle, pk_o)
     assert _pk_digest(pk_gpu) == _pk_digest(pk)                       # cg_setup on the same degenerate shape
-    prover = cc.Prover(pk, cm)
+    prover = cc.Prover(pk, cm, h_coefficient_basis=(M % 2 == 0))
     try:
         for wit in ("random", "zeros", "max"):
             if wit == "random":
@@ -455,7 +460,7 @@ def test_prove_equals_cpu_restatement(cc, oracle, shape, bit_fraction):
     rng = random.Random(11)
     tau, alpha, beta, delta = (rng.randrange(1, oracle.R) for _ in range(4))
     pk = cc.generate_parameters_with_qap(cm, alpha, beta, delta, tau)
-    prover = cc.Prover(pk, cm, proof_slots=2)
+    prover = cc.Prover(pk, cm, proof_slots=2, h_coefficient_basis=(shape == "log13"))
     try:
         assert bytes(prover.witness_map(w)) == bytes(cpu_ref.witness_map((cm.a, cm.b, cm.c), l, m, M, w, nthreads=8))
         for r, s in ((0, 0), (rng.randrange(oracle.R), rng.randrange(oracle.R))):
