@@ -34,7 +34,7 @@ __device__ void smul_xyzz(XYZZ29<FB>& acc, bool& inf, const XYZZ29<FB>& v, const
     }
 }
 
-// slot[rev(i)] = (g^-i / n) · H_i      (identity for i >= n_in or an identity base)
+// slot[rev(i)] = scale_i · H_i      (identity for i >= n_in or an identity base)
 __global__ void __launch_bounds__(256) k_ec_load_scale(const uint32_t* __restrict__ row0, const uint8_t* __restrict__ valid,
                                                        uint64_t n_in, uint64_t n, int logn, const Fr* __restrict__ scale_mont,
                                                        uint32_t* __restrict__ slots) {
@@ -109,14 +109,13 @@ __global__ void __launch_bounds__(256) k_ec_store(const uint32_t* __restrict__ s
     valid[j] = inf ? 0 : 1;
 }
 
-void ec_transform_h_bases(const uint32_t* row0_in, const uint8_t* valid_in, uint64_t n_in, int logn, uint32_t* row0_out,
-                          uint8_t* valid_out, hipStream_t st) {
+void ec_inverse_dft(const uint32_t* row0_in, const uint8_t* valid_in, uint64_t n_in, int logn, const Fr& scale_base,
+                    const Fr& scale_mult, uint32_t* row0_out, uint8_t* valid_out, hipStream_t st) {
     const uint64_t n = 1ull << logn;
     if (n_in > n) throw HipError(CG_ERR_INVALID_ARGUMENT, "h query longer than the domain");
-    const Fr g = fr_from_u64(5);                               // F::GENERATOR (r1cs_to_qap.rs:182,202)
     const Fr w = fr_root_of_unity(logn);
     DevBuf<Fr> scale(n), tw(n > 1 ? n / 2 : 1);
-    fr_pow_table(scale.p, inv(g), inv(fr_from_u64(n)), n, false, logn, st);          // g^-i / n
+    fr_pow_table(scale.p, scale_base, scale_mult, n, false, logn, st);                // mult · base^i
     fr_pow_table(tw.p, inv(w), Fr::one(), n > 1 ? n / 2 : 1, false, logn, st);        // ω^-e
     DevBuf<uint32_t> slots(n * ACC1);
     k_ec_load_scale<<<ceil_div(n, 256), 256, 0, st>>>(row0_in, valid_in, n_in, n, logn, scale.p, slots.p);
@@ -128,6 +127,100 @@ void ec_transform_h_bases(const uint32_t* row0_in, const uint8_t* valid_in, uint
     k_ec_store<<<ceil_div(n, 256), 256, 0, st>>>(slots.p, n, row0_out, valid_out);
     CG_KERNEL_CHECK();
     CG_HIP(hipStreamSynchronize(st));     // the temporaries are released on return
+}
+
+void ec_transform_h_bases(const uint32_t* row0_in, const uint8_t* valid_in, uint64_t n_in, int logn, uint32_t* row0_out,
+                          uint8_t* valid_out, hipStream_t st) {
+    const Fr g = fr_from_u64(5);                               // F::GENERATOR (r1cs_to_qap.rs:182,202)
+    ec_inverse_dft(row0_in, valid_in, n_in, logn, inv(g), inv(fr_from_u64(1ull << logn)), row0_out, valid_out, st);   // g^-i / n
+}
+
+// ---- the C matrix folded into the l query ----------------------------------------------------------------------------
+// term t of C^T (wire k = key[t], constraint j = col[t], coefficient c):  c · G'_j
+__global__ void __launch_bounds__(256) k_ec_terms(const uint32_t* __restrict__ col, const uint32_t* __restrict__ cidx,
+                                                  const Fr* __restrict__ dict_mont, uint64_t nnz, const uint32_t* __restrict__ g_row0,
+                                                  const uint8_t* __restrict__ g_valid, uint32_t* __restrict__ pts) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nnz) return;
+    const uint32_t j = col[t];
+    XYZZ29<FB> acc;
+    bool inf = true;
+    if (g_valid[j]) {
+        const Affine29<FB> p = load_table_point<FB>(g_row0, j, false);
+        const uint32_t ci = cidx[t];
+        if (ci == 0) {                       // the literal one
+            madd29(acc, inf, p);
+        } else {
+            const Fr k = from_mont(dict_mont[ci]);
+            bool started = false;
+            for (int w = 7; w >= 0; --w) {
+                const uint32_t kw = k.l[w];
+                if (!started && kw == 0) continue;
+                for (int b = 31; b >= 0; --b) {
+                    if (started && !inf) acc = dbl29(acc);
+                    if ((kw >> b) & 1u) {
+                        madd29(acc, inf, p);
+                        started = true;
+                    }
+                }
+            }
+        }
+    }
+    store_acc(pts + t * ACC1, acc, inf);
+}
+
+// new l base k = P_k (+ l_query[k − num_inputs] for a witness wire), as a packed table point
+__global__ void __launch_bounds__(256) k_ec_fold_l(const uint32_t* __restrict__ p_sums, const uint32_t* __restrict__ l_row0,
+                                                   const uint8_t* __restrict__ l_valid, uint64_t num_inputs, uint64_t M,
+                                                   uint32_t* __restrict__ row0, uint8_t* __restrict__ valid) {
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= M) return;
+    XYZZ29<FB> acc;
+    bool inf = load_acc(p_sums + k * ACC1, acc);
+    if (k >= num_inputs && l_valid[k - num_inputs]) madd29(acc, inf, load_table_point<FB>(l_row0, (uint32_t)(k - num_inputs), false));
+    uint32_t w[AFF1];
+    if (inf) {
+#pragma unroll
+        for (int i = 0; i < AFF1; ++i) w[i] = 0;
+    } else {
+        store_table_point_from_xyzz(acc, w);
+    }
+    uint4* dst = reinterpret_cast<uint4*>(row0 + k * AFF1);
+#pragma unroll
+    for (int i = 0; i < AFF1 / 4; ++i) dst[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+    valid[k] = inf ? 0 : 1;
+}
+
+void ec_fold_c_into_l(const uint32_t* h_row0, const uint8_t* h_valid, uint64_t n_h, int logn, const Fr& vanishing_inv,
+                      const cg_csr& c_matrix, uint64_t num_constraints, uint64_t num_inputs, uint64_t M,
+                      const uint32_t* l_row0, const uint8_t* l_valid, uint32_t* row0_out, uint8_t* valid_out, hipStream_t st) {
+    const uint64_t n = 1ull << logn;
+    // G'_j = −vinv/n · Σ_i ω^{-ij} H_i : the h query in the Lagrange basis of the domain, times −1/Z(g)
+    DevBuf<uint32_t> g_row0(n * AFF1);
+    DevBuf<uint8_t> g_valid(n);
+    ec_inverse_dft(h_row0, h_valid, n_h, logn, Fr::one(), neg(mul(vanishing_inv, inv(fr_from_u64(n)))), g_row0.p, g_valid.p, st);
+    // P_k = Σ_j C_jk · G'_j : the terms of C^T, summed per wire
+    DevBuf<uint32_t> p_sums(M * ACC1);
+    fill_zero(p_sums.p, p_sums.bytes(), st);
+    const uint64_t nnz = c_matrix.nnz;
+    if (nnz && num_constraints) {
+        HostCsc t;
+        csr_transpose(c_matrix, num_constraints, M, t);
+        DevCsr ct;
+        ct.upload(t.view, M, num_constraints);
+        std::vector<uint32_t> keys_h(nnz);
+        for (uint64_t k = 0; k < M; ++k)
+            for (uint64_t e = t.ptr[k]; e < t.ptr[k + 1]; ++e) keys_h[e] = (uint32_t)k;
+        DevBuf<uint32_t> keys(nnz), pts(nnz * ACC1);
+        CG_HIP(hipMemcpyAsync(keys.p, keys_h.data(), nnz * 4, hipMemcpyHostToDevice, st));
+        k_ec_terms<<<ceil_div(nnz, 256), 256, 0, st>>>(ct.col.p, ct.coef_idx.p, ct.dict.p, nnz, g_row0.p, g_valid.p, pts.p);
+        CG_KERNEL_CHECK();
+        sum_xyzz_by_key(keys.p, pts.p, nnz, p_sums.p, st);
+        CG_HIP(hipStreamSynchronize(st));    // keys_h, ct and the device temporaries above outlive the kernels
+    }
+    k_ec_fold_l<<<ceil_div(M, 256), 256, 0, st>>>(p_sums.p, l_row0, l_valid, num_inputs, M, row0_out, valid_out);
+    CG_KERNEL_CHECK();
+    CG_HIP(hipStreamSynchronize(st));
 }
 
 }  // namespace cg

@@ -180,23 +180,6 @@ void MsmBases<F>::build_from_row0(const uint32_t* row0_dev, const uint8_t* valid
     expand_rows(st);
 }
 
-// h query -> coset evaluation basis (ecntt.hip), then the usual window rows over the slice [first, first + count)
-void build_h_bases_coset(MsmBases<Fq>& out, const Affine<Fq>* bases_dev, uint64_t n_in, int logn, uint64_t first, uint64_t count,
-                         int c, hipStream_t st) {
-    constexpr int AFF = MsmBases<Fq>::AFF;
-    const uint64_t n = 1ull << logn;
-    if (first + count > n) throw HipError(CG_ERR_INVALID_ARGUMENT, "h range outside the domain");
-    DevBuf<uint32_t> row0(n_in ? n_in * AFF : 4), row0t(n * AFF);
-    DevBuf<uint8_t> valid(n_in ? n_in : 1), validt(n);
-    if (n_in) {
-        k_table_first<Fq><<<ceil_div(n_in, 256), 256, 0, st>>>(bases_dev, row0.p, valid.p, n_in);
-        CG_KERNEL_CHECK();
-    }
-    ec_transform_h_bases(row0.p, valid.p, n_in, logn, row0t.p, validt.p, st);
-    out.build_from_row0(row0t.p + first * AFF, validt.p + first, count, c, st);
-    CG_HIP(hipStreamSynchronize(st));
-}
-
 template <class F>
 void MsmBases<F>::rebuild(int c_new, hipStream_t st) {
     if (!precomputed || c_new == c || !n) return;
@@ -762,6 +745,62 @@ XYZZ<F> MsmEngine<F>::value() const {
         add(acc, window_value<F>(h_result.p + (size_t)j * 2 * ACC, ACC, cbits));
     }
     return acc;
+}
+
+// Σ of XYZZ accumulators per key (keys sorted ascending), added into sums[key]: the partial-combining levels of the
+// bucket accumulation (k_accum_xyzz) run on their own
+void sum_xyzz_by_key(const uint32_t* keys, const uint32_t* pts, uint64_t count, uint32_t* sums, hipStream_t st) {
+    typedef Fq29 F29T;
+    constexpr int ACC = Words29<F29T>::ACC;
+    if (!count) return;
+    const uint64_t pa = 2 * ceil_div(count, ACC_LEVEL_L), pb = 2 * ceil_div(pa, ACC_LEVEL_L);
+    DevBuf<uint32_t> ka(pa), kb(pb), qa(pa * ACC), qb(pb * ACC);
+    const uint32_t* ik = keys;
+    const uint32_t* ip = pts;
+    bool to_a = true;
+    uint32_t cnt = (uint32_t)count;
+    while (cnt) {
+        const uint32_t Tk = ceil_div(cnt, ACC_LEVEL_L);
+        uint32_t* ok = to_a ? ka.p : kb.p;
+        uint32_t* op = to_a ? qa.p : qb.p;
+        k_accum_xyzz<F29T><<<ceil_div(Tk, 256), 256, 0, st>>>(ik, ip, cnt, ACC_LEVEL_L, Tk, sums, ok, op);
+        CG_KERNEL_CHECK();
+        cnt = (Tk == 1) ? 0 : 2 * Tk;
+        ik = ok;
+        ip = op;
+        to_a = !to_a;
+    }
+    CG_HIP(hipStreamSynchronize(st));
+}
+
+// h query -> coset evaluation basis, C matrix -> l query (ecntt.hip), then the usual window rows over each slice
+void build_hl_bases_folded(MsmBases<Fq>& out_h, MsmBases<Fq>& out_l, const Affine<Fq>* h_bases_dev, uint64_t n_h, int logn,
+                           const Affine<Fq>* l_bases_dev, uint64_t num_inputs, uint64_t M, const cg_csr& c_matrix,
+                           uint64_t num_constraints, const Fr& vanishing_inv, uint64_t h_first, uint64_t h_count, int c_h,
+                           uint64_t l_first, uint64_t l_count, int c_l, hipStream_t st) {
+    constexpr int AFF = MsmBases<Fq>::AFF;
+    const uint64_t n = 1ull << logn, n_l = M - num_inputs;
+    if (h_first + h_count > n || l_first + l_count > M) throw HipError(CG_ERR_INVALID_ARGUMENT, "range outside the query");
+    DevBuf<uint32_t> h_row0(n_h ? n_h * AFF : 4), l_row0(n_l ? n_l * AFF : 4);
+    DevBuf<uint8_t> h_valid(n_h ? n_h : 1), l_valid(n_l ? n_l : 1);
+    if (n_h) k_table_first<Fq><<<ceil_div(n_h, 256), 256, 0, st>>>(h_bases_dev, h_row0.p, h_valid.p, n_h);
+    if (n_l) k_table_first<Fq><<<ceil_div(n_l, 256), 256, 0, st>>>(l_bases_dev, l_row0.p, l_valid.p, n_l);
+    CG_KERNEL_CHECK();
+    {
+        DevBuf<uint32_t> row0t(n * AFF);
+        DevBuf<uint8_t> validt(n);
+        ec_transform_h_bases(h_row0.p, h_valid.p, n_h, logn, row0t.p, validt.p, st);
+        out_h.build_from_row0(row0t.p + h_first * AFF, validt.p + h_first, h_count, c_h, st);
+        CG_HIP(hipStreamSynchronize(st));
+    }
+    {
+        DevBuf<uint32_t> row0f(M * AFF);
+        DevBuf<uint8_t> validf(M);
+        ec_fold_c_into_l(h_row0.p, h_valid.p, n_h, logn, vanishing_inv, c_matrix, num_constraints, num_inputs, M, l_row0.p, l_valid.p,
+                         row0f.p, validf.p, st);
+        out_l.build_from_row0(row0f.p + l_first * AFF, validf.p + l_first, l_count, c_l, st);
+        CG_HIP(hipStreamSynchronize(st));
+    }
 }
 
 template struct MsmBases<Fq>;

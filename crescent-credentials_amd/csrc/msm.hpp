@@ -4,6 +4,7 @@
 #pragma once
 #include "common.hpp"
 #include "curve29.cuh"
+#include "ntt.hpp"
 
 namespace cg {
 
@@ -80,19 +81,34 @@ struct MsmEngine {
     XYZZ<F> value() const;
 };
 
-// The h query in the evaluation basis of the coset (G1 only).  prover.rs:63-66 computes Σ_i h_i·H_i with h the
-// coefficients that the last transform of the witness map (coset ifft, r1cs_to_qap.rs:210) produces from the coset
-// values q_j = ((a∘b − c)/Z)(g·ω^j).  That transform is linear, h_i = (g^-i / n) Σ_j ω^{-ij} q_j, so the same group
-// element is Σ_j q_j·H'_j with
-//     H'_j = Σ_i ω^{-ij} · (g^-i / n) · H_i        (H_i = identity for i >= n_in: the key holds n - 1 points)
-// — an inverse DFT over group elements, done ONCE at load (n/2·log n scalar multiplications by twiddles), after
-// which every proof skips its seventh transform.  in: n_in packed table points + validity; out: n = 2^logn of each.
+// Two changes of basis made ONCE per key so that a proof needs four transforms instead of seven (G1 only).
+//
+// prover.rs:63-66 computes h_acc = Σ_i h_i·H_i with h = coset_ifft(((a∘b − c)/Z) on the coset) (r1cs_to_qap.rs:187-210).
+// Z is the constant 1/vinv on the coset and coset_ifft is linear, so h = coset_ifft(vinv·a∘b) − vinv·coeffs(c), and
+//   (1) Σ_i coset_ifft(q)_i·H_i = Σ_j q_j·H'_j,  H'_j = Σ_i ω^{-ij}·(g^-i / n)·H_i   (H_i = identity for i >= n_h: the key
+//       holds n − 1 points) — the h query in the evaluation basis of the coset (ec_transform_h_bases): the coset values
+//       q_j = vinv·a_j·b_j are the MSM's scalars and the seventh transform disappears;
+//   (2) −vinv·Σ_i coeffs(c)_i·H_i = Σ_j c_j·G'_j with c_j = <C_j, w> and G'_j = −(vinv / n)·Σ_i ω^{-ij}·H_i, which is
+//       Σ_k w_k·P_k,  P_k = Σ_j C_jk·G'_j: the C matrix folded into per-wire points that are simply added to the l query
+//       (ec_fold_c_into_l) — the sparse product with C and both of c's transforms disappear.  The folded l query has one
+//       base per wire (the ℓ instance wires included) and takes the full assignment as its scalars.
+// Every step is an identity between group elements, so the proof bytes are unchanged for ANY assignment, satisfying
+// or not.  Both are inverse DFTs over group elements (n/2·log n scalar multiplications by twiddles each, ≈1 s at 2^21).
+void ec_inverse_dft(const uint32_t* row0_in, const uint8_t* valid_in, uint64_t n_in, int logn, const Fr& scale_base,
+                    const Fr& scale_mult, uint32_t* row0_out, uint8_t* valid_out, hipStream_t st);
 void ec_transform_h_bases(const uint32_t* row0_in, const uint8_t* valid_in, uint64_t n_in, int logn, uint32_t* row0_out,
                           uint8_t* valid_out, hipStream_t st);
-
-// bases_dev: the key's n_in h-query points; out: window tables over transformed points [first, first + count) of 2^logn
-void build_h_bases_coset(MsmBases<Fq>& out, const Affine<Fq>* bases_dev, uint64_t n_in, int logn, uint64_t first, uint64_t count,
-                         int c, hipStream_t st);
+// row0_out / valid_out: M packed table points: P_k for k < num_inputs, l_query[k − num_inputs] + P_k above
+void ec_fold_c_into_l(const uint32_t* h_row0, const uint8_t* h_valid, uint64_t n_h, int logn, const Fr& vanishing_inv,
+                      const cg_csr& c_matrix, uint64_t num_constraints, uint64_t num_inputs, uint64_t M,
+                      const uint32_t* l_row0, const uint8_t* l_valid, uint32_t* row0_out, uint8_t* valid_out, hipStream_t st);
+void sum_xyzz_by_key(const uint32_t* keys, const uint32_t* pts, uint64_t count, uint32_t* sums, hipStream_t st);
+// window tables of the transformed h query over [h_first, h_first + h_count) of 2^logn and of the folded l query over
+// [l_first, l_first + l_count) of M
+void build_hl_bases_folded(MsmBases<Fq>& out_h, MsmBases<Fq>& out_l, const Affine<Fq>* h_bases_dev, uint64_t n_h, int logn,
+                           const Affine<Fq>* l_bases_dev, uint64_t num_inputs, uint64_t M, const cg_csr& c_matrix,
+                           uint64_t num_constraints, const Fr& vanishing_inv, uint64_t h_first, uint64_t h_count, int c_h,
+                           uint64_t l_first, uint64_t l_count, int c_l, hipStream_t st);
 
 // import packed affine points (64 B / 128 B each, `coord_form`) into Montgomery Affine<F> on the device
 template <class F>

@@ -112,6 +112,29 @@ void NttDomain::build(int logn_, bool with_coset, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------
 // sparse matrix-vector product (evaluate_constraint, r1cs_to_qap.rs:16-45)
 // ---------------------------------------------------------------------------------------------
+void csr_transpose(const cg_csr& m, uint64_t rows, uint64_t cols, HostCsc& out) {
+    out.ptr.assign(cols + 1, 0);
+    for (uint64_t t = 0; t < m.nnz; ++t) {
+        if (m.col[t] >= cols) throw HipError(CG_ERR_INVALID_ARGUMENT, "column index out of range");
+        out.ptr[m.col[t] + 1]++;
+    }
+    for (uint64_t j = 0; j < cols; ++j) out.ptr[j + 1] += out.ptr[j];
+    out.row.resize(m.nnz ? m.nnz : 1);
+    out.coeff.resize((m.nnz ? m.nnz : 1) * 32);
+    std::vector<uint64_t> cur(out.ptr.begin(), out.ptr.end() - 1);
+    for (uint64_t i = 0; i < rows; ++i)
+        for (uint64_t t = m.row_ptr[i]; t < m.row_ptr[i + 1]; ++t) {
+            uint64_t pos = cur[m.col[t]]++;
+            out.row[pos] = (uint32_t)i;
+            memcpy(&out.coeff[pos * 32], m.coeff + 32 * t, 32);
+        }
+    out.view.row_ptr = out.ptr.data();
+    out.view.col = out.row.data();
+    out.view.coeff = out.coeff.data();
+    out.view.nnz = m.nnz;
+}
+
+
 void DevCsr::upload(const cg_csr& m, uint64_t rows_, uint64_t num_variables) {
     rows = rows_;
     nnz = m.nnz;

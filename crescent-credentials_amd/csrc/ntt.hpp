@@ -35,6 +35,15 @@ struct DevCsr {
     DevBuf<Fr> dict;            // Montgomery
     void upload(const cg_csr& m, uint64_t rows, uint64_t num_variables);
 };
+// host-side transpose of a CSR view (rows x cols): CSR of the transpose, terms of one column kept in row order
+struct HostCsc {
+    std::vector<uint64_t> ptr;
+    std::vector<uint32_t> row;
+    std::vector<uint8_t> coeff;
+    cg_csr view;
+};
+void csr_transpose(const cg_csr& m, uint64_t rows, uint64_t cols, HostCsc& out);
+
 // out[i] = <M_i, w> for i < rows (w Montgomery), rows..n_out zero-filled except the caller's patch
 void spmv(const DevCsr& m, const Fr* w, Fr* out, hipStream_t st);
 

@@ -110,7 +110,9 @@ struct cg_ctx {
     uint64_t l = 0, m = 0, M = 0, D = 0;
     int logD = 0;
     int shard_rank = 0, shard_count = 1;
-    bool h_coset_basis = true;   // h query held in the coset evaluation basis: six transforms per proof instead of seven
+    // h query held in the coset evaluation basis and the C matrix folded into the l query (msm.hpp): four transforms
+    // per proof instead of seven, no sparse product with C; false = the reference's arrangement
+    bool folded = true;
     // host copies of the single points the finishing step needs (Montgomery)
     G1Affine alpha_g1, beta_g1, delta_g1, a0, b1_0;
     G2Affine beta_g2, delta_g2, b2_0;
@@ -237,27 +239,31 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         c->a0 = g1_import(pk->a_query, form);            // query[0] of calculate_coeff (prover.rs:265)
         c->b1_0 = g1_import(pk->b_g1_query, form);
         c->b2_0 = g2_import(pk->b_g2_query, form);
-        c->h_coset_basis = !(opt && (opt->flags & CG_FLAG_H_COEFFICIENT_BASIS));
-        c->rh = shard_range(c->h_coset_basis ? D : D - 1, c->shard_rank, c->shard_count);
-        c->rl = shard_range(M - l, c->shard_rank, c->shard_count);
+        c->folded = !(opt && (opt->flags & CG_FLAG_H_COEFFICIENT_BASIS));
+        c->rh = shard_range(c->folded ? D : D - 1, c->shard_rank, c->shard_count);
+        c->rl = shard_range(c->folded ? M : M - l, c->shard_rank, c->shard_count);
         c->ra = shard_range(M - 1, c->shard_rank, c->shard_count);
-        if (c->h_coset_basis) {
-            // every shard transforms the whole query (the DFT mixes all points) and keeps its own range of the result
-            DevBuf<G1Affine> tmp(D);
-            import_bases<Fq>(pk->h_query, form, D - 1, tmp.p, s0);
-            const uint64_t cnt = c->rh.hi - c->rh.lo;
-            build_h_bases_coset(c->bh, tmp.p, D - 1, logD, c->rh.lo, cnt, wb > 0 ? wb : msm_default_window(cnt ? cnt : 1, true), s0);
-        } else {
-            load_query<Fq>(c->bh, pk->h_query, form, c->rh.lo, c->rh.hi - c->rh.lo, wb, s0);
-        }
-        load_query<Fq>(c->bl, pk->l_query, form, c->rl.lo, c->rl.hi - c->rl.lo, wb, s0);
-        load_query<Fq>(c->ba, pk->a_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, s0);    // query[1..] (prover.rs:266)
-        load_query<Fq>(c->bb1, pk->b_g1_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, s0);
-        load_query<Fq2>(c->bb2, pk->b_g2_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, s0);
-        c->A.upload(abc[0], m, M);
+        c->A.upload(abc[0], m, M);     // validates the CSR views (monotone row_ptr, column range, canonical coefficients)
         c->B.upload(abc[1], m, M);
         c->C.upload(abc[2], m, M);
         c->dom.build(logD, true, s0);
+        CG_HIP(hipStreamSynchronize(s0));
+        if (c->folded) {
+            // every shard transforms the whole queries (the DFT mixes all points) and keeps its own ranges of the results
+            DevBuf<G1Affine> th(D), tl(M - l ? M - l : 1);
+            import_bases<Fq>(pk->h_query, form, D - 1, th.p, s0);
+            import_bases<Fq>(pk->l_query, form, M - l, tl.p, s0);
+            const uint64_t nh = c->rh.hi - c->rh.lo, nl = c->rl.hi - c->rl.lo;
+            build_hl_bases_folded(c->bh, c->bl, th.p, D - 1, logD, tl.p, l, M, abc[2], m, c->dom.vanishing_inv, c->rh.lo, nh,
+                                  wb > 0 ? wb : msm_default_window(nh ? nh : 1, true), c->rl.lo, nl,
+                                  wb > 0 ? wb : msm_default_window(nl ? nl : 1, true), s0);
+        } else {
+            load_query<Fq>(c->bh, pk->h_query, form, c->rh.lo, c->rh.hi - c->rh.lo, wb, s0);
+            load_query<Fq>(c->bl, pk->l_query, form, c->rl.lo, c->rl.hi - c->rl.lo, wb, s0);
+        }
+        load_query<Fq>(c->ba, pk->a_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, s0);    // query[1..] (prover.rs:266)
+        load_query<Fq>(c->bb1, pk->b_g1_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, s0);
+        load_query<Fq2>(c->bb2, pk->b_g2_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, s0);
         c->wdom.build(c->dom, s0);
         c->dA.build(c->A, s0); c->dB.build(c->B, s0); c->dC.build(c->C, s0);
         CG_HIP(hipStreamSynchronize(s0));
@@ -334,13 +340,13 @@ static int prove_partial_impl(cg_ctx* c, ProofSlot* S, const void* assignment, b
     for (int i = 1; i < 5; ++i) CG_HIP(hipStreamWaitEvent(S->st[i], S->ev_w, 0));
     // assignment-driven MSMs: operands (prover.rs:70-74, 84-89, 265-266)
     //   l: l_query[i] x w[l + i];  a, b1, b2: query[1 + i] x w[1 + i]
-    S->el.digits(w_dev + l + c->rl.lo, c->rl.hi - c->rl.lo, S->st[1]);
+    S->el.digits(w_dev + (c->folded ? 0 : l) + c->rl.lo, c->rl.hi - c->rl.lo, S->st[1]);   // folded l query: one base per wire
     S->ea.digits(w_dev + 1 + c->ra.lo, c->ra.hi - c->ra.lo, S->st[2]);
     if (!skip_b1) S->eb1.digits(w_dev + 1 + c->ra.lo, c->ra.hi - c->ra.lo, S->st[3]);
     S->eb2.digits(w_dev + 1 + c->ra.lo, c->ra.hi - c->ra.lo, S->st[4]);
     // witness map, then h digits, on stream 0
     if (tm) CG_HIP(hipEventRecord(S->ev_t[0], s0));
-    run_witness_map(c, S, w_dev, s0, c->h_coset_basis);   // h_canon: coefficients of h, or its coset values for a transformed h query
+    run_witness_map(c, S, w_dev, s0, c->folded);   // h_canon: coefficients of h, or the coset values vinv·a·b for a folded key
     if (tm) CG_HIP(hipEventRecord(S->ev_t[1], s0));
     S->eh.digits(S->h_canon.p + c->rh.lo, c->rh.hi - c->rh.lo, s0);
     // second phase (each waits for its own entry count)

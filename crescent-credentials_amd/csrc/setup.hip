@@ -120,35 +120,6 @@ __global__ void __launch_bounds__(256) k_abc_combine(const Fr* a, const Fr* b, c
     out[i] = mul(t, i < l ? ginv : dinv);
 }
 
-// CSR of the transpose
-struct HostCsc {
-    std::vector<uint64_t> ptr;
-    std::vector<uint32_t> row;
-    std::vector<uint8_t> coeff;
-    cg_csr view;
-};
-static void transpose(const cg_csr& m, uint64_t rows, uint64_t cols, HostCsc& out) {
-    out.ptr.assign(cols + 1, 0);
-    for (uint64_t t = 0; t < m.nnz; ++t) {
-        if (m.col[t] >= cols) throw HipError(CG_ERR_INVALID_ARGUMENT, "column index out of range");
-        out.ptr[m.col[t] + 1]++;
-    }
-    for (uint64_t j = 0; j < cols; ++j) out.ptr[j + 1] += out.ptr[j];
-    out.row.resize(m.nnz ? m.nnz : 1);
-    out.coeff.resize((m.nnz ? m.nnz : 1) * 32);
-    std::vector<uint64_t> cur(out.ptr.begin(), out.ptr.end() - 1);
-    for (uint64_t i = 0; i < rows; ++i)
-        for (uint64_t t = m.row_ptr[i]; t < m.row_ptr[i + 1]; ++t) {
-            uint64_t pos = cur[m.col[t]]++;
-            out.row[pos] = (uint32_t)i;
-            memcpy(&out.coeff[pos * 32], m.coeff + 32 * t, 32);
-        }
-    out.view.row_ptr = out.ptr.data();
-    out.view.col = out.row.data();
-    out.view.coeff = out.coeff.data();
-    out.view.nnz = m.nnz;
-}
-
 template <class F>
 static void fixed_base_to_host(const Affine<F>* table, const Fr* scalars_dev, uint64_t n, uint8_t* host_out, hipStream_t st) {
     if (!n) return;
@@ -198,7 +169,7 @@ extern "C" int cg_setup(const cg_csr abc[3], uint64_t num_inputs, uint64_t num_c
             Fr* q[3] = {qa.p, qb.p, qc.p};
             for (int k = 0; k < 3; ++k) {
                 HostCsc t;
-                transpose(abc[k], m, M, t);
+                csr_transpose(abc[k], m, M, t);
                 DevCsr d;
                 d.upload(t.view, M, m);
                 spmv(d, u.p, q[k], st);

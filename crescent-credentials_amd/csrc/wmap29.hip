@@ -210,9 +210,9 @@ __device__ __forceinline__ void bfly(Fr29& u, Fr29& v, const Fr29& w) {
 // STORE: 0 = value reduced just enough to pack; 1 = multiplied by scale[natural index] and made canonical
 //        (coset factor, or the exit from Montgomery form); 2 = multiplied by the constant passed in `vinv_p`
 //        and made canonical (unit-level transforms: plain 1 or plain 1/n; never combined with LOAD = 1);
-//        3 = the transformed vector is c on the coset and `in_b`, `in_c` hold a and b there (natural order): stores the
-//        canonical quotient values ((a∘b − c)/Z)(g·ω^i) = (a·b − c)·vinv with vinv (PLAIN form) in `vinv_p`
-//        (r1cs_to_qap.rs:187,201-208 fused into the store of the sixth transform)
+//        3 = the transformed vector is b on the coset and `in_b` holds vinv·a there as PLAIN integers (natural order):
+//        stores the canonical products vinv·a_i·b_i — the coset values of the quotient's a∘b part (r1cs_to_qap.rs:187,
+//        201-208; c's part is folded into the l query at load, msm.hpp)
 // Stages are taken two at a time as radix-4 groups held in registers (three twiddle loads and ONE carry
 // propagation per element for two stages, half the barriers); an odd last stage runs radix-2.
 // Lazy-value bounds: a pass starts below 6N (packed inputs are < 2^256 = 5.3N), every stage adds at most 3N,
@@ -291,11 +291,7 @@ __global__ void __launch_bounds__(256) k_ntt29_pass(const uint32_t* __restrict__
         Fr29 y;
         if (STORE == 1) y = cond_sub_n(mul(x, load_packed29(scale, gi)));
         else if (STORE == 2) y = cond_sub_n(mul(x, unpack29<Fr29P>(vinv_p.w)));   // one constant for every element
-        else if (STORE == 3) {                                                    // x = c:  (a·b − c)·vinv, out of Montgomery form
-            const Fr29 aa = load_packed29(in_b, gi), bb = load_packed29(in_c, gi);
-            const Fr29 t = normalize(sub<3, 1>(mul(aa, bb), weak_reduce(x)));     // < 2N + 3N
-            y = cond_sub_n(mul(t, unpack29<Fr29P>(vinv_p.w)));
-        }
+        else if (STORE == 3) y = cond_sub_n(mul(load_packed29(in_b, gi), x));     // x = b on the coset, in_b = vinv·a (plain)
         else y = weak_reduce(x);
         store_packed29(out, store_bitrev ? brev(gi, pp.logn) : gi, y);
     }
@@ -313,7 +309,7 @@ static void launch_pass(uint32_t tiles, const uint32_t* a, const uint32_t* b, co
 // it must not be in place: callers give dst != work (and != in_a for a single-pass transform) in that case.
 static void dit29(const Wm29Domain& d, const uint32_t* tw, const uint32_t* in_a, const uint32_t* in_b, const uint32_t* in_c,
                   bool pointwise, uint32_t* work, uint32_t* dst, const uint32_t* scale, bool store_bitrev, hipStream_t st,
-                  const uint32_t* const_scale = nullptr, const uint32_t* quot_a = nullptr, const uint32_t* quot_b = nullptr) {
+                  const uint32_t* const_scale = nullptr, const uint32_t* quot_a = nullptr) {
     const int logn = d.logn;
     Packed8 vinv;
     memcpy(vinv.w, const_scale ? const_scale : d.vinv, 32);
@@ -336,7 +332,7 @@ static void dit29(const Wm29Domain& d, const uint32_t* tw, const uint32_t* in_a,
         const bool pw = first && pointwise;
         const bool sc = last && scale != nullptr;
         const int sb = last && store_bitrev ? 1 : 0;
-        if (last && quot_a) launch_pass<0, 3>(tiles, a, quot_a, quot_b, o, tw, nullptr, vinv, plan[i], sb, st);   // const_scale = plain vinv
+        if (last && quot_a) launch_pass<0, 3>(tiles, a, quot_a, nullptr, o, tw, nullptr, vinv, plan[i], sb, st);
         else if (last && const_scale) launch_pass<0, 2>(tiles, a, nullptr, nullptr, o, tw, nullptr, vinv, plan[i], sb, st);
         else if (pw && sc) launch_pass<1, 1>(tiles, a, in_b, in_c, o, tw, scale, vinv, plan[i], sb, st);
         else if (pw) launch_pass<1, 0>(tiles, a, in_b, in_c, o, tw, scale, vinv, plan[i], sb, st);
@@ -357,7 +353,8 @@ void wm29_run(const Wm29Domain& dom, const DevCsr& A, const DevCsr& B, const Dev
     uint32_t* v[3] = {buf.va.p, buf.vb.p, buf.vc.p};
     const DevCsr* mats[3] = {&A, &B, &C};
     const Csr29* dicts[3] = {&dA, &dB, &dC};
-    for (int k = 0; k < 3; ++k) {
+    const int nvec = coset_values ? 2 : 3;       // c's share of the quotient lives in the folded l query
+    for (int k = 0; k < nvec; ++k) {
         fill_zero(v[k], D * 32, st);
         if (mats[k]->rows) {
             k_spmv29<<<ceil_div(mats[k]->rows, 256), 256, 0, st>>>(mats[k]->row_ptr.p, mats[k]->col.p, mats[k]->coef_idx.p, dicts[k]->dict.p,
@@ -368,13 +365,12 @@ void wm29_run(const Wm29Domain& dom, const DevCsr& A, const DevCsr& B, const Dev
     k_place_inputs29<<<ceil_div(l, 256), 256, 0, st>>>(buf.w29.p, buf.va.p, m, l, logn);
     CG_KERNEL_CHECK();
     if (coset_values) {
-        // six transforms: the quotient's values on the coset are the h MSM's scalars (bases moved to that basis at load)
-        for (int k = 0; k < 3; ++k) {
-            dit29(dom, dom.tw_inv.p, v[k], nullptr, nullptr, false, v[k], buf.vt.p, dom.coset.p, true, st);
-            if (k < 2) dit29(dom, dom.tw_fwd.p, buf.vt.p, nullptr, nullptr, false, buf.vt.p, v[k], nullptr, false, st);
-            else dit29(dom, dom.tw_fwd.p, buf.vt.p, nullptr, nullptr, false, buf.vt.p, reinterpret_cast<uint32_t*>(h_out), nullptr, false, st,
-                       dom.vinv_plain, buf.va.p, buf.vb.p);
-        }
+        // four transforms: q_j = vinv·a(gω^j)·b(gω^j), the scalars of the h MSM over the transformed h query
+        dit29(dom, dom.tw_inv.p, buf.va.p, nullptr, nullptr, false, buf.va.p, buf.vt.p, dom.coset.p, true, st);
+        dit29(dom, dom.tw_fwd.p, buf.vt.p, nullptr, nullptr, false, buf.vt.p, buf.va.p, nullptr, false, st, dom.vinv_plain);   // vinv·a, plain
+        dit29(dom, dom.tw_inv.p, buf.vb.p, nullptr, nullptr, false, buf.vb.p, buf.vt.p, dom.coset.p, true, st);
+        dit29(dom, dom.tw_fwd.p, buf.vt.p, nullptr, nullptr, false, buf.vt.p, reinterpret_cast<uint32_t*>(h_out), nullptr, false, st, nullptr,
+              buf.va.p);
         return;
     }
     for (int k = 0; k < 3; ++k) {

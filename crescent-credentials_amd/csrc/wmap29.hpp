@@ -59,8 +59,9 @@ struct Ntt29Unit {
 };
 
 // w_canon: M canonical scalars on the device.  h_out: D canonical scalars (natural order), on the device:
-// the coefficients of h (coset_values = false: the reference's result, seven transforms), or the values of the
-// quotient on the coset, q_j = h(g·ω^j) (coset_values = true: six transforms; for an h query held in that basis).
+// the coefficients of h (coset_values = false: the reference's result, seven transforms), or the coset values of the
+// quotient's a∘b part, q_j = vinv·a(g·ω^j)·b(g·ω^j) (coset_values = true: four transforms; for a key whose h query is
+// held in that basis and whose l query carries the C matrix, msm.hpp).
 void wm29_run(const Wm29Domain& dom, const DevCsr& A, const DevCsr& B, const DevCsr& C, const Csr29& dA, const Csr29& dB,
               const Csr29& dC, Wm29Buffers& buf, const Fr* w_canon, uint64_t M, uint64_t m, uint64_t l, Fr* h_out,
               hipStream_t st, bool coset_values);
