@@ -481,6 +481,14 @@ static uint32_t level1_L(uint64_t N) {
     return (uint32_t)L;
 }
 
+// Digit entries are 64-bit records sorted on at most 21 key bits: ten bits per Onesweep pass (two passes instead of
+// rocPRIM's three at its default eight), and Onesweep rather than the ~12-launch merge sort for the small MSMs too.
+using EntrySortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                   rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>,
+                                                                                       rocprim::kernel_config<1024, 8>, 10,
+                                                                                       rocprim::block_radix_rank_algorithm::match>,
+                                                   (size_t)1 << 16>;
+
 template <class F>
 void MsmEngine<F>::init(const MsmBases<F>* b) {
     bases = b;
@@ -495,7 +503,7 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
     // rocPRIM temp sizes for the worst case
     size_t scan_bytes = 0, sort_bytes = 0;
     (void)rocprim::inclusive_scan(nullptr, scan_bytes, thread_counts.p, thread_counts.p, (size_t)(n ? n : 1), rocprim::plus<uint64_t>());
-    (void)rocprim::radix_sort_keys(nullptr, sort_bytes, ent_a.p, ent_b.p, (size_t)cap_entries, 32u, 64u);
+    (void)rocprim::radix_sort_keys<EntrySortConfig>(nullptr, sort_bytes, ent_a.p, ent_b.p, (size_t)cap_entries, 32u, 64u);
     sort_tmp_bytes = scan_bytes > sort_bytes ? scan_bytes : sort_bytes;
     sort_tmp.alloc(sort_tmp_bytes ? sort_tmp_bytes : 1);
     bucket_sums.alloc((size_t)nbuckets_total * ACC);
@@ -579,7 +587,7 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
         size_t tmp = sort_tmp_bytes;
         CG_HIP(hipEventRecord(ev_t[1], st));
         // one 64-bit record per entry, sorted on the key bits only (stable: ties keep emission order)
-        CG_HIP(rocprim::radix_sort_keys(sort_tmp.p, tmp, ent_a.p, ent_b.p, (size_t)N, 32u, 32u + (unsigned)key_bits, st));
+        CG_HIP(rocprim::radix_sort_keys<EntrySortConfig>(sort_tmp.p, tmp, ent_a.p, ent_b.p, (size_t)N, 32u, 32u + (unsigned)key_bits, st));
         CG_HIP(hipEventRecord(ev_t[2], st));
         // level 1
         uint32_t L = level1_L(N);
