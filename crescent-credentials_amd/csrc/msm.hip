@@ -206,27 +206,34 @@ __device__ __forceinline__ uint32_t limb_at(const uint32_t s[8], int idx) {
     for (int i = 0; i < 8; ++i) r = (idx == i) ? s[i] : r;
     return r;
 }
-// bits [pos, pos+c) of the 256-bit little-endian integer s (c <= 22)
-__device__ __forceinline__ uint32_t bits_at(const uint32_t s[8], int pos, int c) {
-    int w = pos >> 5, sh = pos & 31;
-    uint64_t lo = limb_at(s, w);
-    uint64_t hi = (w + 1 < 8) ? limb_at(s, w + 1) : 0u;
-    uint64_t v = (lo | (hi << 32)) >> sh;
-    return (uint32_t)v & ((1u << c) - 1u);
-}
-
-// Calls f(j, digit) for every window; digit in [-2^(c-1), 2^(c-1)].
+// Calls f(j, digit) for every window with a non-zero digit candidate; digit in [-2^(c-1), 2^(c-1)], c <= 22.
+// The scalar's bits stream through a 64-bit buffer that is refilled one limb at a time (a dynamic limb index costs
+// eight selects, so it is paid per limb, not per window), and the walk ends as soon as nothing is left above the
+// current window — after one step for the 0/1 wires that make up most of a circom witness.
 template <class Fn>
 __device__ __forceinline__ void for_each_digit(const uint32_t s[8], int c, int W, Fn f) {
+    int hl = -1;                                   // highest non-zero limb
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hl = s[i] ? i : hl;
+    if (hl < 0) return;
+    uint64_t buf = (uint64_t)s[0] | ((uint64_t)s[1] << 32);
+    int avail = 64, next = 2;
     uint32_t carry = 0;
-    const uint32_t half = 1u << (c - 1);
+    const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
     for (int j = 0; j < W; ++j) {
-        int pos = j * c;
-        uint32_t raw = (pos < 256 ? bits_at(s, pos, c) : 0u) + carry;
+        const uint32_t raw = ((uint32_t)buf & mask) + carry;
+        buf >>= c;
+        avail -= c;
+        if (avail <= 32 && next < 8) {
+            buf |= (uint64_t)limb_at(s, next) << avail;
+            avail += 32;
+            ++next;
+        }
         int32_t d;
         if (raw > half) { d = (int32_t)raw - (int32_t)(1u << c); carry = 1; }
         else { d = (int32_t)raw; carry = 0; }
         f(j, d);
+        if (buf == 0 && carry == 0 && next > hl) break;
     }
 }
 
