@@ -173,6 +173,16 @@ void DevCsr::upload(const cg_csr& m, uint64_t rows_, uint64_t num_variables) {
     }
     for (auto& c : dict_h) c = to_mont(c);
     row_ptr.alloc(rows + 1);
+    {
+        // counting sort of the rows by their length (stable; lengths above 255 share the last class)
+        std::vector<uint32_t> start(257, 0), order(rows ? rows : 1);
+        auto cls = [&](uint64_t i) { uint32_t len = rp[i + 1] - rp[i]; return len > 255u ? 255u : len; };
+        for (uint64_t i = 0; i < rows; ++i) start[cls(i) + 1]++;
+        for (int k = 0; k < 256; ++k) start[k + 1] += start[k];
+        for (uint64_t i = 0; i < rows; ++i) order[start[cls(i)]++] = (uint32_t)i;
+        row_order.alloc(rows ? rows : 1);
+        if (rows) CG_HIP(hipMemcpy(row_order.p, order.data(), rows * 4, hipMemcpyHostToDevice));
+    }
     col.alloc(nnz ? nnz : 1);
     coef_idx.alloc(nnz ? nnz : 1);
     dict.alloc(dict_h.size());

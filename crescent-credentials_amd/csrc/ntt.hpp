@@ -30,6 +30,8 @@ void fr_pow_table(Fr* out, const Fr& base, const Fr& scale, uint64_t n, bool bit
 struct DevCsr {
     uint64_t rows = 0, nnz = 0;
     DevBuf<uint32_t> row_ptr;   // rows + 1  (nnz < 2^32 enforced at load)
+    DevBuf<uint32_t> row_order; // rows sorted by length: lane t of the sparse product takes row row_order[t], so the
+                                // lanes of a wave run the same number of terms (its output is scattered anyway)
     DevBuf<uint32_t> col;
     DevBuf<uint32_t> coef_idx;
     DevBuf<Fr> dict;            // Montgomery

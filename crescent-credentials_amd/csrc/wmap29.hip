@@ -137,11 +137,13 @@ __global__ void __launch_bounds__(256) k_w_to29(const Fr* __restrict__ w, uint32
 
 // out[rev(i)] = <M_i, w>, i < rows  (evaluate_constraint, r1cs_to_qap.rs:16-45); the output vector is the
 // bit-reversed input the first transform wants.
-__global__ void __launch_bounds__(256) k_spmv29(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+__global__ void __launch_bounds__(256) k_spmv29(const uint32_t* __restrict__ row_order, const uint32_t* __restrict__ row_ptr,
+                                                const uint32_t* __restrict__ col,
                                                 const uint32_t* __restrict__ cidx, const uint32_t* __restrict__ dict,
                                                 const uint32_t* __restrict__ w29, uint32_t* __restrict__ out, uint64_t rows, int logn) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows) return;
+    const uint64_t lane = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= rows) return;
+    const uint64_t i = row_order[lane];     // rows of equal length share a wave
     uint32_t b = row_ptr[i], e = row_ptr[i + 1];
     Fr29 acc = Fr29::zero();
     uint32_t cnt = 0;
@@ -357,7 +359,7 @@ void wm29_run(const Wm29Domain& dom, const DevCsr& A, const DevCsr& B, const Dev
     for (int k = 0; k < nvec; ++k) {
         fill_zero(v[k], D * 32, st);
         if (mats[k]->rows) {
-            k_spmv29<<<ceil_div(mats[k]->rows, 256), 256, 0, st>>>(mats[k]->row_ptr.p, mats[k]->col.p, mats[k]->coef_idx.p, dicts[k]->dict.p,
+            k_spmv29<<<ceil_div(mats[k]->rows, 256), 256, 0, st>>>(mats[k]->row_order.p, mats[k]->row_ptr.p, mats[k]->col.p, mats[k]->coef_idx.p, dicts[k]->dict.p,
                                                                    buf.w29.p, v[k], mats[k]->rows, logn);
             CG_KERNEL_CHECK();
         }
