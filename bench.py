@@ -53,8 +53,8 @@ def pmc_traffic(launches_per_proof):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--shape", default="rs256-sd")
     ap.add_argument("--mode", default="throughput", choices=["throughput", "sharded"])
     ap.add_argument("--witness", default="circom", choices=["circom", "uniform"],

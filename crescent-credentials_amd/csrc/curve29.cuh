@@ -160,6 +160,15 @@ CG_HD XYZZ29<F> dbl29(const XYZZ29<F>& a) {
     return {X3, Y3, mul(a.zz, V), mul(a.zzz, W)};
 }
 
+// a·b − c·d.  Over Fq one dual-product reduction, (a·b + (KY·N − c)·d)/R' (c normalised, value < (KY−1)·N — a stored Y):
+// one Montgomery reduction and one subtraction of reduced values fewer than two products, and a result below 2.2 N.
+CG_HD Fq29 mul_sub(const Fq29& a, const Fq29& b, const Fq29& c, const Fq29& d) {
+    return mul2_core(a, b, sub<KY, 1>(Fq29::zero(), c), d);
+}
+CG_HD Fq2_29 mul_sub(const Fq2_29& a, const Fq2_29& b, const Fq2_29& c, const Fq2_29& d) {
+    return normalize(sub<K1, 1>(mul(a, b), mul(c, d)));
+}
+
 // acc += p (p affine, never the identity)          (madd-2008-s)
 // Statement order keeps at most seven field values live (an Fq2 value is 18 VGPRs).
 // In every Fq2 product the SECOND operand is the one that is normalised with the smaller bound.
@@ -183,10 +192,9 @@ CG_HD void madd29(XYZZ29<F>& acc, bool& inf, const Affine29<F>& p) {
     F PPP = mul(P, PP);
     F R = normalize(sub<KY, 1>(mul(acc.zzz, p.y), acc.y));      // S2 - Y1
     F ZZZ3 = mul(acc.zzz, PPP);
-    F T = mul(acc.y, PPP);
     F X3 = normalize(sub<K2, 2>(sub<K1, 1>(sqr(R), PPP), dbl(Q)));
     F d = normalize(sub<KX, 1>(Q, X3));
-    acc.y = normalize(sub<K1, 1>(mul(d, R), T));
+    acc.y = mul_sub(d, R, acc.y, PPP);                          // R·(Q − X3) − Y1·PPP
     acc.x = X3;
     acc.zz = ZZ3;
     acc.zzz = ZZZ3;

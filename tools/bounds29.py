@@ -47,6 +47,15 @@ class Fq:
         return B(a.V * a.V / RN + 1.0, 1.0)
 
     @staticmethod
+    def mul_sub(a, b, c, d, K):
+        """a*b - c*d as one dual-product reduction (a b + (K N - c) d)/R'  (curve29.cuh mul_sub, Fq)"""
+        assert c.L <= 1.0 + 1e-9, "mul_sub: negated operand must be normalised"
+        assert c.V <= K - 1 + 1e-9, "mul_sub: value %.2f needs K >= %d" % (c.V, math.ceil(c.V + 1))
+        cneg = B(float(K), 2.0)
+        col_ok([(a.L, b.L), (cneg.L, d.L)], 18)
+        return B((a.V * b.V + cneg.V * d.V) / RN + 1.0, 1.0)
+
+    @staticmethod
     def add(a, b):
         return B(a.V + b.V, a.L + b.L)
 
@@ -121,7 +130,10 @@ def madd(F, inv, k):
     t = F.sub(RR, PPP, k["K1"], 1)
     X3 = F.norm(F.sub(t, F.dbl(Q), k["K2"], 2))
     d = F.norm(F.sub(Q, X3, k["KX"], 1))
-    Y3 = F.norm(F.sub(F.mul(R, d), F.mul(Y1, PPP), k["K1"], 1))
+    if F is Fq:
+        Y3 = Fq.mul_sub(d, R, Y1, PPP, k["KY"])
+    else:
+        Y3 = F.norm(F.sub(F.mul(R, d), F.mul(Y1, PPP), k["K1"], 1))
     ZZ3 = F.mul(ZZ1, PP)
     ZZZ3 = F.mul(ZZZ1, PPP)
     return X3, Y3, ZZ3, ZZZ3
