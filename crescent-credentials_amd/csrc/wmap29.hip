@@ -217,8 +217,9 @@ __device__ __forceinline__ void bfly(Fr29& u, Fr29& v, const Fr29& w) {
 //        201-208; c's part is folded into the l query at load, msm.hpp)
 // Stages are taken two at a time as radix-4 groups held in registers (three twiddle loads and ONE carry
 // propagation per element for two stages, half the barriers); an odd last stage runs radix-2.
-// Lazy-value bounds: a pass starts below 6N (packed inputs are < 2^256 = 5.3N), every stage adds at most 3N,
-// so after ten stages values stay under 36N and limbs, renormalised every second stage, under 2^32.
+// Lazy-value bounds: a pass starts below 6N (packed inputs are < 2^256 = 5.3N), every stage adds at most 3N — the
+// product-free first group of a transform ends below 22.6N instead — so after ten stages values stay under 47N
+// (representable: 2^261 = 169N) and limbs, renormalised every second stage, under 2^32.
 template <int LOAD, int STORE>
 __global__ void __launch_bounds__(256) k_ntt29_pass(const uint32_t* __restrict__ in_a, const uint32_t* __restrict__ in_b,
                                                     const uint32_t* __restrict__ in_c, uint32_t* __restrict__ out,
@@ -250,13 +251,29 @@ __global__ void __launch_bounds__(256) k_ntt29_pass(const uint32_t* __restrict__
             const uint32_t gi = l2g29(e00, tile, pp);
             const uint32_t k = gi & ((1u << q) - 1u);
             Fr29 x0 = lds_get(sm, e00), x1 = lds_get(sm, e01), x2 = lds_get(sm, e10), x3 = lds_get(sm, e11);
-            const Fr29 w1 = load_tw(tw, (uint64_t)k << sh1);
-            bfly(x0, x1, w1);
-            bfly(x2, x3, w1);
-            const Fr29 w2a = load_tw(tw, (uint64_t)k << sh2);
-            const Fr29 w2b = load_tw(tw, (uint64_t)(k + (1u << q)) << sh2);
-            bfly(x0, x2, w2a);
-            bfly(x1, x3, w2b);
+            if (q == 0) {
+                // the first two stages of a transform: three of the four twiddles are 1 (k = 0), the fourth is ω^(n/4).
+                // Inputs are freshly unpacked (< 2^256 < 6N, normalised), so the three products are skipped and the lazy
+                // bounds become: after stage 0 < 10.6N / 12.3N, after stage 1 < 22.6N (instead of 11.3N).
+                Fr29 t = x1;
+                x1 = sub<7, 1>(x0, t);
+                x0 = add(x0, t);
+                t = x3;
+                x3 = sub<7, 1>(x2, t);
+                x2 = add(x2, t);
+                t = x2;
+                x2 = sub<12, 2>(x0, t);
+                x0 = add(x0, t);
+                bfly(x1, x3, load_tw(tw, (uint64_t)1 << sh2));
+            } else {
+                const Fr29 w1 = load_tw(tw, (uint64_t)k << sh1);
+                bfly(x0, x1, w1);
+                bfly(x2, x3, w1);
+                const Fr29 w2a = load_tw(tw, (uint64_t)k << sh2);
+                const Fr29 w2b = load_tw(tw, (uint64_t)(k + (1u << q)) << sh2);
+                bfly(x0, x2, w2a);
+                bfly(x1, x3, w2b);
+            }
             lds_put(sm, e00, normalize(x0));
             lds_put(sm, e01, normalize(x1));
             lds_put(sm, e10, normalize(x2));
