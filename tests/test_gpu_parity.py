@@ -469,6 +469,45 @@ def test_prove_equals_cpu_restatement(cc, oracle, shape, bit_fraction):
         prover.close()
 
 
+def test_folded_key_equals_reference_arrangement_on_arbitrary_assignments(cc, oracle):
+    """The default key layout (h query in the coset evaluation basis, C matrix folded into the l query: four
+    transforms) and the reference's arrangement (CG_FLAG_H_COEFFICIENT_BASIS: seven transforms, l query as loaded)
+    are different algorithms for the same group elements; they must agree byte for byte on ANY assignment —
+    satisfying, random, sparse, all-ones — and any (r, s), and one of the two is pinned to the C restatement."""
+    import cpu_ref
+    from crescent_credentials_amd import workloads as wl
+    l, m, M = 9, 40_000, 52_000
+    cm, w_sat = wl.synthetic_circuit(31337, l, m, M, 0.6, 3)
+    rng = random.Random(5150)
+    trap = [rng.randrange(1, oracle.R) for _ in range(4)]
+    pk = cc.generate_parameters_with_qap(cm, *trap)
+    folded = cc.Prover(pk, cm, proof_slots=2)
+    plain = cc.Prover(pk, cm, proof_slots=2, h_coefficient_basis=True)
+    try:
+        nprng = np.random.default_rng(99)
+        def random_assignment(kind):
+            a = nprng.integers(0, 256, (M, 32), dtype=np.uint8)
+            a[:, 31] %= 0x30
+            if kind == "sparse":
+                a[nprng.random(M) < 0.97] = 0
+            elif kind == "ones":
+                a[:] = 0
+                a[:, 0] = 1
+            a[0] = 0
+            a[0, 0] = 1                                   # the constant-one wire
+            return a.reshape(-1).copy()
+        cases = [w_sat] + [random_assignment(k) for k in ("random", "random", "sparse", "ones")]
+        for i, w in enumerate(cases):
+            for r, s in ((0, 0), (rng.randrange(oracle.R), rng.randrange(oracle.R))):
+                pf = folded.prove(w, r, s).data
+                assert pf == plain.prove(w, r, s).data, (i, r != 0)
+            if i in (0, 1):
+                assert pf == cpu_ref.prove(pk, (cm.a, cm.b, cm.c), l, m, M, w, r, s, nthreads=8), i
+    finally:
+        folded.close()
+        plain.close()
+
+
 def test_proofs_in_flight_are_independent(cc, oracle):
     """several host threads on one context (proof_slots) give the same bytes as serial proving"""
     from concurrent.futures import ThreadPoolExecutor
