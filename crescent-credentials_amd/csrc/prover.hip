@@ -11,6 +11,7 @@
 #include <mutex>
 #include <chrono>
 #include <cstdlib>
+#include <functional>
 
 #include "msm.hpp"
 #include "ntt.hpp"
@@ -72,6 +73,37 @@ static XYZZ<F> scalar_mul_bytes(const XYZZ<F>& p, const uint8_t k[32]) {
     return scalar_mul(p, e);
 }
 
+// Host-side fixed-base table of one point (delta_g1, delta_g2): 64 four-bit windows x 15 affine multiples, built once
+// per circuit, so that r·delta, s·delta and (r·s)·delta cost 64 mixed additions instead of a 254-bit double-and-add.
+template <class F>
+struct FixedBase {
+    std::vector<Affine<F>> t;   // t[j*15 + (d-1)] = d·16^j·P
+    void build(const Affine<F>& p) {
+        t.assign(64 * 15, Affine<F>::inf());
+        if (p.is_inf()) return;
+        XYZZ<F> base = XYZZ<F>::from_affine(p);
+        for (int j = 0; j < 64; ++j) {
+            const Affine<F> b = to_affine(base);
+            XYZZ<F> acc = XYZZ<F>::from_affine(b);
+            t[j * 15] = b;
+            for (int d = 2; d <= 15; ++d) {
+                madd(acc, b);
+                t[j * 15 + d - 1] = to_affine(acc);
+            }
+            if (j + 1 < 64) { madd(acc, b); base = acc; }     // 16·16^j·P
+        }
+    }
+    XYZZ<F> mul(const uint8_t k[32]) const {
+        XYZZ<F> acc = XYZZ<F>::inf();
+        if (t.empty()) return acc;
+        for (int j = 0; j < 64; ++j) {
+            const unsigned d = (k[j >> 1] >> ((j & 1) * 4)) & 15u;
+            if (d) madd(acc, t[j * 15 + d - 1]);
+        }
+        return acc;
+    }
+};
+
 struct Range { uint64_t lo, hi; };
 static Range shard_range(uint64_t n, int rank, int count) {
     if (count <= 1) return {0, n};
@@ -116,6 +148,8 @@ struct cg_ctx {
     // host copies of the single points the finishing step needs (Montgomery)
     G1Affine alpha_g1, beta_g1, delta_g1, a0, b1_0;
     G2Affine beta_g2, delta_g2, b2_0;
+    FixedBase<Fq> fb_delta_g1;
+    FixedBase<Fq2> fb_delta_g2;
     // scalar ranges (into the MSM operand numbering) owned by this shard
     Range rh, rl, ra;   // h: [0, D-1), l: [0, M-l), a/b: [0, M-1)
     MsmBases<Fq> bh, bl, ba, bb1;
@@ -239,6 +273,8 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         c->a0 = g1_import(pk->a_query, form);            // query[0] of calculate_coeff (prover.rs:265)
         c->b1_0 = g1_import(pk->b_g1_query, form);
         c->b2_0 = g2_import(pk->b_g2_query, form);
+        c->fb_delta_g1.build(c->delta_g1);
+        c->fb_delta_g2.build(c->delta_g2);
         c->folded = !(opt && (opt->flags & CG_FLAG_H_COEFFICIENT_BASIS));
         c->rh = shard_range(c->folded ? D : D - 1, c->shard_rank, c->shard_count);
         c->rl = shard_range(c->folded ? M : M - l, c->shard_rank, c->shard_count);
@@ -319,7 +355,8 @@ static float ev_ms(hipEvent_t a, hipEvent_t b) {
     return ms;
 }
 
-static int prove_partial_impl(cg_ctx* c, ProofSlot* S, const void* assignment, bool on_device, bool skip_b1, Partials& P, cg_timings* tm) {
+static int prove_partial_impl(cg_ctx* c, ProofSlot* S, const void* assignment, bool on_device, bool skip_b1, Partials& P, cg_timings* tm,
+                              const std::function<void()>* while_gpu_runs = nullptr) {
     CG_HIP(hipSetDevice(c->device));
     auto t0 = std::chrono::steady_clock::now();
     const uint64_t M = c->M, l = c->l;
@@ -355,6 +392,7 @@ static int prove_partial_impl(cg_ctx* c, ProofSlot* S, const void* assignment, b
     if (!skip_b1) S->eb1.accumulate(S->st[3]);
     S->eb2.accumulate(S->st[4]);
     S->eh.accumulate(s0);
+    if (while_gpu_runs) (*while_gpu_runs)();      // host work that needs no MSM value
     for (int i = 0; i < 5; ++i) CG_HIP(hipStreamSynchronize(S->st[i]));
     if (S->wm.h_bad_input.p[0]) return fail(CG_ERR_INVALID_ARGUMENT, "full_assignment holds a value >= the scalar field modulus");
     P.h = to_affine(S->eh.value());
@@ -385,12 +423,32 @@ static int prove_partial_impl(cg_ctx* c, ProofSlot* S, const void* assignment, b
     return CG_OK;
 }
 
+// The scalar multiples of delta that do not depend on the MSM values (prover.rs:76-80,94,104,116): fixed-base, and
+// computed while the GPU is still working on the proof.
+struct DeltaMultiples {
+    G1XYZZ r_g1, rs_delta, s_g1;
+    G2XYZZ s_g2;
+};
+static DeltaMultiples delta_multiples(const cg_ctx* c, const uint8_t r[32], const uint8_t s[32]) {
+    DeltaMultiples d;
+    d.r_g1 = c->fb_delta_g1.mul(r);                              // :94
+    // r_s_delta_g1 = (delta_g1 * r) * s = (r·s mod n)·delta_g1   (:76-80)
+    uint8_t rs[32];
+    fp_to_bytes(from_mont(mul(to_mont(fp_from_bytes<Fr>(r)), to_mont(fp_from_bytes<Fr>(s)))), rs);
+    d.rs_delta = c->fb_delta_g1.mul(rs);
+    d.s_g1 = c->fb_delta_g1.mul(s);                              // :104
+    d.s_g2 = c->fb_delta_g2.mul(s);                              // :116
+    return d;
+}
+
 // prover.rs:76-135 with the MSM values given
-static void assemble_impl(const cg_ctx* c, const Partials& S, const uint8_t r[32], const uint8_t s[32], uint8_t proof_out[256]) {
+static void assemble_impl(const cg_ctx* c, const Partials& S, const uint8_t r[32], const uint8_t s[32], uint8_t proof_out[256],
+                          const DeltaMultiples* pre = nullptr) {
     const bool r_zero = scalar_is_zero(r);
-    // r_s_delta_g1 = (delta_g1 * r) * s   (:76-80)
-    G1XYZZ r_g1 = scalar_mul_bytes(c->delta_g1, r);            // :94
-    G1XYZZ rs_delta = scalar_mul_bytes(r_g1, s);
+    DeltaMultiples local;
+    if (!pre) { local = delta_multiples(c, r, s); pre = &local; }
+    const G1XYZZ& r_g1 = pre->r_g1;
+    const G1XYZZ& rs_delta = pre->rs_delta;
     // A = r*delta + a_query[0] + msm_a + alpha   (:96, 256-274)
     G1XYZZ g_a = r_g1;
     madd(g_a, c->a0);
@@ -400,13 +458,13 @@ static void assemble_impl(const cg_ctx* c, const Partials& S, const uint8_t r[32
     // B in G1 (:102-112)
     G1XYZZ g1_b = G1XYZZ::inf();
     if (!r_zero) {
-        g1_b = scalar_mul_bytes(c->delta_g1, s);
+        g1_b = pre->s_g1;
         madd(g1_b, c->b1_0);
         madd(g1_b, S.b1);
         madd(g1_b, c->beta_g1);
     }
     // B in G2 (:116-117)
-    G2XYZZ g2_b = scalar_mul_bytes(c->delta_g2, s);
+    G2XYZZ g2_b = pre->s_g2;
     madd(g2_b, c->b2_0);
     madd(g2_b, S.b2);
     madd(g2_b, c->beta_g2);
@@ -480,16 +538,18 @@ static int prove_common(cg_ctx* ctx, const void* assignment, bool on_device, con
     if (ctx->shard_count != 1) return fail(CG_ERR_INVALID_ARGUMENT, "context is a shard; use cg_prove_partial + cg_assemble");
     try {
         Partials P;
+        DeltaMultiples pre;
+        const std::function<void()> overlap = [&]() { pre = delta_multiples(ctx, r, s); };
         int e;
         {
             std::shared_lock<std::shared_mutex> tl(ctx->tune_mu);
             SlotGuard g(ctx);
-            e = prove_partial_impl(ctx, g.s, assignment, on_device, scalar_is_zero(r), P, tm);
+            e = prove_partial_impl(ctx, g.s, assignment, on_device, scalar_is_zero(r), P, tm, &overlap);
         }
         if (!e) maybe_retune(ctx);
         if (e) return e;
         auto t0 = std::chrono::steady_clock::now();
-        assemble_impl(ctx, P, r, s, proof_out);
+        assemble_impl(ctx, P, r, s, proof_out, &pre);
         if (tm) {
             tm->finish_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
             tm->total_ms += tm->finish_ms;
