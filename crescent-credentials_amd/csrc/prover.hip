@@ -11,6 +11,7 @@
 #include <mutex>
 #include <chrono>
 #include <cstdlib>
+#include <exception>
 #include <functional>
 
 #include "msm.hpp"
@@ -184,8 +185,15 @@ struct cg_ctx {
 struct SlotGuard {
     cg_ctx* c;
     ProofSlot* s;
-    explicit SlotGuard(cg_ctx* ctx) : c(ctx), s(ctx->acquire()) {}
-    ~SlotGuard() { c->release(s); }
+    int exceptions;
+    explicit SlotGuard(cg_ctx* ctx) : c(ctx), s(ctx->acquire()), exceptions(std::uncaught_exceptions()) {}
+    ~SlotGuard() {
+        // a failure part-way through a proof may leave kernels queued on the slot's streams: drain them before the
+        // working set is handed to the next proof
+        if (std::uncaught_exceptions() > exceptions)
+            for (auto st : s->st) if (st) (void)hipStreamSynchronize(st);
+        c->release(s);
+    }
 };
 
 namespace cg {
@@ -248,6 +256,14 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
     if (pk->a_len != M || pk->b_g1_len != M || pk->b_g2_len != M) return fail(CG_ERR_MALFORMED_KEY, "a/b query length must equal num_variables");
     if (pk->l_len != M - l) return fail(CG_ERR_MALFORMED_KEY, "l_query length must equal num_variables - num_inputs");
     if (pk->h_len != D - 1) return fail(CG_ERR_MALFORMED_KEY, "h_query length must equal domain_size - 1 = %llu", (unsigned long long)(D - 1));
+    // options are checked before the GPU is touched
+    const int shard_count = (opt && opt->shard_count > 1) ? opt->shard_count : 1;
+    const int shard_rank = (opt && shard_count > 1) ? opt->shard_rank : 0;
+    if (shard_rank < 0 || shard_rank >= shard_count) return fail(CG_ERR_INVALID_ARGUMENT, "shard_rank out of range");
+    const int wb = opt ? opt->window_bits : 0;
+    if (wb < 0 || wb == 1 || wb > 22) return fail(CG_ERR_INVALID_ARGUMENT, "window_bits must be 0 (automatic) or in [2, 22]");
+    if (opt && opt->proof_slots < 0) return fail(CG_ERR_INVALID_ARGUMENT, "proof_slots must not be negative");
+    if (opt && (opt->flags & ~CG_FLAG_H_COEFFICIENT_BASIS)) return fail(CG_ERR_INVALID_ARGUMENT, "unknown bits in flags");
     try {
         int dev = (opt && opt->device >= 0) ? opt->device : -1;
         if (dev < 0) CG_HIP(hipGetDevice(&dev));
@@ -255,10 +271,8 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         std::unique_ptr<cg_ctx> c(new cg_ctx());
         c->device = dev;
         c->l = l; c->m = m; c->M = M; c->D = D; c->logD = logD;
-        c->shard_count = (opt && opt->shard_count > 1) ? opt->shard_count : 1;
-        c->shard_rank = (opt && c->shard_count > 1) ? opt->shard_rank : 0;
-        if (c->shard_rank < 0 || c->shard_rank >= c->shard_count) return fail(CG_ERR_INVALID_ARGUMENT, "shard_rank out of range");
-        const int wb = opt ? opt->window_bits : 0;
+        c->shard_count = shard_count;
+        c->shard_rank = shard_rank;
         c->fixed_window = wb > 0;
         int n_slots = (opt && opt->proof_slots > 0) ? opt->proof_slots : 1;
         if (n_slots > 16) n_slots = 16;

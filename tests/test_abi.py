@@ -168,6 +168,14 @@ def test_circuit_load_validates_before_touching_the_gpu(cc):
     assert rc == -6 and b"h_query" in L.cg_last_error()
     rc = L.cg_circuit_load(ctypes.byref(h), ctypes.byref(pk), abc, 3, (1 << 28) + 5, (1 << 28) + 9, None)
     assert rc == -5            # PolynomialDegreeTooLarge (r1cs_to_qap.rs:156-157)
+    # options
+    pk.h_len = 7
+    for kw, msg in ((dict(window_bits=1), b"window_bits"), (dict(window_bits=23), b"window_bits"), (dict(window_bits=-3), b"window_bits"),
+                    (dict(shard_count=4, shard_rank=4), b"shard_rank"), (dict(shard_count=2, shard_rank=-1), b"shard_rank"),
+                    (dict(proof_slots=-1), b"proof_slots"), (dict(flags=2), b"flags")):
+        opt = api._CgOptions(device=-1, **kw)
+        rc = L.cg_circuit_load(ctypes.byref(h), ctypes.byref(pk), abc, 3, 4, 7, ctypes.byref(opt))
+        assert rc == -1 and msg in L.cg_last_error(), kw
 
 
 def _c_struct_fields(name):
