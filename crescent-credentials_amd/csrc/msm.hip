@@ -326,6 +326,134 @@ __global__ void __launch_bounds__(256) k_accum_affine(const uint64_t* __restrict
     }
 }
 
+// ---- the same over Fq2 with the accumulator in LDS -------------------------------------------------------------------
+// An Fq2 XYZZ accumulator is 72 VGPRs; held in registers next to the point and the temporaries of a mixed addition
+// it pushes the kernel past 400 VGPRs (one wave per SIMD, spills).  Here the running accumulator lives in LDS
+// (word-major, [word][lane]: conflict-free) and each coordinate is read where the formula needs it and written back
+// when it is final, so the kernel fits two waves per SIMD.
+__device__ __forceinline__ Fq2_29 lacc_ld(const uint32_t* sl, int f) {
+    Fq2_29 r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        r.c0.l[i] = sl[(f * 18 + i) * 256];
+        r.c1.l[i] = sl[(f * 18 + 9 + i) * 256];
+    }
+    return r;
+}
+__device__ __forceinline__ void lacc_st(uint32_t* sl, int f, const Fq2_29& v) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        sl[(f * 18 + i) * 256] = v.c0.l[i];
+        sl[(f * 18 + 9 + i) * 256] = v.c1.l[i];
+    }
+}
+// coordinate `which` (0 = x, 1 = y) of table point idx; y negated when `negate`
+__device__ __forceinline__ Fq2_29 load_table_coord2(const uint32_t* __restrict__ table, uint32_t idx, int which, bool negate) {
+    const uint4* p = reinterpret_cast<const uint4*>(table + (size_t)idx * 32 + which * 16);
+    uint32_t w[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint4 v = p[i];
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+    Fq2_29 c;
+    load_coord(c, w);
+    if (which == 1) {
+        Fq2_29 nc = normalize(sub<2, 1>(Fq2_29::zero(), c));
+        if (negate) c = nc;
+    }
+    return c;
+}
+// acc (in LDS) += table point   (madd-2008-s in the statement order of curve29.cuh's madd29)
+__device__ __forceinline__ void madd29_lds(uint32_t* sl, bool& inf, const uint32_t* __restrict__ table, uint32_t idx, bool negate) {
+    typedef Fq2_29 F;
+    const F px = load_table_coord2(table, idx, 0, false);
+    if (inf) {
+        lacc_st(sl, 0, px);
+        lacc_st(sl, 1, load_table_coord2(table, idx, 1, negate));
+        lacc_st(sl, 2, F::one());
+        lacc_st(sl, 3, F::one());
+        inf = false;
+        return;
+    }
+    const F zz = lacc_ld(sl, 2), x1 = lacc_ld(sl, 0);
+    F P = normalize(sub<KX, 1>(mul(zz, px), x1));
+    F PP = sqr(P);
+    F ZZ3 = mul(zz, PP);
+    if (is_zero_mod(ZZ3)) {                      // same x: doubling or cancellation (rare)
+        const F py = load_table_coord2(table, idx, 1, negate);
+        F R0 = normalize(sub<KY, 1>(mul(lacc_ld(sl, 3), py), lacc_ld(sl, 1)));
+        if (is_zero_mod(canonical(R0))) {
+            XYZZ29<F> d2 = dbl_affine29(Affine29<F>{px, py});
+            lacc_st(sl, 0, d2.x); lacc_st(sl, 1, d2.y); lacc_st(sl, 2, d2.zz); lacc_st(sl, 3, d2.zzz);
+        } else {
+            inf = true;
+        }
+        return;
+    }
+    lacc_st(sl, 2, ZZ3);
+    F Q = mul(x1, PP);
+    F PPP = mul(P, PP);
+    const F py = load_table_coord2(table, idx, 1, negate);
+    const F zzz = lacc_ld(sl, 3), y1 = lacc_ld(sl, 1);
+    F R = normalize(sub<KY, 1>(mul(zzz, py), y1));
+    lacc_st(sl, 3, mul(zzz, PPP));
+    F X3 = normalize(sub<K2, 2>(sub<K1, 1>(sqr(R), PPP), dbl(Q)));
+    lacc_st(sl, 0, X3);
+    F d = normalize(sub<KX, 1>(Q, X3));
+    lacc_st(sl, 1, mul_sub(d, R, y1, PPP));
+}
+__device__ __forceinline__ XYZZ29<Fq2_29> lacc_all(const uint32_t* sl) { return {lacc_ld(sl, 0), lacc_ld(sl, 1), lacc_ld(sl, 2), lacc_ld(sl, 3)}; }
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_accum_affine_g2(const uint64_t* __restrict__ entries, uint32_t N, uint32_t L, uint32_t T, const uint32_t* __restrict__ table,
+                  uint32_t* __restrict__ bucket_sums, uint32_t* __restrict__ part_keys, uint32_t* __restrict__ part_pts) {
+    typedef Fq2_29 F29T;
+    constexpr int ACC = Words29<F29T>::ACC;
+    __shared__ uint32_t sm[ACC * 256];
+    uint32_t* sl = sm + threadIdx.x;
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const bool final_level = (T == 1);
+    uint32_t beg = t * L;
+    uint32_t end = beg + L < N ? beg + L : N;
+    bool inf = true;
+    uint32_t cur = (uint32_t)(entries[beg] >> 32);
+    bool first = true;
+    for (uint32_t k = beg; k < end; ++k) {
+        const uint64_t ent = entries[k];
+        const uint32_t key = (uint32_t)(ent >> 32), v = (uint32_t)ent;
+        if (key != cur) {
+            flush_run(cur, lacc_all(sl), inf, first, final_level, t, bucket_sums, part_keys, part_pts);
+            first = false;
+            inf = true;
+            cur = key;
+        }
+        madd29_lds(sl, inf, table, v & 0x7fffffffu, (v >> 31) != 0);
+    }
+    const XYZZ29<F29T> acc = lacc_all(sl);
+    if (final_level) {
+        store_acc(bucket_sums + (size_t)cur * ACC, acc, inf);
+    } else if (first) {  // the whole segment is one run
+        part_keys[2 * t] = cur;
+        store_acc(part_pts + (size_t)(2 * t) * ACC, acc, inf);
+        part_keys[2 * t + 1] = cur;
+        store_acc(part_pts + (size_t)(2 * t + 1) * ACC, acc, true);
+    } else {
+        part_keys[2 * t + 1] = cur;
+        store_acc(part_pts + (size_t)(2 * t + 1) * ACC, acc, inf);
+    }
+}
+
+template <class F29T>
+static void launch_accum_affine(const uint64_t* entries, uint32_t N, uint32_t L, uint32_t T, const uint32_t* table, uint32_t* bucket_sums,
+                                uint32_t* part_keys, uint32_t* part_pts, hipStream_t st) {
+    if constexpr (Words29<F29T>::NF == 2)
+        k_accum_affine_g2<<<ceil_div(T, 256), 256, 0, st>>>(entries, N, L, T, table, bucket_sums, part_keys, part_pts);
+    else
+        k_accum_affine<F29T><<<ceil_div(T, 256), 256, 0, st>>>(entries, N, L, T, table, bucket_sums, part_keys, part_pts);
+}
+
 template <class F29T>
 __global__ void __launch_bounds__(256) k_accum_xyzz(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ pts,
                                                     uint32_t N, uint32_t L, uint32_t T, uint32_t* __restrict__ bucket_sums,
@@ -600,8 +728,7 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
         uint32_t L = level1_L(N);
         uint32_t T = ceil_div(N, L);
         CG_HIP(hipEventRecord(ev_t[3], st));
-        k_accum_affine<F29T><<<ceil_div(T, 256), 256, 0, st>>>(ent_b.p, N, L, T, bases->table.p, bucket_sums.p,
-                                                               part_keys_a.p, part_pts_a.p);
+        launch_accum_affine<F29T>(ent_b.p, N, L, T, bases->table.p, bucket_sums.p, part_keys_a.p, part_pts_a.p, st);
         CG_KERNEL_CHECK();
         CG_HIP(hipEventRecord(ev_t[4], st));
         // combine partials until one lane covers everything
