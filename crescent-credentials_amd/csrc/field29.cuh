@@ -383,7 +383,7 @@ __device__ __attribute__((noinline)) inline u32x9 mul2_call(u32x9 x0, u32x9 y0, 
 }
 #endif
 CG_HD Fq29 mul2(const Fq29& x0, const Fq29& y0, const Fq29& x1, const Fq29& y1) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(CG_MUL2_CALL)   // measured: inlined is both smaller in VGPRs and faster
     return from_vec<Fq29P>(mul2_call(to_vec(x0), to_vec(y0), to_vec(x1), to_vec(y1)));
 #else
     return mul2_core(x0, y0, x1, y1);
