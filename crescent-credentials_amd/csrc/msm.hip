@@ -270,6 +270,34 @@ __global__ void __launch_bounds__(256) k_digit_emit(const Fr* __restrict__ scala
     });
 }
 
+// Dense form for scalar populations without zero digits to speak of (the h MSM: uniform field elements): entry
+// slot = window * n + scalar, so the writes of a wave are contiguous, no count / prefix sum is needed and the host
+// knows the entry count in advance.  A zero digit or an identity base leaves a filler record whose key is the
+// bucket count: it sorts behind every real entry and the accumulation skips it.
+__global__ void __launch_bounds__(256) k_digit_emit_dense(const Fr* __restrict__ scalars, const uint8_t* __restrict__ valid,
+                                                          uint64_t n, int c, int W, uint64_t* __restrict__ entries,
+                                                          uint64_t row_stride) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t nb = 1u << (c - 1);
+    const uint64_t filler = (uint64_t)nb << 32;
+    int next = 0;                                   // windows below `next` are written
+    if (valid[i]) {
+        Fr s = scalars[i];
+        for_each_digit(s.l, c, W, [&](int j, int32_t d) {
+            uint64_t e = filler;
+            if (d != 0) {
+                uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+                uint32_t sign = d < 0 ? 0x80000000u : 0u;
+                e = ((uint64_t)(mag - 1u) << 32) | ((uint32_t)((uint64_t)j * row_stride + i) | sign);
+            }
+            entries[(uint64_t)j * n + i] = e;
+            next = j + 1;
+        });
+    }
+    for (int j = next; j < W; ++j) entries[(uint64_t)j * n + i] = filler;   // for_each_digit stops above the top limb
+}
+
 // ---------------------------------------------------------------------------------------------
 // bucket accumulation over equal segments of the sorted entry list
 // ---------------------------------------------------------------------------------------------
@@ -290,7 +318,7 @@ template <class F29T>
 __global__ void __launch_bounds__(256) k_accum_affine(const uint64_t* __restrict__ entries,
                                                       uint32_t N, uint32_t L, uint32_t T, const uint32_t* __restrict__ table,
                                                       uint32_t* __restrict__ bucket_sums, uint32_t* __restrict__ part_keys,
-                                                      uint32_t* __restrict__ part_pts) {
+                                                      uint32_t* __restrict__ part_pts, uint32_t filler_key) {
     constexpr int ACC = Words29<F29T>::ACC;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
@@ -310,6 +338,7 @@ __global__ void __launch_bounds__(256) k_accum_affine(const uint64_t* __restrict
             inf = true;
             cur = key;
         }
+        if (key == filler_key) continue;         // dense-mode filler (run of the spare bucket; never read back)
         Affine29<F29T> p = load_table_point<F29T>(table, v & 0x7fffffffu, (v >> 31) != 0);
         madd29(acc, inf, p);
     }
@@ -407,7 +436,8 @@ __device__ __forceinline__ XYZZ29<Fq2_29> lacc_all(const uint32_t* sl) { return 
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_accum_affine_g2(const uint64_t* __restrict__ entries, uint32_t N, uint32_t L, uint32_t T, const uint32_t* __restrict__ table,
-                  uint32_t* __restrict__ bucket_sums, uint32_t* __restrict__ part_keys, uint32_t* __restrict__ part_pts) {
+                  uint32_t* __restrict__ bucket_sums, uint32_t* __restrict__ part_keys, uint32_t* __restrict__ part_pts,
+                  uint32_t filler_key) {
     typedef Fq2_29 F29T;
     constexpr int ACC = Words29<F29T>::ACC;
     __shared__ uint32_t sm[ACC * 256];
@@ -429,6 +459,7 @@ k_accum_affine_g2(const uint64_t* __restrict__ entries, uint32_t N, uint32_t L, 
             inf = true;
             cur = key;
         }
+        if (key == filler_key) continue;
         madd29_lds(sl, inf, table, v & 0x7fffffffu, (v >> 31) != 0);
     }
     const XYZZ29<F29T> acc = lacc_all(sl);
@@ -447,11 +478,11 @@ k_accum_affine_g2(const uint64_t* __restrict__ entries, uint32_t N, uint32_t L, 
 
 template <class F29T>
 static void launch_accum_affine(const uint64_t* entries, uint32_t N, uint32_t L, uint32_t T, const uint32_t* table, uint32_t* bucket_sums,
-                                uint32_t* part_keys, uint32_t* part_pts, hipStream_t st) {
+                                uint32_t* part_keys, uint32_t* part_pts, uint32_t filler_key, hipStream_t st) {
     if constexpr (Words29<F29T>::NF == 2)
-        k_accum_affine_g2<<<ceil_div(T, 256), 256, 0, st>>>(entries, N, L, T, table, bucket_sums, part_keys, part_pts);
+        k_accum_affine_g2<<<ceil_div(T, 256), 256, 0, st>>>(entries, N, L, T, table, bucket_sums, part_keys, part_pts, filler_key);
     else
-        k_accum_affine<F29T><<<ceil_div(T, 256), 256, 0, st>>>(entries, N, L, T, table, bucket_sums, part_keys, part_pts);
+        k_accum_affine<F29T><<<ceil_div(T, 256), 256, 0, st>>>(entries, N, L, T, table, bucket_sums, part_keys, part_pts, filler_key);
 }
 
 template <class F29T>
@@ -641,7 +672,7 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
     (void)rocprim::radix_sort_keys<EntrySortConfig>(nullptr, sort_bytes, ent_a.p, ent_b.p, (size_t)cap_entries, 32u, 64u);
     sort_tmp_bytes = scan_bytes > sort_bytes ? scan_bytes : sort_bytes;
     sort_tmp.alloc(sort_tmp_bytes ? sort_tmp_bytes : 1);
-    bucket_sums.alloc((size_t)nbuckets_total * ACC);
+    bucket_sums.alloc(((size_t)nbuckets_total + 1) * ACC);     // + the spare bucket of the dense mode's filler records
     uint64_t t1 = (cap_entries + ACC_MIN_L - 1) / ACC_MIN_L;
     if (t1 > ACC_TARGET_THREADS) t1 = ACC_TARGET_THREADS;
     uint64_t pa = 2 * t1;
@@ -691,6 +722,12 @@ void MsmEngine<F>::digits(const Fr* scalars_dev, uint64_t n, hipStream_t st) {
     CG_HIP(hipEventRecord(ev_t[0], st));
     if (!n) return;
     const int c = bases->c, W = bases->W;
+    dense_now = dense && bases->precomputed && c <= 20;      // the filler key needs one more key bit: keep two sort passes
+    if (dense_now) {
+        k_digit_emit_dense<<<ceil_div(n, 256), 256, 0, st>>>(scalars_dev, bases->valid.p, n, c, W, ent_a.p, bases->n);
+        CG_KERNEL_CHECK();
+        return;
+    }
     k_digit_count<<<ceil_div(n, 256), 256, 0, st>>>(scalars_dev, bases->valid.p, n, c, W, thread_counts.p);
     CG_KERNEL_CHECK();
     size_t tmp = sort_tmp_bytes;
@@ -708,7 +745,10 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
     const uint32_t nb = 1u << (bases->c - 1);
     n_entries = 0;
     n_nonzero = 0;
-    if (n_scalars) {
+    if (n_scalars && dense_now) {
+        n_entries = (uint32_t)(n_scalars * (uint64_t)bases->W);     // fixed layout: known without asking the device
+        n_nonzero = (uint32_t)n_scalars;
+    } else if (n_scalars) {
         CG_HIP(hipEventSynchronize(ev_count));
         n_entries = (uint32_t)h_count.p[0];
         n_nonzero = (uint32_t)(h_count.p[0] >> 32);
@@ -717,6 +757,7 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
     if (n_entries) {
         const uint32_t N = n_entries;
         int key_bits = bases->c - 1;
+        if (dense_now) key_bits += 1;            // the filler key is the bucket count itself
         if (!bases->precomputed) key_bits += ilog2_ceil((uint64_t)bases->W);
         if (key_bits < 1) key_bits = 1;
         size_t tmp = sort_tmp_bytes;
@@ -728,7 +769,8 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
         uint32_t L = level1_L(N);
         uint32_t T = ceil_div(N, L);
         CG_HIP(hipEventRecord(ev_t[3], st));
-        launch_accum_affine<F29T>(ent_b.p, N, L, T, bases->table.p, bucket_sums.p, part_keys_a.p, part_pts_a.p, st);
+        launch_accum_affine<F29T>(ent_b.p, N, L, T, bases->table.p, bucket_sums.p, part_keys_a.p, part_pts_a.p,
+                                  dense_now ? nb : 0xffffffffu, st);
         CG_KERNEL_CHECK();
         CG_HIP(hipEventRecord(ev_t[4], st));
         // combine partials until one lane covers everything

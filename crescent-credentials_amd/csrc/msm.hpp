@@ -59,6 +59,8 @@ struct MsmEngine {
     DevBuf<uint32_t> result;          // W_keyspace accumulators (1 when precomputed)
     PinnedBuf<uint64_t> h_count;      // low word: entries, high word: scalars with a non-zero digit
     PinnedBuf<uint32_t> h_result;
+    bool dense = false;       // expect (nearly) no zero digits: fixed-stride emission, no count / prefix sum / host wait
+    bool dense_now = false;   // ... in effect for the current MSM
     uint64_t n_scalars = 0;
     uint32_t n_entries = 0;
     uint32_t n_nonzero = 0;

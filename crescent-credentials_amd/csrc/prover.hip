@@ -331,6 +331,7 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
             }
             CG_HIP(hipEventCreateWithFlags(&sl->ev_w, hipEventDisableTiming));
             for (auto& e : sl->ev_t) CG_HIP(hipEventCreate(&e));
+            sl->eh.dense = true;     // the h MSM's scalars are uniform field elements
             sl->eh.init(&c->bh); sl->el.init(&c->bl); sl->ea.init(&c->ba); sl->eb1.init(&c->bb1); sl->eb2.init(&c->bb2);
             sl->w_canon.alloc(M); sl->h_canon.alloc(D);
             sl->wm.alloc(M, D);
