@@ -657,6 +657,7 @@ using EntrySortConfig = rocprim::radix_sort_config<rocprim::default_config, rocp
 
 template <class F>
 void MsmEngine<F>::init(const MsmBases<F>* b) {
+    if (red_graph) { (void)hipGraphExecDestroy(red_graph); red_graph = nullptr; }   // shapes and buffers change below
     bases = b;
     const uint64_t n = b->n;
     const int W = b->W;
@@ -710,6 +711,7 @@ template <class F> float MsmEngine<F>::ms_accum() const { return n_entries ? ela
 
 template <class F>
 MsmEngine<F>::~MsmEngine() {
+    if (red_graph) (void)hipGraphExecDestroy(red_graph);
     if (ev_count) (void)hipEventDestroy(ev_count);
     for (auto& e : ev_t) if (e) (void)hipEventDestroy(e);
 }
@@ -789,7 +791,31 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
             from_a = !from_a;
         }
     }
-    // bucket reduction (see the comment above k_sum_axis)
+    // bucket reduction (see the comment above k_sum_axis).  Its launches are many, small and of a fixed shape for a given
+    // window size, so they are captured once into a HIP graph and replayed: one submission instead of ~20.
+    if (!red_graph) {
+        hipGraph_t g = nullptr;
+        CG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        try {
+            enqueue_reduction(st);
+        } catch (...) {
+            (void)hipStreamEndCapture(st, &g);
+            if (g) (void)hipGraphDestroy(g);
+            throw;
+        }
+        CG_HIP(hipStreamEndCapture(st, &g));
+        hipError_t e = hipGraphInstantiate(&red_graph, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        CG_HIP(e);
+    }
+    CG_HIP(hipGraphLaunch(red_graph, st));
+    CG_HIP(hipEventRecord(ev_t[5], st));
+}
+
+template <class F>
+void MsmEngine<F>::enqueue_reduction(hipStream_t st) {
+    const uint32_t wins = bases->precomputed ? 1u : (uint32_t)bases->W;
+    const uint32_t nb = 1u << (bases->c - 1);
     {
         const int cbits = (bases->c - 1 + 1) / 2 > 10 ? 10 : (bases->c - 1 + 1) / 2;
         const uint32_t C = 1u << cbits, R = nb / C;
@@ -847,7 +873,6 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
         weighted(cols, C, 1, 1);
     }
     CG_HIP(hipMemcpyAsync(h_result.p, result.p, (size_t)wins * 2 * ACC * 4, hipMemcpyDeviceToHost, st));
-    CG_HIP(hipEventRecord(ev_t[5], st));
 }
 
 // ---- host: lazy 29-bit accumulator -> saturated Montgomery(2^256) XYZZ ---------------------------------

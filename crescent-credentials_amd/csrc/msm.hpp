@@ -64,6 +64,8 @@ struct MsmEngine {
     uint64_t n_scalars = 0;
     uint32_t n_entries = 0;
     uint32_t n_nonzero = 0;
+    hipGraphExec_t red_graph = nullptr;   // the bucket reduction's launches, captured on first use (reset by init)
+    void enqueue_reduction(hipStream_t st);
     hipEvent_t ev_count = nullptr;
     // timing events (recorded on the MSM's own stream): digits start, sort begin/end, level-1
     // accumulation kernel begin/end, result ready
