@@ -182,6 +182,11 @@ void DevCsr::upload(const cg_csr& m, uint64_t rows_, uint64_t num_variables) {
         for (uint64_t i = 0; i < rows; ++i) order[start[cls(i)]++] = (uint32_t)i;
         row_order.alloc(rows ? rows : 1);
         if (rows) CG_HIP(hipMemcpy(row_order.p, order.data(), rows * 4, hipMemcpyHostToDevice));
+        std::vector<uint32_t> lr;
+        for (uint64_t i = 0; i < rows; ++i) if (rp[i + 1] - rp[i] > 4096u) lr.push_back((uint32_t)i);
+        n_long_rows = lr.size();
+        long_rows.alloc(lr.size() ? lr.size() : 1);
+        if (!lr.empty()) CG_HIP(hipMemcpy(long_rows.p, lr.data(), lr.size() * 4, hipMemcpyHostToDevice));
     }
     col.alloc(nnz ? nnz : 1);
     coef_idx.alloc(nnz ? nnz : 1);
@@ -194,12 +199,15 @@ void DevCsr::upload(const cg_csr& m, uint64_t rows_, uint64_t num_variables) {
     CG_HIP(hipMemcpy(dict.p, dict_h.data(), dict_h.size() * sizeof(Fr), hipMemcpyHostToDevice));
 }
 
+static constexpr uint32_t SPMV_LONG_ROW = 4096;
+
 __global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
                                               const uint32_t* __restrict__ cidx, const Fr* __restrict__ dict,
                                               const Fr* __restrict__ w, Fr* __restrict__ out, uint64_t rows) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows) return;
     uint32_t b = row_ptr[i], e = row_ptr[i + 1];
+    if (e - b > SPMV_LONG_ROW) return;            // k_spmv_long's
     Fr acc = Fr::zero();
     for (uint32_t t = b; t < e; ++t) {
         Fr v = w[col[t]];
@@ -209,11 +217,38 @@ __global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ row_p
     }
     out[i] = acc;
 }
+// one workgroup per long row (the transposed matrices of cg_setup have a few: the constant-one wire sits in a large share
+// of all constraints), strided partial sums and an LDS tree
+__global__ void __launch_bounds__(256) k_spmv_long(const uint32_t* __restrict__ long_rows, const uint32_t* __restrict__ row_ptr,
+                                                   const uint32_t* __restrict__ col, const uint32_t* __restrict__ cidx,
+                                                   const Fr* __restrict__ dict, const Fr* __restrict__ w, Fr* __restrict__ out) {
+    __shared__ Fr part[256];
+    const uint32_t i = long_rows[blockIdx.x];
+    const uint32_t b = row_ptr[i], e = row_ptr[i + 1];
+    Fr acc = Fr::zero();
+    for (uint32_t t = b + threadIdx.x; t < e; t += 256) {
+        Fr v = w[col[t]];
+        uint32_t ci = cidx[t];
+        if (ci != 0) v = mul(v, dict[ci]);
+        acc = add(acc, v);
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t s2 = 128; s2 > 0; s2 >>= 1) {
+        if (threadIdx.x < s2) part[threadIdx.x] = add(part[threadIdx.x], part[threadIdx.x + s2]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[i] = part[0];
+}
 
 void spmv(const DevCsr& m, const Fr* w, Fr* out, hipStream_t st) {
     if (!m.rows) return;
     k_spmv<<<grid_for(m.rows), 256, 0, st>>>(m.row_ptr.p, m.col.p, m.coef_idx.p, m.dict.p, w, out, m.rows);
     CG_KERNEL_CHECK();
+    if (m.n_long_rows) {
+        k_spmv_long<<<(uint32_t)m.n_long_rows, 256, 0, st>>>(m.long_rows.p, m.row_ptr.p, m.col.p, m.coef_idx.p, m.dict.p, w, out);
+        CG_KERNEL_CHECK();
+    }
 }
 
 }  // namespace cg

@@ -32,6 +32,8 @@ struct DevCsr {
     DevBuf<uint32_t> row_ptr;   // rows + 1  (nnz < 2^32 enforced at load)
     DevBuf<uint32_t> row_order; // rows sorted by length: lane t of the sparse product takes row row_order[t], so the
                                 // lanes of a wave run the same number of terms (its output is scattered anyway)
+    DevBuf<uint32_t> long_rows; // rows with more than 4096 terms (saturated spmv: one workgroup each)
+    uint64_t n_long_rows = 0;
     DevBuf<uint32_t> col;
     DevBuf<uint32_t> coef_idx;
     DevBuf<Fr> dict;            // Montgomery
