@@ -513,6 +513,9 @@ static bool retune_query(cg_ctx* c, MsmBases<F>& bases, MsmEngine<F> ProofSlot::
     double nz_full = W0 > 1 ? (N - nz) / (double)(W0 - 1) : 0.0;
     if (nz_full < 0) nz_full = 0;
     if (nz_full > nz) nz_full = nz;
+    // a population that fills (nearly) every window - uniform scalars - takes the dense digit form from now on
+    const bool dense = N >= 0.98 * (double)e.n_scalars * (double)W0;
+    for (auto& sl : c->slots) ((*sl).*eng).dense = dense;
     int best = msm_best_window(bases.n, nz - nz_full, nz_full);
     if (best == bases.c) return false;
     bases.rebuild(best, st);
