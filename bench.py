@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 # Several proofs are kept in flight per GPU, each on five HIP streams; the runtime maps streams onto this many
 # hardware queues (default 4), and kernels of streams that share a queue cannot overlap.  Must be set before
 # the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

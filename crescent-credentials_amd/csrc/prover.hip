@@ -219,6 +219,10 @@ extern "C" const char* cg_last_error(void) { return last_error().c_str(); }
 extern "C" const char* cg_version(void) { return "crescent_gpu 0.1 (gfx950; BN254 Groth16 prove path: MSM G1/G2 + NTT + witness map)"; }
 
 extern "C" int cg_init(int n_devices, const int* device_ids) {
+    // Proofs in flight run on 5 streams each; the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues
+    // (default 4) and kernels on one queue cannot overlap.  Effective only if HIP has not initialised yet in this
+    // process; a host that initialises HIP earlier should export the variable itself.
+    (void)setenv("GPU_MAX_HW_QUEUES", "32", 0);
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count == 0) return fail(CG_ERR_NO_DEVICE, "no HIP device visible (%s)", hipGetErrorString(e));
