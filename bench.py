@@ -153,6 +153,10 @@ def main():
         dt = time.perf_counter() - t_start
         return max_over_ranks(dt, world, dev)
 
+    # one-time per-circuit tuning (the window re-tune that follows the first proof of a context) belongs to circuit
+    # loading, not to the steady state that W warm-up + K timed steps measure: run it before both, whatever W is
+    one_proof()
+    torch.cuda.synchronize()
     dt = timed_run(a.steps, a.warmup)
     proofs_total = a.steps * (1 if sharded else world)
     value = proofs_total / dt
