@@ -7,9 +7,11 @@
 //
 // Pipeline (all on one stream):
 //   digits   : every canonical scalar -> W signed c-bit digits; zero digits and identity bases are
-//              dropped; survivors become (bucket, table index | sign) entries, compacted with a
-//              deterministic prefix sum.
-//   sort     : rocPRIM radix sort of the entries by bucket (c-1 key bits).
+//              dropped; survivors become one 64-bit entry each (bucket << 32 | table index | sign),
+//              compacted with a deterministic prefix sum - or, for uniform scalars (the h MSM), written
+//              at a fixed window-major stride with a filler key for the rare zero digit (no count, no
+//              prefix sum, no host wait).
+//   sort     : rocPRIM Onesweep on the key bits only (c-1, +1 in the dense form), ten bits per pass.
 //   accumulate: the sorted list is cut into equal segments, one per lane, so every lane of every
 //              wave performs the same number of mixed additions regardless of how skewed the
 //              buckets are (circom witnesses are dominated by 0/1 wires).  A lane flushes runs that
