@@ -224,6 +224,10 @@ def main():
                                              "(+ %.2fs key decode, not counted)" % (threads, ctm["total_s"], ctm["load_s"]),
                                    "host_cores_available": cores, "proof_bytes_identical_to_gpu": bool(same),
                                    "phase_s": {k: round(v, 3) for k, v in ctm.items()}, "wall_s": round(wall, 2)}
+            g1_s = sum(ctm.get(k, 0.0) for k in ("msm_h_s", "msm_l_s", "msm_a_s", "msm_b1_s"))
+            if g1_s > 0 and extra.get("msm_g1_pairs_per_proof"):
+                # the metric's second half on the CPU side: (base, scalar) pairs of the four G1 MSMs per second of MSM time
+                out["cpu_baseline"]["g1_msm_scalar_adds_per_s"] = round(extra["msm_g1_pairs_per_proof"] / g1_s, 1)
             assert same, "CPU restatement and HIP path disagree on the proof bytes"
         except Exception as e:  # the baseline is a reported number, never the thing measured
             out["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
