@@ -45,17 +45,6 @@ CG_HD void store_limbs(const Fq29& f, uint32_t* w) {
 }
 CG_HD void store_limbs(const Fq2_29& f, uint32_t* w) { store_limbs(f.c0, w); store_limbs(f.c1, w + 9); }
 
-// b ? y : x without a conditional move (v_cndmask_b32 issues ~5x slower than a logic op on gfx950:
-// profiles/r01_valu_issue_rates.txt): x ^ ((x ^ y) & mask)
-CG_HD Fq29 select29(const Fq29& x, const Fq29& y, bool b) {
-    const uint32_t m = 0u - (uint32_t)b;
-    Fq29 r;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) r.l[i] = x.l[i] ^ ((x.l[i] ^ y.l[i]) & m);
-    return r;
-}
-CG_HD Fq2_29 select29(const Fq2_29& x, const Fq2_29& y, bool b) { return {select29(x.c0, y.c0, b), select29(x.c1, y.c1, b)}; }
-
 #if defined(__HIPCC__)
 // table point i of `table` (AFF words each), y negated when `negate`
 template <class F>
@@ -72,7 +61,7 @@ CG_HD Affine29<F> load_table_point(const uint32_t* __restrict__ table, uint32_t 
     load_coord(a.x, w);
     load_coord(a.y, w + AFF / 2);
     F ny = normalize(sub<2, 1>(F::zero(), a.y));   // 2N - y
-    a.y = select29(a.y, ny, negate);
+    if (negate) a.y = ny;
     return a;
 }
 
@@ -102,7 +91,7 @@ CG_HD Affine29<F> unpack_point(const RawPoint29<F>& r, bool negate) {
     load_coord(a.x, w);
     load_coord(a.y, w + AFF / 2);
     F ny = normalize(sub<2, 1>(F::zero(), a.y));
-    a.y = select29(a.y, ny, negate);
+    if (negate) a.y = ny;
     return a;
 }
 

@@ -391,7 +391,7 @@ __device__ __forceinline__ Fq2_29 load_table_coord2(const uint32_t* __restrict__
     load_coord(c, w);
     if (which == 1) {
         Fq2_29 nc = normalize(sub<2, 1>(Fq2_29::zero(), c));
-        c = select29(c, nc, negate);
+        if (negate) c = nc;
     }
     return c;
 }
