@@ -745,7 +745,6 @@ void MsmEngine<F>::digits(const Fr* scalars_dev, uint64_t n, hipStream_t st) {
 
 template <class F>
 void MsmEngine<F>::accumulate(hipStream_t st) {
-    const uint32_t wins = bases->precomputed ? 1u : (uint32_t)bases->W;
     const uint32_t nb = 1u << (bases->c - 1);
     n_entries = 0;
     n_nonzero = 0;

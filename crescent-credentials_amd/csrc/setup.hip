@@ -43,8 +43,7 @@ static G2Affine g2_generator() {
              fq_from_decimal("4082367875863433681332203403145435568316851327593401208105741076214120093531")}};
 }
 
-static constexpr int FB_WIN = 8;
-static constexpr int FB_NWIN = 32;
+static constexpr int FB_NWIN = 32;   // 32 windows of 8 bits
 
 // table[j*256 + d] = d * 2^(8j) * gen
 template <class F>
