@@ -205,3 +205,53 @@ def test_rust_shim_bindings_match_header():
     assert [f for f, _ in api._CgOptions._fields_] == _c_struct_fields("cg_options")
     assert [f for f, _ in api.CgTimings._fields_] == _c_struct_fields("cg_timings")
     assert [f for f, _ in api._CgProvingKey._fields_] == _c_struct_fields("cg_proving_key")
+
+
+def test_parsers_survive_mutated_input(cc, oracle):
+    """the two parsers of untrusted bytes (.r1cs, ark-serialize proving key) either succeed or return an error on
+    randomly corrupted, truncated and extended input - never crash, never hand out a view past their buffers"""
+    import random
+    from crescent_credentials_amd import api
+    L = cc.lib()
+    rng = random.Random(7)
+    base = bytearray(bytes.fromhex(K["r1cs_sample_hex"]))
+    parsed = 0
+    for _ in range(3000):
+        b = bytearray(base)
+        for _ in range(rng.choice([1, 1, 2, 4, 8])):
+            pos = rng.randrange(len(b))
+            b[pos] = rng.choice([0, 0xFF, b[pos] ^ (1 << rng.randrange(8)), rng.randrange(256)])
+        if rng.random() < 0.2:
+            b = b[:rng.randrange(len(b) + 1)]
+        if rng.random() < 0.05:
+            b += bytes(rng.randrange(256) for _ in range(rng.randrange(40)))
+        arr = (ctypes.c_uint8 * max(1, len(b))).from_buffer_copy(bytes(b) or b"\0")
+        h = ctypes.c_void_p()
+        if L.cg_r1cs_parse(arr, len(b), ctypes.byref(h)) == 0:
+            parsed += 1
+            hdr = api._CgR1csHeader(); abc = (api._CgCsr * 3)(); wm = ctypes.c_void_p()
+            assert L.cg_r1cs_get(h, ctypes.byref(hdr), abc, ctypes.byref(wm)) == 0
+            for m in abc:                                    # walk what the views claim to cover
+                n = int(m.nnz)
+                if n:
+                    cols = np.ctypeslib.as_array(ctypes.cast(m.col, ctypes.POINTER(ctypes.c_uint32)), shape=(n,))
+                    assert int(cols.max()) < hdr.n_wires
+            L.cg_r1cs_free(h)
+    assert parsed > 100
+    mats = ([[(1, 1)], [(2, 2)]], [[(1, 2)], [(1, 1)]], [[(1, 3)], [(3, 0)]])
+    pk, _ = oracle.generate_parameters(mats, 2, 2, 4, 11, 12, 13, 14)
+    blob = bytearray(oracle.pk_uncompressed(pk))
+    parsed = 0
+    for _ in range(3000):
+        b = bytearray(blob)
+        for _ in range(rng.choice([1, 2, 4])):
+            b[rng.randrange(len(b))] = rng.choice([0, 0xFF, rng.randrange(256)])
+        if rng.random() < 0.3:
+            b = b[:rng.randrange(len(b) + 1)]
+        arr = (ctypes.c_uint8 * max(1, len(b))).from_buffer_copy(bytes(b) or b"\0")
+        h = ctypes.c_void_p(); used = ctypes.c_uint64()
+        if L.cg_pk_parse(arr, len(b), ctypes.byref(h), ctypes.byref(used)) == 0:
+            parsed += 1
+            assert used.value <= len(b)
+            L.cg_pk_free(h)
+    assert parsed > 100
