@@ -156,6 +156,8 @@ def main():
     # one-time per-circuit tuning (the window re-tune that follows the first proof of a context) belongs to circuit
     # loading, not to the steady state that W warm-up + K timed steps measure: run it before both, whatever W is
     one_proof()
+    if not sharded:
+        run_proofs(inflight)          # ... and one proof on every slot (each captures its reduction graphs on first use)
     torch.cuda.synchronize()
     dt = timed_run(a.steps, a.warmup)
     proofs_total = a.steps * (1 if sharded else world)
