@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--mode", default="throughput", choices=["throughput", "sharded"])
     ap.add_argument("--witness", default="circom", choices=["circom", "uniform"],
                     help="wire distribution of the headline run: circom = 45%% zero / 45%% one / 10%% uniform")
+    ap.add_argument("--profile", default="gates", choices=["gates", "r1"],
+                    help="synthetic matrix mix: gates = circomlib gate mix, ~11 terms per row (SURVEY 8d); r1 = round 1's "
+                         "booleanity + short product rows, ~3.4 terms per row (kept for A/B against round-1 numbers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-uniform", action="store_true", help="skip the secondary uniform-witness measurement")
     ap.add_argument("--window", type=int, default=0)
@@ -101,7 +104,7 @@ def main():
     # ---- workload (identical on every rank: same seeds) ------------------------------------------
     t0 = time.time()
     bits = 0.9 if a.witness == "circom" else 0.0
-    cm, w_np = wl.synthetic_circuit(0xC5E5CE47 + 3, l, m, M, bits, 3)
+    cm, w_np = wl.synthetic_circuit(0xC5E5CE47 + 3, l, m, M, bits, 3, profile=a.profile)
     rng = random.Random(0xC5E5CE47)
     trap = [rng.randrange(1, R) for _ in range(4)]
     pk = cc.generate_parameters_with_qap(cm, *trap)
@@ -196,8 +199,9 @@ def main():
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u32 limbs (BN254 Fq/Fr, 254-bit modular integers)",
         "data": "synthetic",
-        "config": {"workload": "%s shape: D=2^%d, m=%d, M=%d, l=%d; witness=%s; pk from seeded trapdoor (GPU setup)" %
-                   (a.shape, prover.domain_size.bit_length() - 1, m, M, l, a.witness),
+        "config": {"workload": "%s shape: D=2^%d, m=%d, M=%d, l=%d, nnz=%d (%s mix); witness=%s; pk from seeded trapdoor (GPU setup)" %
+                   (a.shape, prover.domain_size.bit_length() - 1, m, M, l, cm.a.nnz + cm.b.nnz + cm.c.nnz, a.profile, a.witness),
+                   "wires": wl.wire_stats(w_np),
                    "mode": a.mode, "h_query_basis": "coefficient" if a.h_coefficient_basis else "coset evaluation (transformed at load)",
                    "proofs_per_rank": a.steps, "proofs_in_flight_per_gpu": inflight,
                    "inputs": "witness resident in HBM; (r,s) fresh per proof"},
@@ -238,7 +242,7 @@ def main():
 
     # ---- secondary: uniform-witness run (defines the headline G1 scalar-adds/s per SURVEY §8d) --------
     if rank == 0 and world == 1 and not a.no_uniform and a.witness == "circom":
-        cm_u, wu_np = wl.synthetic_circuit(0xC5E5CE47 + 4, l, m, M, 0.0, 3)
+        cm_u, wu_np = wl.synthetic_circuit(0xC5E5CE47 + 4, l, m, M, 0.0, 3, profile=a.profile)
         pk_u = cc.generate_parameters_with_qap(cm_u, *trap)
         prover.close()
         pu = cc.Prover(pk_u, cm_u, device=local_rank, window_bits=a.window, proof_slots=inflight,

@@ -35,6 +35,8 @@ def _lib():
         L = C.CDLL(_SYNTH_PATH)
         L.cgs_generate.restype = C.c_void_p
         L.cgs_generate.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double, C.c_uint32]
+        L.cgs_generate_gates.restype = C.c_void_p
+        L.cgs_generate_gates.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double, C.c_uint32]
         L.cgs_views.restype = None
         L.cgs_views.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                 C.POINTER(C.c_uint64), C.POINTER(C.c_void_p)]
@@ -45,11 +47,19 @@ def _lib():
 
 
 def synthetic_circuit(seed: int, num_inputs: int, num_constraints: int, num_variables: int,
-                      bit_fraction: float = 0.9, lc_terms: int = 3):
+                      bit_fraction: float = 0.9, lc_terms: int = 3, profile: str = "r1"):
     """-> (ConstraintMatrices, witness uint8[M*32] canonical).  bit_fraction 0.9 = 'circom-like' wires
-    (45 % zero / 45 % one / 10 % uniform), 0.0 = all-uniform wires."""
+    (45 % zero / 45 % one / 10 % uniform), 0.0 = all-uniform wires.
+    profile "r1": booleanity + short product rows (≈3.4 terms per row over A, B, C; lc_terms = mean terms of a
+    product row's side); profile "gates": the circomlib gate mix of synth.cpp's cgs_generate_gates (≈11.5 terms
+    per row as the real main_c.r1cs files have; lc_terms is ignored: the bigint rows get `gates_limb_terms` limbs a side)."""
     L = _lib()
-    h = L.cgs_generate(seed, num_inputs, num_constraints, num_variables, bit_fraction, lc_terms)
+    if profile == "gates":
+        h = L.cgs_generate_gates(seed, num_inputs, num_constraints, num_variables, bit_fraction, gates_limb_terms(bit_fraction))
+    elif profile == "r1":
+        h = L.cgs_generate(seed, num_inputs, num_constraints, num_variables, bit_fraction, lc_terms)
+    else:
+        raise ValueError("profile must be 'r1' or 'gates'")
     if not h:
         raise ValueError("unsupported shape (need num_variables - num_inputs >= num_constraints >= 1)")
     try:
@@ -71,6 +81,27 @@ def synthetic_circuit(seed: int, num_inputs: int, num_constraints: int, num_vari
         L.cgs_free(h)
     cm = ConstraintMatrices(mats[0], mats[1], mats[2], num_inputs, num_variables - num_inputs, num_constraints)
     return cm, w
+
+
+TERMS_PER_ROW = 11.5     # 17 M terms over 1.48 M rows (from the 595 MB main_c.r1cs)
+
+
+def gates_limb_terms(bit_fraction: float) -> int:
+    """Limbs per side of the bigint product rows such that the whole instance keeps ≈ TERMS_PER_ROW terms per row
+    whatever share of the rows are bit gates (those average ≈ 8.5 terms): 17 at bit_fraction 0.9, the RSA-2048
+    limb count of circuit_setup/scripts/prepare_setup.py:42-43."""
+    bf = min(max(bit_fraction, 0.0), 0.97)
+    per_product_row = (TERMS_PER_ROW - bf * 8.5) / (1.0 - bf)
+    return max(2, int(round((per_product_row - 3.0) / 2.1)))
+
+
+def wire_stats(w: np.ndarray) -> dict:
+    """share of zero / one / other wires of a canonical witness (drives the assignment MSMs' digit counts)"""
+    W = w.reshape(-1, 32)
+    rest_zero = ~W[:, 1:].any(axis=1)
+    zero = float((rest_zero & (W[:, 0] == 0)).mean())
+    one = float((rest_zero & (W[:, 0] == 1)).mean())
+    return {"zero": round(zero, 4), "one": round(one, 4), "other": round(1.0 - zero - one, 4)}
 
 
 def matrices_to_rows(cm: ConstraintMatrices):

@@ -95,11 +95,14 @@ static inline void fe_neg(const field_t* F, fe* r, const fe* a) {
     fe_sub(F, r, &z, a);
 }
 static inline void fe_dbl(const field_t* F, fe* r, const fe* a) { fe_add(F, r, a, a); }
-/* Montgomery multiplication, coarsely integrated operand scanning */
-static void fe_mul(const field_t* F, fe* r, const fe* a, const fe* b) {
+/* Montgomery multiplication, coarsely integrated operand scanning; always inlined so that the field constants
+ * fold in and the loops unroll (the shape of ark-ff's generated code for a 4-limb modulus) */
+static inline __attribute__((always_inline)) void fe_mul(const field_t* F, fe* r, const fe* a, const fe* b) {
     uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+_Pragma("GCC unroll 4")
     for (int i = 0; i < 4; ++i) {
         u128 c = 0;
+_Pragma("GCC unroll 4")
         for (int j = 0; j < 4; ++j) {
             c += (u128)a->l[j] * b->l[i] + t[j];
             t[j] = (uint64_t)c;
@@ -111,6 +114,7 @@ static void fe_mul(const field_t* F, fe* r, const fe* a, const fe* b) {
         uint64_t m = t[0] * F->ninv;
         c = (u128)m * F->n[0] + t[0];
         c >>= 64;
+_Pragma("GCC unroll 4")
         for (int j = 1; j < 4; ++j) {
             c += (u128)m * F->n[j] + t[j];
             t[j - 1] = (uint64_t)c;
@@ -352,26 +356,62 @@ static uint64_t bitrev(uint64_t x, int bits) {
     for (int i = 0; i < bits; ++i) { r = (r << 1) | (x & 1); x >>= 1; }
     return r;
 }
-/* in place, natural order in and out: a[k] <- Σ_j a[j] w^{jk} */
+/* in place, natural order in and out: a[k] <- Σ_j a[j] w^{jk}.
+ * Same butterflies as the textbook loop (bit reversal, then log n decimation-in-time stages), arranged the way a
+ * multi-core radix-2 library runs them (ark-poly's parallel FFT splits the same way): the powers of w come from
+ * per-thread geometric runs, the first NTT_BLOCK_LOG stages run block by block inside the cache, and each later
+ * stage is one parallel sweep with unit-stride inner loops. */
+#define NTT_BLOCK_LOG 12
 static void ntt_inplace(fe* a, int logn, const fe* w, int nthreads) {
     const uint64_t n = 1ull << logn;
+    if (n == 1) return;
+    _Pragma("omp parallel for schedule(static) num_threads(nthreads)")
     for (uint64_t i = 0; i < n; ++i) {
         uint64_t j = bitrev(i, logn);
         if (i < j) { fe t = a[i]; a[i] = a[j]; a[j] = t; }
     }
-    fe* tw = (fe*)malloc(sizeof(fe) * (n > 1 ? n / 2 : 1));
-    tw[0] = FR.one;
-    for (uint64_t i = 1; i < n / 2; ++i) fe_mul(&FR, &tw[i], &tw[i - 1], w);
-    for (int s = 1; s <= logn; ++s) {
+    const uint64_t nh = n / 2;
+    fe* tw = (fe*)malloc(sizeof(fe) * nh);
+    _Pragma("omp parallel num_threads(nthreads)")
+    {
+        int t = omp_get_thread_num(), T = omp_get_num_threads();
+        uint64_t lo = nh * t / T, hi = nh * (t + 1) / T;
+        if (lo < hi) {
+            uint64_t e[4] = {lo, 0, 0, 0};
+            fe p; fe_pow(&FR, &p, w, e);
+            for (uint64_t i = lo; i < hi; ++i) { tw[i] = p; fe_mul(&FR, &p, &p, w); }
+        }
+    }
+    const int blk_log = logn < NTT_BLOCK_LOG ? logn : NTT_BLOCK_LOG;
+    const uint64_t blk = 1ull << blk_log;
+    _Pragma("omp parallel for schedule(static) num_threads(nthreads)")
+    for (uint64_t b0 = 0; b0 < n; b0 += blk) {
+        fe* x = a + b0;
+        for (int s = 1; s <= blk_log; ++s) {
+            const uint64_t len = 1ull << s, half = len >> 1, step = n / len;
+            for (uint64_t i0 = 0; i0 < blk; i0 += len)
+                for (uint64_t k = 0; k < half; ++k) {
+                    fe v, u = x[i0 + k];
+                    fe_mul(&FR, &v, &x[i0 + k + half], &tw[k * step]);
+                    fe_add(&FR, &x[i0 + k], &u, &v);
+                    fe_sub(&FR, &x[i0 + k + half], &u, &v);
+                }
+        }
+    }
+    for (int s = blk_log + 1; s <= logn; ++s) {
         const uint64_t len = 1ull << s, half = len >> 1, step = n / len;
+        const uint64_t chunk = 1024;                       /* butterflies per task; half >= 4096 here */
         _Pragma("omp parallel for schedule(static) num_threads(nthreads)")
-        for (uint64_t b = 0; b < n / 2; ++b) {
-            uint64_t blk = b / half, k = b % half;
-            uint64_t i0 = blk * len + k, i1 = i0 + half;
-            fe v, u = a[i0];
-            fe_mul(&FR, &v, &a[i1], &tw[k * step]);
-            fe_add(&FR, &a[i0], &u, &v);
-            fe_sub(&FR, &a[i1], &u, &v);
+        for (uint64_t c0 = 0; c0 < nh; c0 += chunk) {
+            const uint64_t blkidx = c0 / half, k0 = c0 % half;
+            fe* x0 = a + blkidx * len + k0;
+            fe* x1 = x0 + half;
+            for (uint64_t k = 0; k < chunk; ++k) {
+                fe v, u = x0[k];
+                fe_mul(&FR, &v, &x1[k], &tw[(k0 + k) * step]);
+                fe_add(&FR, &x0[k], &u, &v);
+                fe_sub(&FR, &x1[k], &u, &v);
+            }
         }
     }
     free(tw);
@@ -522,10 +562,12 @@ int ref_ntt(uint8_t* data, int logn, int inverse, int coset, int nthreads) {
 }
 int ref_witness_map(const csr_t abc[3], uint64_t l, uint64_t m, uint64_t M, const uint8_t* w_bytes, uint8_t* h_out, int nthreads) {
     fe* w = (fe*)malloc(sizeof(fe) * M);
+    _Pragma("omp parallel for num_threads(nthreads)")
     for (uint64_t i = 0; i < M; ++i) fe_from_canonical(&FR, &w[i], w_bytes + 32 * i);
     fe* h; uint64_t D = witness_map(abc, l, m, w, &h, nthreads);
     free(w);
     if (!D) return -5;
+    _Pragma("omp parallel for num_threads(nthreads)")
     for (uint64_t i = 0; i < D; ++i) fe_to_canonical(&FR, h_out + 32 * i, &h[i]);
     free(h);
     return 0;
@@ -565,6 +607,7 @@ int ref_prove(const ref_pk* pk, const csr_t abc[3], uint64_t l, uint64_t m, uint
     aff1_load(&alpha_g1, pk->alpha_g1); aff1_load(&beta_g1, pk->beta_g1); aff1_load(&delta_g1, pk->delta_g1);
     aff2_load(&beta_g2, pk->beta_g2); aff2_load(&delta_g2, pk->delta_g2);
     fe* w = (fe*)malloc(sizeof(fe) * M);
+    _Pragma("omp parallel for num_threads(nthreads)")
     for (uint64_t i = 0; i < M; ++i) fe_from_canonical(&FR, &w[i], w_bytes + 32 * i);
     double t_loaded = omp_get_wtime();
 
@@ -575,6 +618,7 @@ int ref_prove(const ref_pk* pk, const csr_t abc[3], uint64_t l, uint64_t m, uint
 
     /* into_bigint (prover.rs:63-65,70-72,84-89) */
     uint64_t (*h_big)[4] = (uint64_t(*)[4])malloc(32 * D);
+    _Pragma("omp parallel for num_threads(nthreads)")
     for (uint64_t i = 0; i < D; ++i) fe_to_canonical(&FR, (uint8_t*)h_big[i], &h[i]);
     const uint64_t (*w_big)[4] = (const uint64_t(*)[4])w_bytes;   /* canonical scalars as given */
     uint64_t r[4], s[4];
