@@ -7,9 +7,12 @@ arithmetic itself and raises if the HIP library is missing (there is no CPU fall
 """
 from .api import (  # noqa: F401
     CrescentGpuError,
+    CircomCircuit,
     ConstraintMatrices,
     Groth16,
     LibsnarkReduction,
+    QapContext,
+    R1CSToQAP,
     MsmContext,
     NttContext,
     Proof,

@@ -87,6 +87,10 @@ _SIGNATURES = {
     "cg_assemble": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cg_witness_map": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cg_domain_size": (C.c_uint64, [C.c_void_p]),
+    "cg_qap_load": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(_CgCsr), C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32]),
+    "cg_qap_witness_map": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "cg_qap_domain_size": (C.c_uint64, [C.c_void_p]),
+    "cg_qap_free": (None, [C.c_void_p]),
     "cg_msm_g1": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p]),
     "cg_msm_g2": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p]),
     "cg_ntt": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_int]),
@@ -347,19 +351,113 @@ class Prover:
         return h
 
 
-class LibsnarkReduction:
-    """forks/groth16/src/r1cs_to_qap.rs:100-226 (the default QAP type, lib.rs:55)."""
+class QapContext:
+    """Three constraint matrices resident on one GPU with their domain tables, no proving key (cg_qap_ctx)."""
 
-    @staticmethod
-    def witness_map_from_matrices(prover: Prover, full_assignment) -> np.ndarray:
-        """r1cs_to_qap.rs:150-213 on a loaded circuit -> h coefficients (domain_size x 32 B canonical)."""
-        return prover.witness_map(full_assignment)
+    def __init__(self, matrices: ConstraintMatrices, device: int = -1):
+        self.num_inputs = matrices.num_instance_variables
+        self.num_constraints = matrices.num_constraints
+        self.num_variables = matrices.num_variables
+        abc, _keep = matrices._c()
+        self._h = C.c_void_p()
+        _check(lib().cg_qap_load(C.byref(self._h), abc, self.num_inputs, self.num_constraints, self.num_variables, device))
+        self.domain_size = int(lib().cg_qap_domain_size(self._h))
+
+    def witness_map(self, full_assignment) -> np.ndarray:
+        w = _u8(full_assignment, self.num_variables * 32)
+        h = np.zeros(self.domain_size * 32, dtype=np.uint8)
+        _check(lib().cg_qap_witness_map(self._h, _ptr(w), 0, _ptr(h), 0))
+        return h
+
+    def witness_map_dev(self, d_assignment: int, d_h: int) -> None:
+        """assignment (num_variables x 32 B) and h (domain_size x 32 B) both in this GPU's memory"""
+        _check(lib().cg_qap_witness_map(self._h, C.c_void_p(d_assignment), 1, C.c_void_p(d_h), 1))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().cg_qap_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class R1CSToQAP:
+    """forks/groth16/src/r1cs_to_qap.rs:49-98: the trait `Groth16<E, QAP>` is generic over (lib.rs:55-57).  The
+    prover's half is `witness_map_from_matrices`; the generator's half (`instance_map_with_evaluation`,
+    `h_query_scalars`, :52-56,82-97) is what `generate_parameters_with_qap` -> cg_setup evaluates on the GPU."""
+
+    @classmethod
+    def witness_map_from_matrices(cls, matrices: ConstraintMatrices, num_inputs: int, num_constraints: int,
+                                  full_assignment) -> np.ndarray:
+        raise NotImplementedError
+
+
+class LibsnarkReduction(R1CSToQAP):
+    """forks/groth16/src/r1cs_to_qap.rs:100-226, the default QAP type (lib.rs:55), on the GPU.  The reference's call
+    is stateless; the matrices' device copy is kept per matrices object (strong reference, identity-checked, at most
+    MAX_CACHED resident) so that repeated calls only move the assignment."""
+    MAX_CACHED = 4
+    _cache = {}     # id(matrices) -> (matrices, QapContext)
+
+    @classmethod
+    def _context_for(cls, matrices: ConstraintMatrices) -> QapContext:
+        key = id(matrices)
+        hit = cls._cache.pop(key, None)
+        if hit is not None and hit[0] is matrices and hit[1]._h.value:
+            cls._cache[key] = hit
+            return hit[1]
+        if hit is not None:
+            hit[1].close()
+        ctx = QapContext(matrices)
+        cls._cache[key] = (matrices, ctx)
+        while len(cls._cache) > cls.MAX_CACHED:
+            cls._cache.pop(next(iter(cls._cache)))[1].close()
+        return ctx
+
+    @classmethod
+    def witness_map_from_matrices(cls, matrices: ConstraintMatrices, num_inputs: int, num_constraints: int,
+                                  full_assignment) -> np.ndarray:
+        """r1cs_to_qap.rs:150-213 -> the coefficients of h, domain_size x 32 B canonical.  Raises CrescentGpuError
+        with code CG_ERR_POLY_DEGREE_TOO_LARGE where the reference returns PolynomialDegreeTooLarge (:156-157)."""
+        if num_inputs != matrices.num_instance_variables or num_constraints != matrices.num_constraints:
+            raise ValueError("num_inputs/num_constraints disagree with the matrices")
+        return cls._context_for(matrices).witness_map(full_assignment)
+
+    @classmethod
+    def clear_cache(cls):
+        for _, ctx in cls._cache.values():
+            ctx.close()
+        cls._cache.clear()
 
 
 class Groth16:
-    """forks/groth16/src/lib.rs:55-57 / prover.rs.  Loaded circuits are cached per (pk, matrices) object pair,
-    since the reference's stateless call shape would otherwise re-upload the key for every proof."""
-    _cache = {}
+    """forks/groth16/src/lib.rs:55-57 / prover.rs.  The reference's calls are stateless; here a loaded circuit (key
+    tables + matrices in HBM) is kept per (pk, matrices) object pair, since re-uploading a 0.6 GB key for every proof
+    would defeat the point.  The cache holds strong references to both objects (an id() can be reused once an object
+    is collected) and checks identity on a hit; at most `MAX_CACHED` circuits stay resident, the least recently used
+    one is closed first."""
+    MAX_CACHED = 4
+    _cache = {}          # (id(pk), id(matrices)) -> (pk, matrices, Prover); insertion order = recency
+
+    @classmethod
+    def _prover_for(cls, pk: ProvingKey, matrices: ConstraintMatrices) -> Prover:
+        key = (id(pk), id(matrices))
+        hit = cls._cache.pop(key, None)
+        if hit is not None and hit[0] is pk and hit[1] is matrices and hit[2]._h:
+            cls._cache[key] = hit                      # move to the most-recent end
+            return hit[2]
+        if hit is not None:
+            hit[2].close()
+        pr = Prover(pk, matrices)
+        cls._cache[key] = (pk, matrices, pr)
+        while len(cls._cache) > cls.MAX_CACHED:
+            oldest = next(iter(cls._cache))
+            cls._cache.pop(oldest)[2].close()
+        return pr
 
     @classmethod
     def create_proof_with_reduction_and_matrices(cls, pk: ProvingKey, r: int, s: int, matrices: ConstraintMatrices,
@@ -367,18 +465,64 @@ class Groth16:
         """prover.rs:26-51."""
         if num_inputs != matrices.num_instance_variables or num_constraints != matrices.num_constraints:
             raise ValueError("num_inputs/num_constraints disagree with the matrices")
-        key = (id(pk), id(matrices))
-        pr = cls._cache.get(key)
-        if pr is None:
-            pr = Prover(pk, matrices)
-            cls._cache[key] = pr
-        return pr.prove(full_assignment, r, s)
+        return cls._prover_for(pk, matrices).prove(full_assignment, r, s)
+
+    @classmethod
+    def create_proof_with_reduction(cls, circuit: "CircomCircuit", pk: ProvingKey, r: int, s: int) -> Proof:
+        """prover.rs:177-221.  The reference synthesises the constraint system from the circuit on every call
+        (circuit.rs:29-86) and extracts the matrices (r1cs_to_qap.rs:58-80); here the matrices ARE the circuit's
+        R1CS (column = wire id, circuit.rs:61-67) and stay resident, so only the witness travels."""
+        if circuit.witness is None:
+            raise CrescentGpuError(-1, "AssignmentMissing: the circuit has no witness (SynthesisError::AssignmentMissing, circuit.rs:38-45)")
+        cm = circuit.r1cs.matrices
+        return cls.create_proof_with_reduction_and_matrices(pk, r, s, cm, cm.num_instance_variables, cm.num_constraints,
+                                                            circuit.full_assignment())
+
+    @classmethod
+    def prove(cls, pk: ProvingKey, circuit: "CircomCircuit", rng) -> Proof:
+        """`SNARK::prove` (lib.rs:76-82) -> create_random_proof_with_reduction (prover.rs:142-154): r and s are
+        sampled from `rng` (any object with randrange, e.g. random.Random / random.SystemRandom), r first."""
+        r = rng.randrange(FR_MODULUS)
+        s = rng.randrange(FR_MODULUS)
+        return cls.create_proof_with_reduction(circuit, pk, r, s)
+
+    @classmethod
+    def create_proof_no_zk(cls, circuit: "CircomCircuit", pk: ProvingKey) -> Proof:
+        """prover.rs:160-173 (r = s = 0)."""
+        return cls.create_proof_with_reduction(circuit, pk, 0, 0)
 
     @classmethod
     def clear_cache(cls):
-        for p in cls._cache.values():
+        for _, _, p in cls._cache.values():
             p.close()
         cls._cache.clear()
+
+
+class CircomCircuit:
+    """forks/circom-compat/src/circom/circuit.rs:11-27: an R1CS plus (optionally) the witness the WASM calculator
+    produced for it.  `witness` is the full wire assignment in wire order (wire 0 = 1), canonical 32-byte scalars or
+    Python ints; instance wires come first (circuit.rs:61-67), so it is also the prover's `full_assignment`."""
+
+    def __init__(self, r1cs: "R1CSFile", witness=None):
+        self.r1cs = r1cs
+        self.witness = None
+        if witness is not None:
+            self.set_witness(witness)
+
+    def set_witness(self, witness):
+        if isinstance(witness, (list, tuple)):
+            witness = scalars_to_array([int(x) % FR_MODULUS for x in witness])
+        self.witness = _u8(witness, self.r1cs.num_variables * 32)
+
+    def full_assignment(self) -> np.ndarray:
+        return self.witness
+
+    def get_public_inputs(self):
+        """circuit.rs:18-26: wires 1 .. num_inputs-1 as integers (None without a witness)"""
+        if self.witness is None:
+            return None
+        b = self.witness[32:32 * self.r1cs.num_inputs].tobytes()
+        return [int.from_bytes(b[i:i + 32], "little") for i in range(0, len(b), 32)]
 
 
 def generate_parameters_with_qap(matrices: ConstraintMatrices, alpha: int, beta: int, delta: int, tau: int) -> ProvingKey:

@@ -187,6 +187,12 @@ void MsmBases<F>::rebuild(int c_new, hipStream_t st) {
     if (!precomputed || c_new == c || !n) return;
     const int W_new = (SCALAR_BITS + c_new - 1) / c_new;
     if ((uint64_t)W_new * n >= (1ull << 31)) return;
+    {   // the old and the new table coexist until the swap: never re-tune into an out-of-memory failure
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+        const uint64_t need = (uint64_t)W_new * n * AFF * 4;
+        if (need + (2ull << 30) > free_b) return;
+    }
     DevBuf<uint32_t> t2((uint64_t)W_new * n * AFF);
     CG_HIP(hipMemcpyAsync(t2.p, table.p, n * AFF * 4, hipMemcpyDeviceToDevice, st));   // row 0 = the bases themselves
     for (int j = 1; j < W_new; ++j) {

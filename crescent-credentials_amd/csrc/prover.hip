@@ -5,6 +5,7 @@
 // which algebraic order), re-laid-out for one MI355X: the proving key lives in HBM as per-window
 // base tables, the five MSMs and the witness map run on separate HIP streams, and only the few
 // scalar multiplications by r, s and the final additions run on the host.
+#include <atomic>
 #include <condition_variable>
 #include <shared_mutex>
 #include <memory>
@@ -19,6 +20,8 @@
 #include "wmap29.hpp"
 
 namespace cg {
+
+const char* csr_view_problem(const cg_csr& m);   // unit.hip
 
 std::string& last_error() {
     static thread_local std::string e;
@@ -163,7 +166,7 @@ struct cg_ctx {
     // window tuning: the window of each assignment-driven query is re-chosen once from the digit statistics of
     // the first proof (circom witnesses are mostly 0/1 wires, for which the size-based default is far too wide)
     bool fixed_window = false;
-    bool tuned = false;
+    std::atomic<bool> tuned{false};   // read outside tune_mu by every finished proof
     std::shared_mutex tune_mu;   // proofs hold it shared; a retune holds it exclusively
     std::mutex pick_mu;
     std::condition_variable pick_cv;
@@ -251,6 +254,15 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
     *out = nullptr;
     if (num_inputs == 0 || num_inputs > num_variables) return fail(CG_ERR_INVALID_ARGUMENT, "need 1 <= num_inputs <= num_variables");
     if (pk->coord_form != CG_FORM_CANONICAL && pk->coord_form != CG_FORM_MONTGOMERY) return fail(CG_ERR_INVALID_ARGUMENT, "bad coord_form");
+    // every pointer the structs carry is checked before anything is read through it (a half-filled struct from the
+    // C or Rust side must come back as an error, not a fault)
+    if (!pk->alpha_g1 || !pk->beta_g1 || !pk->delta_g1 || !pk->beta_g2 || !pk->delta_g2)
+        return fail(CG_ERR_INVALID_ARGUMENT, "null key point (alpha_g1 / beta_g1 / delta_g1 / beta_g2 / delta_g2)");
+    if ((pk->a_len && !pk->a_query) || (pk->b_g1_len && !pk->b_g1_query) || (pk->b_g2_len && !pk->b_g2_query) ||
+        (pk->h_len && !pk->h_query) || (pk->l_len && !pk->l_query))
+        return fail(CG_ERR_INVALID_ARGUMENT, "null query pointer with a non-zero length");
+    for (int k = 0; k < 3; ++k)
+        if (const char* why = csr_view_problem(abc[k])) return fail(CG_ERR_INVALID_ARGUMENT, "matrix %d: %s", k, why);
     const uint64_t l = num_inputs, m = num_constraints, M = num_variables;
     const uint64_t dom_in = m + l;
     const int logD = ilog2_ceil(dom_in);
@@ -533,6 +545,10 @@ static void maybe_retune(cg_ctx* c) {
     ProofSlot* S = nullptr;
     for (auto& sl : c->slots) if (sl->el.n_scalars || sl->ea.n_scalars) { S = sl.get(); break; }
     if (!S) return;
+    // A degenerate first assignment (all zero, or next to it) says nothing about the proofs to come: its statistics
+    // would pick the narrowest window and the widest tables for good.  Keep the size-based windows and wait for a
+    // representative proof instead.
+    if ((uint64_t)S->ea.n_nonzero * 64 < S->ea.n_scalars) return;
     CG_HIP(hipSetDevice(c->device));
     hipStream_t st = S->st[0];
     retune_query<Fq>(c, c->bl, &ProofSlot::el, S, st);

@@ -221,6 +221,106 @@ extern "C" int cg_msm_g2(const uint8_t* bases, uint32_t coord_form, uint64_t n_b
 }
 
 // ---------------------------------------------------------------------------------------------
+// R1CS -> QAP witness map over resident matrices (no proving key): the reference's own plug point,
+// `R1CSToQAP::witness_map_from_matrices` (forks/groth16/src/r1cs_to_qap.rs:49-98,150-213)
+// ---------------------------------------------------------------------------------------------
+struct cg_qap_ctx {
+    int device = 0;
+    uint64_t l = 0, m = 0, M = 0, D = 0;
+    int logD = 0;
+    DevCsr A, B, C;
+    Csr29 dA, dB, dC;
+    NttDomain dom;
+    Wm29Domain wdom;
+    Wm29Buffers wm;
+    DevBuf<Fr> w_canon, h_canon;
+    hipStream_t st = nullptr;
+    std::mutex mu;
+    ~cg_qap_ctx() { if (st) (void)hipStreamDestroy(st); }
+};
+
+namespace cg {
+// shared with cg_circuit_load: every pointer a cg_csr view must carry for `rows` rows
+const char* csr_view_problem(const cg_csr& m) {
+    if (!m.row_ptr) return "null row_ptr";
+    if (m.nnz && (!m.col || !m.coeff)) return "null col/coeff with nnz > 0";
+    return nullptr;
+}
+}  // namespace cg
+
+extern "C" int cg_qap_load(cg_qap_ctx** out, const cg_csr abc[3], uint64_t num_inputs, uint64_t num_constraints,
+                           uint64_t num_variables, int32_t device) {
+    if (!out || !abc) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (num_inputs == 0 || num_inputs > num_variables) return fail(CG_ERR_INVALID_ARGUMENT, "need 1 <= num_inputs <= num_variables");
+    for (int k = 0; k < 3; ++k)
+        if (const char* why = csr_view_problem(abc[k])) return fail(CG_ERR_INVALID_ARGUMENT, "matrix %d: %s", k, why);
+    const int logD = ilog2_ceil(num_constraints + num_inputs);
+    if (logD > 28)                                              // r1cs_to_qap.rs:156-157
+        return fail(CG_ERR_POLY_DEGREE_TOO_LARGE, "num_constraints + num_inputs = %llu exceeds 2^28",
+                    (unsigned long long)(num_constraints + num_inputs));
+    try {
+        int dev = device;
+        if (dev < 0) CG_HIP(hipGetDevice(&dev));
+        CG_HIP(hipSetDevice(dev));
+        std::unique_ptr<cg_qap_ctx> c(new cg_qap_ctx());
+        c->device = dev;
+        c->l = num_inputs; c->m = num_constraints; c->M = num_variables;
+        c->logD = logD; c->D = 1ull << logD;
+        CG_HIP(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+        c->A.upload(abc[0], c->m, c->M);
+        c->B.upload(abc[1], c->m, c->M);
+        c->C.upload(abc[2], c->m, c->M);
+        c->dom.build(logD, true, c->st);
+        CG_HIP(hipStreamSynchronize(c->st));
+        c->wdom.build(c->dom, c->st);
+        c->dA.build(c->A, c->st); c->dB.build(c->B, c->st); c->dC.build(c->C, c->st);
+        CG_HIP(hipStreamSynchronize(c->st));
+        c->dom.tw_fwd.release(); c->dom.tw_inv.release(); c->dom.coset_br.release(); c->dom.icoset_br.release();
+        c->A.dict.release(); c->B.dict.release(); c->C.dict.release();
+        c->wm.alloc(c->M, c->D);
+        c->w_canon.alloc(c->M);
+        c->h_canon.alloc(c->D);
+        *out = c.release();
+        return CG_OK;
+    } catch (...) {
+        return translate_current_exception();
+    }
+}
+
+extern "C" uint64_t cg_qap_domain_size(const cg_qap_ctx* ctx) { return ctx ? ctx->D : 0; }
+
+extern "C" int cg_qap_witness_map(cg_qap_ctx* ctx, const void* full_assignment, int assignment_on_device, void* h_out,
+                                  int h_on_device) {
+    if (!ctx || !full_assignment || !h_out) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
+    try {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        CG_HIP(hipSetDevice(ctx->device));
+        const Fr* w = (const Fr*)full_assignment;
+        if (!assignment_on_device) {
+            CG_HIP(hipMemcpyAsync(ctx->w_canon.p, full_assignment, ctx->M * 32, hipMemcpyHostToDevice, ctx->st));
+            w = ctx->w_canon.p;
+        }
+        Fr* h = h_on_device ? (Fr*)h_out : ctx->h_canon.p;
+        wm29_run(ctx->wdom, ctx->A, ctx->B, ctx->C, ctx->dA, ctx->dB, ctx->dC, ctx->wm, w, ctx->M, ctx->m, ctx->l, h, ctx->st,
+                 false);
+        if (!h_on_device) CG_HIP(hipMemcpyAsync(h_out, ctx->h_canon.p, ctx->D * 32, hipMemcpyDeviceToHost, ctx->st));
+        CG_HIP(hipStreamSynchronize(ctx->st));
+        if (ctx->wm.h_bad_input.p[0]) return fail(CG_ERR_INVALID_ARGUMENT, "full_assignment holds a value >= the scalar field modulus");
+        return CG_OK;
+    } catch (...) {
+        return translate_current_exception();
+    }
+}
+
+extern "C" void cg_qap_free(cg_qap_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    delete ctx;
+}
+
+// ---------------------------------------------------------------------------------------------
 // NTT over a resident domain
 // ---------------------------------------------------------------------------------------------
 struct cg_ntt_ctx {

@@ -178,6 +178,23 @@ int cg_assemble(cg_ctx* ctx, const uint8_t* partials, uint32_t n_shards, const u
 int cg_witness_map(cg_ctx* ctx, const uint8_t* full_assignment, uint8_t* h_out);
 uint64_t cg_domain_size(const cg_ctx* ctx);
 
+/* The witness map over RESIDENT matrices, without a proving key: the reference's own plug point.
+ * Replaces: an `impl R1CSToQAP` (forks/groth16/src/r1cs_to_qap.rs:49-98) whose `witness_map_from_matrices`
+ *           (:150-213) is `Groth16<E, QAP>`'s type parameter (forks/groth16/src/lib.rs:55-57): a maintainer who only
+ *           swaps the QAP type (INTEGRATION.md "GpuReduction") keeps arkworks' MSMs and moves the seven transforms
+ *           and three sparse products here.  cg_qap_load copies the matrices once (the `cs.to_matrices()` product,
+ *           r1cs_to_qap.rs:62); cg_qap_witness_map returns the reference's result, the coefficients of h
+ *           (domain_size x 32 B canonical), for a full assignment in host or device memory.
+ * Errors: CG_ERR_POLY_DEGREE_TOO_LARGE as r1cs_to_qap.rs:156-157; a non-canonical assignment element is
+ *         CG_ERR_INVALID_ARGUMENT.  Calls on one handle serialise. */
+typedef struct cg_qap_ctx cg_qap_ctx;
+int cg_qap_load(cg_qap_ctx** out, const cg_csr abc[3], uint64_t num_inputs, uint64_t num_constraints,
+                uint64_t num_variables, int32_t device /* -1 = current */);
+int cg_qap_witness_map(cg_qap_ctx* ctx, const void* full_assignment, int assignment_on_device, void* h_out,
+                       int h_on_device);
+uint64_t cg_qap_domain_size(const cg_qap_ctx* ctx);
+void cg_qap_free(cg_qap_ctx* ctx);
+
 /* Unit level: Σ scalars[i]·bases[i] over BN254 G1 / G2 for caller-supplied bases.
  * Replaces: `<G as VariableBaseMSM>::msm_bigint(bases, scalars)` (ark-ec; call sites
  *           prover.rs:66,74,266).  bases in `coord_form`; scalars canonical; result affine
