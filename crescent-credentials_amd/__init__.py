@@ -8,6 +8,10 @@ arithmetic itself and raises if the HIP library is missing (there is no CPU fall
 from .api import (  # noqa: F401
     CrescentGpuError,
     CircomCircuit,
+    ClientState,
+    IOLocations,
+    ProverParams,
+    create_client_state,
     ConstraintMatrices,
     Groth16,
     LibsnarkReduction,

@@ -67,6 +67,21 @@ class CgTimings(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class _CgProverParamsView(C.Structure):
+    _fields_ = [("pk", _CgProvingKey), ("gamma_g2", C.c_void_p), ("gamma_abc_g1", C.c_void_p), ("gamma_abc_len", C.c_uint64),
+                ("vk_bytes", C.c_void_p), ("vk_len", C.c_uint64), ("pvk_bytes", C.c_void_p), ("pvk_len", C.c_uint64),
+                ("config_str", C.c_void_p), ("config_len", C.c_uint64)]
+
+
+class _CgClientStateView(C.Structure):
+    _fields_ = [("inputs", C.c_void_p), ("n_inputs", C.c_uint64), ("aux", C.c_void_p), ("aux_len", C.c_uint64),
+                ("has_aux", C.c_int32), ("has_input_com_randomness", C.c_int32), ("proof", C.c_void_p),
+                ("vk_bytes", C.c_void_p), ("vk_len", C.c_uint64), ("pvk_bytes", C.c_void_p), ("pvk_len", C.c_uint64),
+                ("input_com_randomness", C.c_void_p),
+                ("openings_bytes", C.c_void_p), ("openings_len", C.c_uint64), ("n_openings", C.c_uint64),
+                ("credtype", C.c_void_p), ("credtype_len", C.c_uint64), ("config_str", C.c_void_p), ("config_len", C.c_uint64)]
+
+
 class _CgR1csHeader(C.Structure):
     _fields_ = [("field_size", C.c_uint32), ("n_wires", C.c_uint32), ("n_pub_out", C.c_uint32),
                 ("n_pub_in", C.c_uint32), ("n_prv_in", C.c_uint32), ("n_constraints", C.c_uint32),
@@ -112,6 +127,17 @@ _SIGNATURES = {
     "cg_pk_free": (None, [C.c_void_p]),
     "cg_pk_serialized_size": (C.c_uint64, [C.POINTER(_CgProvingKey), C.c_uint64]),
     "cg_pk_serialize": (C.c_int, [C.POINTER(_CgProvingKey), C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
+    "cg_prover_params_parse": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "cg_prover_params_get": (C.c_int, [C.c_void_p, C.POINTER(_CgProverParamsView)]),
+    "cg_prover_params_free": (None, [C.c_void_p]),
+    "cg_prover_params_serialized_size": (C.c_uint64, [C.POINTER(_CgProvingKey), C.c_uint64, C.c_uint64, C.c_uint64]),
+    "cg_prover_params_serialize": (C.c_int, [C.POINTER(_CgProvingKey), C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                             C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
+    "cg_client_state_serialized_size": (C.c_uint64, [C.POINTER(_CgClientStateView)]),
+    "cg_client_state_serialize": (C.c_int, [C.POINTER(_CgClientStateView), C.c_void_p, C.c_uint64]),
+    "cg_client_state_parse": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "cg_client_state_get": (C.c_int, [C.c_void_p, C.POINTER(_CgClientStateView)]),
+    "cg_client_state_free": (None, [C.c_void_p]),
 }
 
 _lib = None
@@ -687,18 +713,190 @@ def proving_key_from_bytes(data) -> Tuple["ProvingKey", int]:
         g2 = C.c_void_p(); gabc = C.c_void_p(); ngabc = C.c_uint64()
         _check(L.cg_pk_get(h, C.byref(v), C.byref(g2), C.byref(gabc), C.byref(ngabc)))
 
-        def arr(ptr, nbytes):
-            if not nbytes:
-                return np.zeros(0, np.uint8)
-            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(nbytes,)).copy()
-        vk = VerifyingKey(alpha_g1=arr(v.alpha_g1, 64), beta_g2=arr(v.beta_g2, 128), gamma_g2=arr(g2, 128),
-                          delta_g1=arr(v.delta_g1, 64), delta_g2=arr(v.delta_g2, 128), gamma_abc_g1=arr(gabc, 64 * ngabc.value))
-        pk = ProvingKey(vk=vk, beta_g1=arr(v.beta_g1, 64), delta_g1=arr(v.delta_g1, 64), a_query=arr(v.a_query, 64 * v.a_len),
-                        b_g1_query=arr(v.b_g1_query, 64 * v.b_g1_len), b_g2_query=arr(v.b_g2_query, 128 * v.b_g2_len),
-                        h_query=arr(v.h_query, 64 * v.h_len), l_query=arr(v.l_query, 64 * v.l_len))
+        pk = _pk_from_view(v, g2, gabc, ngabc.value)
     finally:
         L.cg_pk_free(h)
     return pk, int(used.value)
+
+
+def _arr(ptr, nbytes) -> np.ndarray:
+    if not nbytes:
+        return np.zeros(0, np.uint8)
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(int(nbytes),)).copy()
+
+
+def _pk_from_view(v: _CgProvingKey, gamma_g2, gamma_abc, n_gamma_abc) -> "ProvingKey":
+    vk = VerifyingKey(alpha_g1=_arr(v.alpha_g1, 64), beta_g2=_arr(v.beta_g2, 128), gamma_g2=_arr(gamma_g2, 128),
+                      delta_g1=_arr(v.delta_g1, 64), delta_g2=_arr(v.delta_g2, 128), gamma_abc_g1=_arr(gamma_abc, 64 * n_gamma_abc))
+    return ProvingKey(vk=vk, beta_g1=_arr(v.beta_g1, 64), delta_g1=_arr(v.delta_g1, 64), a_query=_arr(v.a_query, 64 * v.a_len),
+                      b_g1_query=_arr(v.b_g1_query, 64 * v.b_g1_len), b_g2_query=_arr(v.b_g2_query, 128 * v.b_g2_len),
+                      h_query=_arr(v.h_query, 64 * v.h_len), l_query=_arr(v.l_query, 64 * v.l_len))
+
+
+@dataclass
+class ProverParams:
+    """creds/src/lib.rs:58-63.  `groth16_pvk` and `vk_bytes` are the serialized PreparedVerifyingKey / VerifyingKey
+    exactly as the file holds them: the prover passes them on to the ClientState (creds/src/lib.rs:292-299)."""
+    groth16_params: ProvingKey
+    groth16_pvk: bytes
+    config_str: str
+    vk_bytes: bytes = b""
+
+    @staticmethod
+    def from_bytes(data) -> "ProverParams":
+        """`read_from_file::<ProverParams>` (creds/src/utils.rs:179-189, creds/src/lib.rs:268)"""
+        L = lib()
+        buf = _u8(data)
+        h = C.c_void_p()
+        _check(L.cg_prover_params_parse(_ptr(buf), buf.size, C.byref(h)))
+        try:
+            v = _CgProverParamsView()
+            _check(L.cg_prover_params_get(h, C.byref(v)))
+            pk = _pk_from_view(v.pk, v.gamma_g2, v.gamma_abc_g1, v.gamma_abc_len)
+            return ProverParams(pk, _arr(v.pvk_bytes, v.pvk_len).tobytes(), _arr(v.config_str, v.config_len).tobytes().decode("utf-8"),
+                                _arr(v.vk_bytes, v.vk_len).tobytes())
+        finally:
+            L.cg_prover_params_free(h)
+
+    def to_bytes(self) -> bytes:
+        """`write_to_file(&prover_params, ..)` (creds/src/utils.rs:140-152, creds/src/lib.rs:245-248)"""
+        L = lib()
+        pk = self.groth16_params
+        cpk = pk._c()
+        n = pk.vk.gamma_abc_g1.size // 64
+        pvk = _u8(self.groth16_pvk)
+        cfg = _u8(self.config_str.encode("utf-8"))
+        size = int(L.cg_prover_params_serialized_size(C.byref(cpk), n, pvk.size, cfg.size))
+        out = np.zeros(size, np.uint8)
+        gabc = pk.vk.gamma_abc_g1 if n else np.zeros(64, np.uint8)
+        _check(L.cg_prover_params_serialize(C.byref(cpk), _ptr(pk.vk.gamma_g2), _ptr(gabc), n, _ptr(pvk), pvk.size,
+                                            _ptr(cfg) if cfg.size else None, cfg.size, _ptr(out), size))
+        return out.tobytes()
+
+
+@dataclass
+class ClientState:
+    """creds/src/groth16rand.rs:23-35.  vk / pvk travel as their serialized bytes (they come out of prover_params.bin);
+    `committed_input_openings` as the serialized items (empty for a state fresh out of create_client_state)."""
+    inputs: List[int]
+    aux: Optional[str]
+    proof: Proof
+    vk: bytes
+    pvk: bytes
+    config_str: str
+    credtype: str = "jwt"                       # groth16rand.rs:76
+    input_com_randomness: Optional[int] = None
+    committed_input_openings: bytes = b""
+    n_openings: int = 0
+
+    @staticmethod
+    def new(inputs, aux, proof: Proof, vk: bytes, pvk: bytes, config_str: str) -> "ClientState":
+        """ClientState::new (groth16rand.rs:60-80)"""
+        return ClientState(list(inputs), aux, proof, vk, pvk, config_str)
+
+    def to_bytes(self) -> bytes:
+        """ClientState::write_to_file (groth16rand.rs:89-98)"""
+        L = lib()
+        v = _CgClientStateView()
+        keep = []
+
+        def put(field, length_field, data):
+            a = _u8(data)
+            keep.append(a)
+            setattr(v, field, _ptr(a) if a.size else None)
+            if length_field:
+                setattr(v, length_field, a.size)
+        put("inputs", None, scalars_to_array(self.inputs) if self.inputs else b"")
+        v.n_inputs = len(self.inputs)
+        v.has_aux = 0 if self.aux is None else 1
+        put("aux", "aux_len", (self.aux or "").encode("utf-8"))
+        put("proof", None, self.proof.data)
+        put("vk_bytes", "vk_len", self.vk)
+        put("pvk_bytes", "pvk_len", self.pvk)
+        v.has_input_com_randomness = 0 if self.input_com_randomness is None else 1
+        put("input_com_randomness", None, fr_to_bytes(self.input_com_randomness or 0))
+        put("openings_bytes", "openings_len", self.committed_input_openings)
+        v.n_openings = self.n_openings
+        put("credtype", "credtype_len", self.credtype.encode("utf-8"))
+        put("config_str", "config_len", self.config_str.encode("utf-8"))
+        if len(self.proof.data) != 256:
+            raise ValueError("proof must be 256 bytes")
+        size = int(L.cg_client_state_serialized_size(C.byref(v)))
+        out = np.zeros(size, np.uint8)
+        _check(L.cg_client_state_serialize(C.byref(v), _ptr(out), size))
+        return out.tobytes()
+
+    @staticmethod
+    def from_bytes(data) -> "ClientState":
+        """ClientState::new_from_file (groth16rand.rs:82-87)"""
+        L = lib()
+        buf = _u8(data)
+        h = C.c_void_p()
+        _check(L.cg_client_state_parse(_ptr(buf), buf.size, C.byref(h)))
+        try:
+            v = _CgClientStateView()
+            _check(L.cg_client_state_get(h, C.byref(v)))
+            ib = _arr(v.inputs, 32 * v.n_inputs).tobytes()
+            inputs = [int.from_bytes(ib[i:i + 32], "little") for i in range(0, len(ib), 32)]
+            aux = _arr(v.aux, v.aux_len).tobytes().decode("utf-8") if v.has_aux else None
+            rnd = int.from_bytes(_arr(v.input_com_randomness, 32).tobytes(), "little") if v.has_input_com_randomness else None
+            return ClientState(inputs, aux, Proof(_arr(v.proof, 256).tobytes()), _arr(v.vk_bytes, v.vk_len).tobytes(),
+                               _arr(v.pvk_bytes, v.pvk_len).tobytes(), _arr(v.config_str, v.config_len).tobytes().decode("utf-8"),
+                               _arr(v.credtype, v.credtype_len).tobytes().decode("utf-8"), rnd,
+                               _arr(v.openings_bytes, v.openings_len).tobytes(), int(v.n_openings))
+        finally:
+            L.cg_client_state_free(h)
+
+
+class IOLocations:
+    """creds/src/structs.rs:26-100: `io_locations.sym`, one `name,location` row per public input/output of the
+    Groth16 circuit (location = wire index, so public input i of the proof is location - 1; creds/src/lib.rs:305-307)."""
+
+    def __init__(self, io_data: str):
+        self.public_io_locations = {}
+        for line in io_data.splitlines():                       # new_from_str (structs.rs:48-68)
+            parts = line.split(",")
+            if len(parts) != 2:
+                raise ValueError("Line %s in io_locations.sym is not formatted correctly! Found %d parts." % (line, len(parts)))
+            if not parts[1].isdigit():
+                raise ValueError("Line %s in io_locations.sym: location is not an unsigned integer" % line)
+            self.public_io_locations[parts[0]] = int(parts[1])
+        self.public_io_locations = dict(sorted(self.public_io_locations.items()))    # BTreeMap order
+
+    @staticmethod
+    def from_file(path: str) -> "IOLocations":
+        with open(path) as f:
+            return IOLocations(f.read())
+
+    def get_io_location(self, key: str) -> int:
+        if key not in self.public_io_locations:
+            raise KeyError("Key %s not found in public_io_locations" % key)
+        return self.public_io_locations[key]
+
+    def get_public_key_indices(self) -> List[int]:
+        """structs.rs:80-90: zero-based input positions of the issuer key limbs"""
+        return sorted(v - 1 for k, v in self.public_io_locations.items() if k.startswith("modulus") or k.startswith("pubkey"))
+
+    def get_all_names(self) -> List[str]:
+        return list(self.public_io_locations.keys())
+
+
+def create_client_state(r1cs_bytes, prover_params_bytes, witness, rng, prover_aux: Optional[str] = None,
+                        credtype: str = "jwt", prover: Optional["Prover"] = None) -> "ClientState":
+    """creds/src/lib.rs:255-301 without the witness generator: parse main_c.r1cs and prover_params.bin, prove with
+    (r, s) drawn from `rng`, and assemble the ClientState the `show` step starts from.  `witness` is the full wire
+    assignment the WASM calculator would have produced (wire 0 = 1).  The reference also verifies the proof against
+    groth16_pvk.bin before returning (:286-290); that check is the caller's (the tests do it with the oracle)."""
+    r1cs = R1CSFile(r1cs_bytes)
+    pp = ProverParams.from_bytes(prover_params_bytes)
+    circuit = CircomCircuit(r1cs, witness)
+    if prover is not None:
+        proof = prover.prove(circuit.full_assignment(), rng.randrange(FR_MODULUS), rng.randrange(FR_MODULUS))
+    else:
+        proof = Groth16.prove(pp.groth16_params, circuit, rng)
+    cs = ClientState.new(circuit.get_public_inputs(), prover_aux, proof, pp.vk_bytes, pp.groth16_pvk, pp.config_str)
+    cs.credtype = credtype
+    return cs
 
 
 def proving_key_to_bytes(pk: "ProvingKey") -> bytes:

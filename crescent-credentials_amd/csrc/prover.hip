@@ -254,15 +254,6 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
     *out = nullptr;
     if (num_inputs == 0 || num_inputs > num_variables) return fail(CG_ERR_INVALID_ARGUMENT, "need 1 <= num_inputs <= num_variables");
     if (pk->coord_form != CG_FORM_CANONICAL && pk->coord_form != CG_FORM_MONTGOMERY) return fail(CG_ERR_INVALID_ARGUMENT, "bad coord_form");
-    // every pointer the structs carry is checked before anything is read through it (a half-filled struct from the
-    // C or Rust side must come back as an error, not a fault)
-    if (!pk->alpha_g1 || !pk->beta_g1 || !pk->delta_g1 || !pk->beta_g2 || !pk->delta_g2)
-        return fail(CG_ERR_INVALID_ARGUMENT, "null key point (alpha_g1 / beta_g1 / delta_g1 / beta_g2 / delta_g2)");
-    if ((pk->a_len && !pk->a_query) || (pk->b_g1_len && !pk->b_g1_query) || (pk->b_g2_len && !pk->b_g2_query) ||
-        (pk->h_len && !pk->h_query) || (pk->l_len && !pk->l_query))
-        return fail(CG_ERR_INVALID_ARGUMENT, "null query pointer with a non-zero length");
-    for (int k = 0; k < 3; ++k)
-        if (const char* why = csr_view_problem(abc[k])) return fail(CG_ERR_INVALID_ARGUMENT, "matrix %d: %s", k, why);
     const uint64_t l = num_inputs, m = num_constraints, M = num_variables;
     const uint64_t dom_in = m + l;
     const int logD = ilog2_ceil(dom_in);
@@ -280,6 +271,15 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
     if (wb < 0 || wb == 1 || wb > 22) return fail(CG_ERR_INVALID_ARGUMENT, "window_bits must be 0 (automatic) or in [2, 22]");
     if (opt && opt->proof_slots < 0) return fail(CG_ERR_INVALID_ARGUMENT, "proof_slots must not be negative");
     if (opt && (opt->flags & ~CG_FLAG_H_COEFFICIENT_BASIS)) return fail(CG_ERR_INVALID_ARGUMENT, "unknown bits in flags");
+    // every pointer the structs carry is checked before anything is read through it (a half-filled struct from the
+    // C or Rust side must come back as an error, not a fault)
+    if (!pk->alpha_g1 || !pk->beta_g1 || !pk->delta_g1 || !pk->beta_g2 || !pk->delta_g2)
+        return fail(CG_ERR_INVALID_ARGUMENT, "null key point (alpha_g1 / beta_g1 / delta_g1 / beta_g2 / delta_g2)");
+    if ((pk->a_len && !pk->a_query) || (pk->b_g1_len && !pk->b_g1_query) || (pk->b_g2_len && !pk->b_g2_query) ||
+        (pk->h_len && !pk->h_query) || (pk->l_len && !pk->l_query))
+        return fail(CG_ERR_INVALID_ARGUMENT, "null query pointer with a non-zero length");
+    for (int k = 0; k < 3; ++k)
+        if (const char* why = csr_view_problem(abc[k])) return fail(CG_ERR_INVALID_ARGUMENT, "matrix %d: %s", k, why);
     try {
         int dev = (opt && opt->device >= 0) ? opt->device : -1;
         if (dev < 0) CG_HIP(hipGetDevice(&dev));

@@ -284,6 +284,58 @@ uint64_t cg_pk_serialized_size(const cg_proving_key* pk, uint64_t gamma_abc_len)
 int cg_pk_serialize(const cg_proving_key* pk, const uint8_t* gamma_g2, const uint8_t* gamma_abc_g1,
                     uint64_t gamma_abc_len, uint8_t* out, uint64_t out_len);
 
+/* prover_params.bin: `ProverParams { groth16_params: ProvingKey, groth16_pvk: PreparedVerifyingKey,
+ * config_str: String }`.
+ * Replaces: `read_from_file::<ProverParams>` in `create_client_state` (creds/src/lib.rs:58-63,268;
+ *           creds/src/utils.rs:179-189) and `write_to_file(&prover_params, ..)` in `run_zksetup` (creds/src/lib.rs:245-248).
+ * The prover consumes the key; the serialized VerifyingKey, PreparedVerifyingKey (data_structures.rs:62-71: vk, an Fq12
+ * and two bn::G2Prepared) and the configuration string are returned verbatim, because `create_client_state` copies
+ * them into the ClientState (creds/src/lib.rs:292-299).  Views stay valid until cg_prover_params_free. */
+typedef struct cg_prover_params cg_prover_params;
+typedef struct cg_prover_params_view {
+    cg_proving_key pk;               /* canonical packed arrays, as cg_pk_get */
+    const uint8_t* gamma_g2;         /* vk.gamma_g2, 128 B */
+    const uint8_t* gamma_abc_g1;     /* vk.gamma_abc_g1, gamma_abc_len x 64 B */
+    uint64_t gamma_abc_len;
+    const uint8_t* vk_bytes;  uint64_t vk_len;      /* groth16_params.vk as serialized */
+    const uint8_t* pvk_bytes; uint64_t pvk_len;     /* groth16_pvk as serialized */
+    const uint8_t* config_str; uint64_t config_len; /* UTF-8, no terminator */
+} cg_prover_params_view;
+int cg_prover_params_parse(const uint8_t* data, uint64_t len, cg_prover_params** out);
+int cg_prover_params_get(const cg_prover_params* pp, cg_prover_params_view* view);
+void cg_prover_params_free(cg_prover_params* pp);
+uint64_t cg_prover_params_serialized_size(const cg_proving_key* pk, uint64_t gamma_abc_len, uint64_t pvk_len,
+                                          uint64_t config_len);
+int cg_prover_params_serialize(const cg_proving_key* pk, const uint8_t* gamma_g2, const uint8_t* gamma_abc_g1,
+                               uint64_t gamma_abc_len, const uint8_t* pvk_bytes, uint64_t pvk_len,
+                               const uint8_t* config_str, uint64_t config_len, uint8_t* out, uint64_t out_len);
+
+/* client_state.bin: the hand-over from the prove step to the host-side `show` step.
+ * Replaces: `ClientState::<E>::new` + `write_to_file` / `new_from_file` (creds/src/groth16rand.rs:23-35,60-98;
+ *           creds/src/lib.rs:292-300), ark-serialize uncompressed, fields in declaration order:
+ *           inputs: Vec<Fr> | aux: Option<String> | proof | vk | pvk | input_com_randomness: Option<Fr> |
+ *           committed_input_openings: Vec<PedersenOpening<G1>> (creds/src/dlog.rs:24-29) | credtype | config_str.
+ * The library writes the 256-byte proof cg_prove returned next to the vk / pvk / config bytes that came out of
+ * prover_params.bin; openings (empty for a fresh state) travel as their serialized bytes. */
+typedef struct cg_client_state cg_client_state;
+typedef struct cg_client_state_view {
+    const uint8_t* inputs; uint64_t n_inputs;        /* public inputs (wires 1 .. num_inputs-1), 32 B canonical each */
+    const uint8_t* aux; uint64_t aux_len; int32_t has_aux;
+    int32_t has_input_com_randomness;
+    const uint8_t* proof;                            /* 256 B */
+    const uint8_t* vk_bytes; uint64_t vk_len;
+    const uint8_t* pvk_bytes; uint64_t pvk_len;
+    const uint8_t* input_com_randomness;             /* 32 B when has_input_com_randomness */
+    const uint8_t* openings_bytes; uint64_t openings_len; uint64_t n_openings;
+    const uint8_t* credtype; uint64_t credtype_len;  /* "jwt" (groth16rand.rs:76) or "mdl" */
+    const uint8_t* config_str; uint64_t config_len;
+} cg_client_state_view;
+uint64_t cg_client_state_serialized_size(const cg_client_state_view* v);
+int cg_client_state_serialize(const cg_client_state_view* v, uint8_t* out, uint64_t out_len);
+int cg_client_state_parse(const uint8_t* data, uint64_t len, cg_client_state** out);
+int cg_client_state_get(const cg_client_state* cs, cg_client_state_view* view);
+void cg_client_state_free(cg_client_state* cs);
+
 /* Library / device description for logs ("crescent_gpu 0.1 gfx950 ..."). */
 const char* cg_version(void);
 

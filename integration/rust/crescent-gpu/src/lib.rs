@@ -7,10 +7,14 @@ pub mod sys;
 
 use ark_bn254::{Bn254, Fq, Fq2, Fr, G1Affine, G2Affine};
 use ark_ff::{BigInteger, PrimeField};
+use ark_groth16::r1cs_to_qap::{LibsnarkReduction, R1CSToQAP};
 use ark_groth16::{Proof, ProvingKey};
-use ark_relations::r1cs::{ConstraintMatrices, SynthesisError};
+use ark_poly::EvaluationDomain;
+use ark_relations::r1cs::{ConstraintMatrices, ConstraintSystemRef, SynthesisError};
 use ark_serialize::CanonicalDeserialize;
+use std::collections::HashMap;
 use std::ffi::CStr;
+use std::sync::{Arc, Mutex, OnceLock};
 
 // `Affine { x, y, infinity }` is repr(Rust): coordinates are packed into byte arrays, struct pointers never
 // cross the boundary.  The Montgomery limbs are copied as they are (`Fp.0` is the BigInt of x·2^256 mod p, the
@@ -52,7 +56,7 @@ struct Csr {
     col: Vec<u32>,
     coeff: Vec<u8>,
 }
-fn to_csr(rows: &[Vec<(Fr, usize)>]) -> Csr {
+fn to_csr<F: PrimeField>(rows: &[Vec<(F, usize)>]) -> Csr {
     let mut m = Csr { row_ptr: vec![0u64], col: Vec::new(), coeff: Vec::new() };
     for row in rows {
         for (c, j) in row {
@@ -158,6 +162,122 @@ impl GpuCircuit {
 impl Drop for GpuCircuit {
     fn drop(&mut self) {
         unsafe { sys::cg_circuit_free(self.ctx) }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The reference's own plug point: `Groth16<E, QAP: R1CSToQAP = LibsnarkReduction>` (forks/groth16/src/lib.rs:55-57).
+// `Groth16::<Bn254, GpuReduction>::prove(..)` keeps the whole of prover.rs - synthesis, arkworks' MSMs - and moves the
+// witness map (three sparse products, seven transforms; r1cs_to_qap.rs:150-213) to the GPU through cg_qap_*.  It is the
+// smaller of the two integrations (the other being `GpuCircuit`, which also takes the five MSMs); both give the same bytes.
+// ---------------------------------------------------------------------------------------------------------------
+struct QapHandle(*mut sys::cg_qap_ctx);
+unsafe impl Send for QapHandle {}
+unsafe impl Sync for QapHandle {} // calls on one handle serialise inside the library
+impl Drop for QapHandle {
+    fn drop(&mut self) {
+        unsafe { sys::cg_qap_free(self.0) }
+    }
+}
+
+/// Matrices are constants of a credential type but arrive by reference on every call (r1cs_to_qap.rs:150-155), so the
+/// resident copy is looked up by a fingerprint of their content: shape, non-zero counts and every 1024th term.
+fn fingerprint<F: PrimeField>(m: &ConstraintMatrices<F>) -> [u64; 8] {
+    let mut f = [
+        m.num_instance_variables as u64, m.num_witness_variables as u64, m.num_constraints as u64,
+        m.a_num_non_zero as u64, m.b_num_non_zero as u64, m.c_num_non_zero as u64, 0, 0,
+    ];
+    let mut t = 0u64;
+    for mat in [&m.a, &m.b, &m.c] {
+        for row in mat.iter() {
+            for (c, j) in row {
+                if t % 1024 == 0 {
+                    let limb = c.into_bigint().as_ref()[0];
+                    f[6] = f[6].rotate_left(7) ^ limb;
+                    f[7] = f[7].wrapping_mul(0x9e3779b97f4a7c15).wrapping_add(*j as u64);
+                }
+                t += 1;
+            }
+        }
+    }
+    f
+}
+fn qap_for<F: PrimeField>(m: &ConstraintMatrices<F>) -> Result<Arc<QapHandle>, SynthesisError> {
+    static CACHE: OnceLock<Mutex<HashMap<[u64; 8], Arc<QapHandle>>>> = OnceLock::new();
+    let key = fingerprint(m);
+    let mut cache = CACHE.get_or_init(|| Mutex::new(HashMap::new())).lock().unwrap();
+    if let Some(h) = cache.get(&key) {
+        return Ok(h.clone());
+    }
+    let rc = unsafe { sys::cg_init(0, std::ptr::null()) };
+    if rc != 0 {
+        return Err(map_err(rc));
+    }
+    let (ca, cb, cc) = (to_csr(&m.a), to_csr(&m.b), to_csr(&m.c));
+    let abc = [ca.view(), cb.view(), cc.view()];
+    let mut ctx: *mut sys::cg_qap_ctx = std::ptr::null_mut();
+    let rc = unsafe {
+        sys::cg_qap_load(&mut ctx, abc.as_ptr(), m.num_instance_variables as u64, m.num_constraints as u64,
+                         (m.num_instance_variables + m.num_witness_variables) as u64, -1)
+    };
+    if rc != 0 {
+        return Err(map_err(rc));
+    }
+    let h = Arc::new(QapHandle(ctx));
+    cache.insert(key, h.clone());
+    Ok(h)
+}
+
+/// `impl R1CSToQAP` (forks/groth16/src/r1cs_to_qap.rs:49-98).  Usage: `Groth16::<Bn254, GpuReduction>::prove(&pk, circuit, &mut rng)`.
+pub struct GpuReduction;
+
+impl R1CSToQAP for GpuReduction {
+    // the generator's half is untouched: it runs once per circuit at zksetup time
+    fn instance_map_with_evaluation<F: PrimeField, D: EvaluationDomain<F>>(
+        cs: ConstraintSystemRef<F>,
+        t: &F,
+    ) -> Result<(Vec<F>, Vec<F>, Vec<F>, F, usize, usize), SynthesisError> {
+        LibsnarkReduction::instance_map_with_evaluation::<F, D>(cs, t)
+    }
+
+    fn witness_map_from_matrices<F: PrimeField, D: EvaluationDomain<F>>(
+        matrices: &ConstraintMatrices<F>,
+        num_inputs: usize,
+        num_constraints: usize,
+        full_assignment: &[F],
+    ) -> Result<Vec<F>, SynthesisError> {
+        // The library computes over BN254's scalar field only; any other field keeps the CPU path.
+        if F::MODULUS.to_bytes_le() != <Fr as PrimeField>::MODULUS.to_bytes_le() {
+            return LibsnarkReduction::witness_map_from_matrices::<F, D>(matrices, num_inputs, num_constraints, full_assignment);
+        }
+        // F is BN254's Fr (checked by modulus); everything crosses the boundary as canonical bytes, so no cast is needed
+        let m = matrices;
+        if num_inputs != m.num_instance_variables || num_constraints != m.num_constraints
+            || full_assignment.len() != m.num_instance_variables + m.num_witness_variables
+        {
+            return Err(SynthesisError::AssignmentMissing);
+        }
+        let h = qap_for(m)?;
+        let mut w = Vec::with_capacity(full_assignment.len() * 32);
+        for x in full_assignment {
+            w.extend_from_slice(&x.into_bigint().to_bytes_le());
+        }
+        let d = unsafe { sys::cg_qap_domain_size(h.0) } as usize;
+        let mut out = vec![0u8; d * 32];
+        let rc = unsafe { sys::cg_qap_witness_map(h.0, w.as_ptr() as *const _, 0, out.as_mut_ptr() as *mut _, 0) };
+        if rc != 0 {
+            return Err(map_err(rc));
+        }
+        Ok(out.chunks_exact(32).map(F::from_le_bytes_mod_order).collect()) // domain_size coefficients (r1cs_to_qap.rs:212)
+    }
+
+    fn h_query_scalars<F: PrimeField, D: EvaluationDomain<F>>(
+        max_power: usize,
+        t: F,
+        zt: F,
+        delta_inverse: F,
+    ) -> Result<Vec<F>, SynthesisError> {
+        LibsnarkReduction::h_query_scalars::<F, D>(max_power, t, zt, delta_inverse)
     }
 }
 

@@ -74,6 +74,7 @@ pub struct cg_timings {
 
 pub enum cg_ctx {}
 pub enum cg_msm_ctx {}
+pub enum cg_qap_ctx {}
 
 extern "C" {
     pub fn cg_init(n_devices: c_int, device_ids: *const c_int) -> c_int;
@@ -98,6 +99,23 @@ extern "C" {
     ) -> c_int;
     pub fn cg_witness_map(ctx: *mut cg_ctx, full_assignment: *const u8, h_out: *mut u8) -> c_int;
     pub fn cg_domain_size(ctx: *const cg_ctx) -> u64;
+    pub fn cg_qap_load(
+        out: *mut *mut cg_qap_ctx,
+        abc: *const cg_csr,
+        num_inputs: u64,
+        num_constraints: u64,
+        num_variables: u64,
+        device: i32,
+    ) -> c_int;
+    pub fn cg_qap_witness_map(
+        ctx: *mut cg_qap_ctx,
+        full_assignment: *const c_void,
+        assignment_on_device: c_int,
+        h_out: *mut c_void,
+        h_on_device: c_int,
+    ) -> c_int;
+    pub fn cg_qap_domain_size(ctx: *const cg_qap_ctx) -> u64;
+    pub fn cg_qap_free(ctx: *mut cg_qap_ctx);
     pub fn cg_msm_g1(
         bases: *const u8,
         coord_form: u32,

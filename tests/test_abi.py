@@ -176,6 +176,25 @@ def test_circuit_load_validates_before_touching_the_gpu(cc):
         opt = api._CgOptions(device=-1, **kw)
         rc = L.cg_circuit_load(ctypes.byref(h), ctypes.byref(pk), abc, 3, 4, 7, ctypes.byref(opt))
         assert rc == -1 and msg in L.cg_last_error(), kw
+    # a struct with consistent lengths but unset pointers is an argument error, not a fault
+    rc = L.cg_circuit_load(ctypes.byref(h), ctypes.byref(pk), abc, 3, 4, 7, None)
+    assert rc == -1 and b"null key point" in L.cg_last_error()
+    import numpy as np
+    pt = np.zeros(128, np.uint8)
+    for f in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "delta_g2"):
+        setattr(pk, f, pt.ctypes.data)
+    rc = L.cg_circuit_load(ctypes.byref(h), ctypes.byref(pk), abc, 3, 4, 7, None)
+    assert rc == -1 and b"null query pointer" in L.cg_last_error()
+    q = np.zeros(7 * 128, np.uint8)
+    for f in ("a_query", "b_g1_query", "b_g2_query", "h_query", "l_query"):
+        setattr(pk, f, q.ctypes.data)
+    rc = L.cg_circuit_load(ctypes.byref(h), ctypes.byref(pk), abc, 3, 4, 7, None)
+    assert rc == -1 and b"null row_ptr" in L.cg_last_error()
+    # the witness-map handle validates the same way
+    q2 = ctypes.c_void_p()
+    assert L.cg_qap_load(ctypes.byref(q2), abc, 3, 4, 7, -1) == -1 and b"null row_ptr" in L.cg_last_error()
+    assert L.cg_qap_load(ctypes.byref(q2), abc, 3, (1 << 28) + 5, (1 << 28) + 9, -1) == -1
+    assert L.cg_qap_load(ctypes.byref(q2), abc, 0, 4, 7, -1) == -1
 
 
 def _c_struct_fields(name):
