@@ -533,111 +533,180 @@ __global__ void __launch_bounds__(256) k_accum_xyzz(const uint32_t* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// combining the per-segment partials: one wave per 64 consecutive segments
+//
+// Every segment of the level below leaves two pieces: F (its first run) and L (its last run); a segment that is a
+// single run leaves F = its total and L = empty under the same key.  Laid side by side, the pieces of 64 segments are
+// a key-sorted list of 128, and what is wanted is its sum by key: runs that lie inside the wave go to the bucket
+// array, the run touching the wave's left edge and the one touching its right edge go up as this wave's own (F, L).
+// With uniform keys a run spans two segments, so the whole step is ONE addition per lane (L of the lane to the left
+// + own F); where a key covers whole segments (the 0/1 wires of a circom witness all share a bucket) the open run is
+// carried across the lanes by a segmented scan, taken only by waves that contain such a segment.  A list of T
+// segments is finished in ceil(log64 T) launches of one addition's depth each, where the segment-per-lane scheme
+// (k_accum_xyzz, still used at load time) needed log4 T launches of eight.
+// ---------------------------------------------------------------------------------------------
+static constexpr uint32_t NO_KEY = 0xfffffffeu;   // key of the padding lanes of the last wave; never emitted
+
+template <class F29T>
+__device__ __forceinline__ XYZZ29<F29T> shfl_up_acc(const XYZZ29<F29T>& a, unsigned d) {
+    constexpr int ACC = Words29<F29T>::ACC;
+    uint32_t w[ACC];
+    store_limbs(a.x, w);
+    store_limbs(a.y, w + ACC / 4);
+    store_limbs(a.zz, w + ACC / 2);
+    store_limbs(a.zzz, w + 3 * ACC / 4);
+#pragma unroll
+    for (int i = 0; i < ACC; ++i) w[i] = (uint32_t)__shfl_up((int)w[i], d, 64);
+    XYZZ29<F29T> r;
+    load_limbs(r.x, w);
+    load_limbs(r.y, w + ACC / 4);
+    load_limbs(r.zz, w + ACC / 2);
+    load_limbs(r.zzz, w + 3 * ACC / 4);
+    return r;
+}
+
+template <class F29T>
+__global__ void __launch_bounds__(64) k_combine_wave(const uint32_t* __restrict__ in_keys, const uint32_t* __restrict__ in_pts,
+                                                     uint32_t T, uint32_t* __restrict__ bucket_sums,
+                                                     uint32_t* __restrict__ out_keys, uint32_t* __restrict__ out_pts) {
+    constexpr int ACC = Words29<F29T>::ACC;
+    const uint32_t lane = threadIdx.x, wv = blockIdx.x, t = wv * 64u + lane;
+    const bool final_level = gridDim.x == 1;
+    uint32_t kF = NO_KEY, kL = NO_KEY;
+    XYZZ29<F29T> A, B;
+    bool Ainf = true, Binf = true;
+    if (t < T) {
+        kF = in_keys[2 * t];
+        kL = in_keys[2 * t + 1];
+        Ainf = load_acc(in_pts + (size_t)(2 * t) * ACC, A);
+        Binf = load_acc(in_pts + (size_t)(2 * t + 1) * ACC, B);
+    }
+    const bool single = kF == kL;                 // one run covers the segment: F carries it, L is empty
+    // C = the run still open at the right end of this segment
+    XYZZ29<F29T> Cv = single ? A : B;
+    bool Cinf = single ? Ainf : Binf;
+    if (single && !Binf) add29(Cv, Cinf, B, Binf);
+    const uint32_t kPrev = (uint32_t)__shfl_up((int)kL, 1, 64);
+    const bool joinL = lane > 0 && kPrev == kF;   // the run open at the end of the lane to the left continues here
+    bool f = single && joinL;                     // ... and runs on through this whole segment
+    if (__ballot(f)) {
+        for (unsigned d = 1; d < 64; d <<= 1) {   // segmented inclusive scan of C; f true at step d implies lane >= d
+            XYZZ29<F29T> Cu = shfl_up_acc(Cv, d);
+            const bool Cuinf = __shfl_up((int)Cinf, d, 64) != 0;
+            const bool fu = __shfl_up((int)f, d, 64) != 0;
+            if (f) add29(Cv, Cinf, Cu, Cuinf);
+            f = f && fu;
+        }
+    }
+    XYZZ29<F29T> Pv = shfl_up_acc(Cv, 1);         // the open run of the lane to the left, after the scan
+    const bool Pinf = __shfl_up((int)Cinf, 1, 64) != 0;
+    // lanes 0..j all single and chained <=> the run open at the end of lane j started at or before the wave's left edge
+    const unsigned long long chain = __ballot(single && (lane == 0 || joinL));
+    auto open_left = [&](unsigned j) { return (~chain & (j >= 63 ? ~0ull : ((2ull << j) - 1ull))) == 0ull; };
+    auto emit = [&](uint32_t key, const XYZZ29<F29T>& v, bool vinf, bool touches_left) {
+        if (key == NO_KEY) return;
+        if (touches_left && !final_level) {
+            out_keys[2 * wv] = key;
+            store_acc(out_pts + (size_t)(2 * wv) * ACC, v, vinf);
+        } else {
+            store_acc(bucket_sums + (size_t)key * ACC, v, vinf);
+        }
+    };
+    if (lane > 0 && !joinL) emit(kPrev, Pv, Pinf, open_left(lane - 1));      // the left neighbour's open run ends at the boundary
+    if (!single) {                                                           // this segment's first run ends inside it
+        XYZZ29<F29T> H = A;
+        bool Hinf = Ainf, left = lane == 0;
+        if (joinL) { add29(H, Hinf, Pv, Pinf); left = open_left(lane - 1); }
+        emit(kF, H, Hinf, left);
+    }
+    if (lane == 63) {                                                        // the run open at the wave's right edge
+        if (final_level) {
+            emit(kL, Cv, Cinf, false);
+        } else if (open_left(63)) {                                          // the whole wave is one run
+            emit(kL, Cv, Cinf, true);
+            out_keys[2 * wv + 1] = kL;
+            store_acc(out_pts + (size_t)(2 * wv + 1) * ACC, Cv, true);
+        } else {
+            out_keys[2 * wv + 1] = kL;
+            store_acc(out_pts + (size_t)(2 * wv + 1) * ACC, Cv, Cinf);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // bucket reduction: per window, Σ_b (b+1)·S_b
 //
 // The buckets of a window are viewed as an R x C matrix (b = r·C + col, C = 2^cb):
 //     Σ_b (b+1)·S_b = C · Σ_r r·Row_r  +  Σ_col (col+1)·Col_col,    Row_r = Σ_col S[r,col],  Col_col = Σ_r S[r,col]
 // Row and column sums are plain sums - 2 additions per bucket like the textbook running sum, but fully
-// parallel (tree depth, no serial chain over the buckets) - and the two weighted sums that remain have only
-// R and C terms, each handled as a small scalar multiple followed by a tree sum.
+// parallel - taken by ONE launch (a block per row and a block per column, an LDS tree inside each).  The two
+// weighted sums Σ_r r·Row_r and Σ_col (col+1)·Col_col are taken bit by bit: Σ_i w_i·P_i = Σ_k 2^k·(Σ_{i: bit k of w_i} P_i),
+// one block per bit in a second launch, and the log-many partial sums go to the host, which folds them with one
+// doubling and one addition each while it normalises the result anyway.  Depth: two tree sums; the double-and-add
+// per lane and the ~10 fan-in steps per axis of the earlier scheme are gone.
 // ---------------------------------------------------------------------------------------------
-// out[w][o][i] = Σ_{k<cnt} in[w][o·in_o_stride + k·k_stride + i],  i < n_inner  (accumulator units)
+// Σ over the block of each thread's (acc, inf); the result lands in thread 0's acc / inf.  sm: blockDim.x * ACC words.
 template <class F29T>
-__global__ void __launch_bounds__(256) k_sum_axis(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                  uint32_t n_o, uint32_t n_inner, uint32_t cnt, uint32_t in_o_stride,
-                                                  uint32_t k_stride, uint32_t in_win_stride, uint32_t out_win_stride) {
+__device__ __forceinline__ void block_tree_sum(XYZZ29<F29T>& acc, bool& inf, uint32_t* sm) {
     constexpr int ACC = Words29<F29T>::ACC;
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_o * n_inner) return;
-    const uint32_t w = blockIdx.y;
-    uint32_t o = g / n_inner, i = g % n_inner;
-    const uint32_t* src = in + ((size_t)w * in_win_stride + (size_t)o * in_o_stride + i) * ACC;
-    XYZZ29<F29T> acc;
-    bool inf = true;
-    for (uint32_t k = 0; k < cnt; ++k) {
-        XYZZ29<F29T> q;
-        bool qinf = load_acc(src + (size_t)k * k_stride * ACC, q);
-        add29(acc, inf, q, qinf);
-    }
-    store_acc(out + ((size_t)w * out_win_stride + g) * ACC, acc, inf);
-}
-
-// out[w][blk] = Σ_{i in block} (i + offset)·in[w][i]   (weights < 2^22; double-and-add, then an LDS tree)
-template <class F29T>
-__global__ void __launch_bounds__(256) k_weighted_sum(const uint32_t* __restrict__ in, uint32_t n, uint32_t offset,
-                                                      uint32_t in_win_stride, uint32_t* __restrict__ out, uint32_t out_win_stride) {
-    constexpr int ACC = Words29<F29T>::ACC;
-    extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
-    const uint32_t w = blockIdx.y;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    XYZZ29<F29T> acc;
-    bool inf = true;
-    if (i < n) {
-        XYZZ29<F29T> x;
-        bool xinf = load_acc(in + ((size_t)w * in_win_stride + i) * ACC, x);
-        uint32_t wt = i + offset;
-        if (!xinf && wt != 0) {
-            acc = x;
-            inf = false;
-            int top = 31 - __clz(wt);
-            for (int bit = top - 1; bit >= 0; --bit) {
-                if (!inf) acc = dbl29(acc);
-                if ((wt >> bit) & 1u) add29(acc, inf, x, false);
-            }
-        }
-    }
     store_acc(sm + (size_t)threadIdx.x * ACC, acc, inf);
     __syncthreads();
     for (uint32_t s = blockDim.x / 2; s > 0; s >>= 1) {
         if (threadIdx.x < s) {
-            XYZZ29<F29T> a, b;
-            bool ai = load_acc(sm + (size_t)threadIdx.x * ACC, a);
+            XYZZ29<F29T> b;
             bool bi = load_acc(sm + (size_t)(threadIdx.x + s) * ACC, b);
-            add29(a, ai, b, bi);
-            store_acc(sm + (size_t)threadIdx.x * ACC, a, ai);
+            add29(acc, inf, b, bi);
+            store_acc(sm + (size_t)threadIdx.x * ACC, acc, inf);
         }
         __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        XYZZ29<F29T> a;
-        bool ai = load_acc(sm, a);
-        store_acc(out + ((size_t)w * out_win_stride + blockIdx.x) * ACC, a, ai);
     }
 }
 
-// out[w*out_per_window + blk] = Σ of this block's slice of in[w*in_per_window ...]
+// blocks [0, R): Row_r = Σ_col S[r·C + col];  blocks [R, R + C): Col_col = Σ_r S[r·C + col];  blockIdx.y = window
 template <class F29T>
-__global__ void __launch_bounds__(256) k_sum_points(const uint32_t* __restrict__ in, uint32_t in_per_window,
-                                                    uint32_t* __restrict__ out, uint32_t out_per_window) {
+__global__ void __launch_bounds__(256) k_bucket_rows_cols(const uint32_t* __restrict__ buckets, uint32_t R, uint32_t C,
+                                                          uint32_t* __restrict__ rows, uint32_t* __restrict__ cols) {
     constexpr int ACC = Words29<F29T>::ACC;
     extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
-    const uint32_t w = blockIdx.y;
-    const uint32_t blk = blockIdx.x;
-    const uint32_t* src = in + (size_t)w * in_per_window * ACC;
+    const uint32_t w = blockIdx.y, b = blockIdx.x;
+    const bool is_row = b < R;
+    const uint32_t count = is_row ? C : R, base = is_row ? b * C : b - R, stride = is_row ? 1u : C;
+    const uint32_t* src = buckets + (size_t)w * R * C * ACC;
     XYZZ29<F29T> acc;
     bool inf = true;
-    for (uint32_t i = blk * blockDim.x + threadIdx.x; i < in_per_window; i += gridDim.x * blockDim.x) {
+    for (uint32_t k = threadIdx.x; k < count; k += blockDim.x) {
         XYZZ29<F29T> q;
-        bool qinf = load_acc(src + (size_t)i * ACC, q);
+        bool qinf = load_acc(src + ((size_t)base + (size_t)k * stride) * ACC, q);
         add29(acc, inf, q, qinf);
     }
-    store_acc(sm + (size_t)threadIdx.x * ACC, acc, inf);
-    __syncthreads();
-    for (uint32_t s = blockDim.x / 2; s > 0; s >>= 1) {
-        if (threadIdx.x < s) {
-            XYZZ29<F29T> a, b;
-            bool ai = load_acc(sm + (size_t)threadIdx.x * ACC, a);
-            bool bi = load_acc(sm + (size_t)(threadIdx.x + s) * ACC, b);
-            add29(a, ai, b, bi);
-            store_acc(sm + (size_t)threadIdx.x * ACC, a, ai);
-        }
-        __syncthreads();
-    }
+    block_tree_sum(acc, inf, sm);
     if (threadIdx.x == 0) {
-        XYZZ29<F29T> a;
-        bool ai = load_acc(sm, a);
-        store_acc(out + ((size_t)w * out_per_window + blk) * ACC, a, ai);
+        uint32_t* dst = is_row ? rows + ((size_t)w * R + b) * ACC : cols + ((size_t)w * C + (b - R)) * ACC;
+        store_acc(dst, acc, inf);
     }
+}
+
+// block b < rbits: Σ_{r: bit b of r} Row_r;  block rbits + k: Σ_{col: bit k of (col + 1)} Col_col;  blockIdx.y = window
+template <class F29T>
+__global__ void __launch_bounds__(256) k_bit_sums(const uint32_t* __restrict__ rows, uint32_t R, uint32_t rbits,
+                                                  const uint32_t* __restrict__ cols, uint32_t C, uint32_t* __restrict__ out) {
+    constexpr int ACC = Words29<F29T>::ACC;
+    extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
+    const uint32_t w = blockIdx.y, b = blockIdx.x;
+    const bool is_row = b < rbits;
+    const uint32_t bit = is_row ? b : b - rbits, n = is_row ? R : C, offset = is_row ? 0u : 1u;
+    const uint32_t* src = is_row ? rows + (size_t)w * R * ACC : cols + (size_t)w * C * ACC;
+    XYZZ29<F29T> acc;
+    bool inf = true;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        if (((i + offset) >> bit) & 1u) {
+            XYZZ29<F29T> q;
+            bool qinf = load_acc(src + (size_t)i * ACC, q);
+            add29(acc, inf, q, qinf);
+        }
+    }
+    block_tree_sum(acc, inf, sm);
+    if (threadIdx.x == 0) store_acc(out + ((size_t)w * gridDim.x + b) * ACC, acc, inf);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -646,8 +715,9 @@ __global__ void __launch_bounds__(256) k_sum_points(const uint32_t* __restrict__
 static constexpr uint32_t ACC_TARGET_THREADS = 256u * 4u * 4u * 64u;  // CUs x SIMDs x waves x lanes: one fully resident round
 static constexpr uint32_t ACC_MIN_L = 16;
 static constexpr uint32_t ACC_LEVEL_L = 8;   // segment length of the partial-combining levels
-static constexpr uint32_t RED_F_BIG = 4;     // fan-in of a row/column-sum step while the step still fills the GPU ...
-static constexpr uint32_t RED_F = 2;         // ... and below that (latency-bound: minimise the depth)
+
+// shape of the bucket matrix of a window: nb = R·C buckets, C = 2^cbits columns (at most 1024)
+static int red_cbits(int c) { return (c - 1 + 1) / 2 > 10 ? 10 : (c - 1 + 1) / 2; }
 
 static uint32_t level1_L(uint64_t N) {
     uint64_t L = (N + ACC_TARGET_THREADS - 1) / ACC_TARGET_THREADS;
@@ -684,24 +754,21 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
     bucket_sums.alloc(((size_t)nbuckets_total + 1) * ACC);     // + the spare bucket of the dense mode's filler records
     uint64_t t1 = (cap_entries + ACC_MIN_L - 1) / ACC_MIN_L;
     if (t1 > ACC_TARGET_THREADS) t1 = ACC_TARGET_THREADS;
-    uint64_t pa = 2 * t1;
-    uint64_t t2 = (pa + ACC_LEVEL_L - 1) / ACC_LEVEL_L;
-    uint64_t pb = 2 * t2;
+    const uint64_t pa = 2 * t1, pb = 2 * ceil_div(t1, 64);   // two pieces per segment, then two per wave of 64 segments
     part_keys_a.alloc(pa); part_pts_a.alloc(pa * ACC);
     part_keys_b.alloc(pb); part_pts_b.alloc(pb * ACC);
     const uint32_t wins = b->precomputed ? 1u : (uint32_t)W;
-    // scratch of the bucket reduction: the first row/column-sum step leaves nb/RED_F (+ slack) accumulators
-    uint64_t red_elems = (uint64_t)(nb / 2 + 2048) * wins;
-    red_a.alloc(red_elems * ACC);
-    red_b.alloc(red_elems * ACC);
     {
-        const int cbits = (b->c - 1 + 1) / 2 > 10 ? 10 : (b->c - 1 + 1) / 2;
-        rows_buf.alloc((size_t)(nb >> cbits) * wins * ACC);
-        cols_buf.alloc((size_t)(1u << cbits) * wins * ACC);
+        const int cbits = red_cbits(b->c);
+        const uint32_t C = 1u << cbits, R = nb / C;
+        red_rbits = ilog2_ceil((uint64_t)R);      // weights r < R
+        red_cbits1 = cbits + 1;                   // weights col + 1 <= C
+        rows_buf.alloc((size_t)R * wins * ACC);
+        cols_buf.alloc((size_t)C * wins * ACC);
     }
-    result.alloc((size_t)wins * 2 * ACC);      // per window: rows part, columns part
+    result.alloc((size_t)wins * (red_rbits + red_cbits1) * ACC);      // per window: the per-bit sums of rows, then of columns
     h_count.alloc(1);
-    h_result.alloc((size_t)wins * 2 * ACC);
+    h_result.alloc((size_t)wins * (red_rbits + red_cbits1) * ACC);
     if (!ev_count) {
         CG_HIP(hipEventCreateWithFlags(&ev_count, hipEventDisableTiming));
         for (auto& e : ev_t) CG_HIP(hipEventCreate(&e));
@@ -782,24 +849,23 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
                                   dense_now ? nb : 0xffffffffu, st);
         CG_KERNEL_CHECK();
         CG_HIP(hipEventRecord(ev_t[4], st));
-        // combine partials until one lane covers everything
+        // combine the segments' pieces wave by wave until one wave covers them all (k_combine_wave)
         bool from_a = true;
-        uint32_t count = (T == 1) ? 0 : 2 * T;
-        while (count) {
-            uint32_t Lk = ACC_LEVEL_L;
-            uint32_t Tk = ceil_div(count, Lk);
+        uint32_t segs = (T == 1) ? 0 : T;
+        while (segs) {
+            const uint32_t waves = ceil_div(segs, 64u);
             const uint32_t* ik = from_a ? part_keys_a.p : part_keys_b.p;
             const uint32_t* ip = from_a ? part_pts_a.p : part_pts_b.p;
             uint32_t* ok = from_a ? part_keys_b.p : part_keys_a.p;
             uint32_t* op = from_a ? part_pts_b.p : part_pts_a.p;
-            k_accum_xyzz<F29T><<<ceil_div(Tk, 256), 256, 0, st>>>(ik, ip, count, Lk, Tk, bucket_sums.p, ok, op);
+            k_combine_wave<F29T><<<waves, 64, 0, st>>>(ik, ip, segs, bucket_sums.p, ok, op);
             CG_KERNEL_CHECK();
-            count = (Tk == 1) ? 0 : 2 * Tk;
+            segs = (waves == 1) ? 0 : waves;
             from_a = !from_a;
         }
     }
-    // bucket reduction (see the comment above k_sum_axis).  Its launches are many, small and of a fixed shape for a given
-    // window size, so they are captured once into a HIP graph and replayed: one submission instead of ~20.
+    // bucket reduction (see the comment above block_tree_sum): two launches and the copy of the per-bit sums, of a fixed
+    // shape for a given window size - captured once into a HIP graph and replayed as one submission.
     if (!red_graph) {
         hipGraph_t g = nullptr;
         CG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -823,63 +889,14 @@ template <class F>
 void MsmEngine<F>::enqueue_reduction(hipStream_t st) {
     const uint32_t wins = bases->precomputed ? 1u : (uint32_t)bases->W;
     const uint32_t nb = 1u << (bases->c - 1);
-    {
-        const int cbits = (bases->c - 1 + 1) / 2 > 10 ? 10 : (bases->c - 1 + 1) / 2;
-        const uint32_t C = 1u << cbits, R = nb / C;
-        // plain sum of `cnt_total` accumulators per (o, i): repeated fan-in RED_F steps over the middle axis
-        auto sum_axis = [&](const uint32_t* in, uint32_t in_win_stride, uint32_t O, uint32_t A, uint32_t I, uint32_t* out_final,
-                            uint32_t out_final_win_stride) {
-            // tensor [O][A][I]; returns [O][I] in out_final
-            const uint32_t* src = in;
-            uint32_t src_win = in_win_stride;
-            bool to_a = true;
-            if (A == 1) {   // nothing to add: copy through a 1-term sum
-                k_sum_axis<F29T><<<dim3(ceil_div((uint64_t)O * I, 256), wins), 256, 0, st>>>(src, out_final, O, I, 1, I, I, src_win, out_final_win_stride);
-                CG_KERNEL_CHECK();
-                return;
-            }
-            while (A > 1) {
-                uint32_t f = ((uint64_t)O * A * I / RED_F_BIG >= 131072 && A % RED_F_BIG == 0) ? RED_F_BIG : RED_F;
-                if (f > A) f = A;
-                uint32_t A2 = A / f;
-                const bool last = (A2 == 1);
-                uint32_t* dst = last ? out_final : (to_a ? red_a.p : red_b.p);
-                uint32_t dst_win = last ? out_final_win_stride : O * A2 * I;
-                // [O][f][A2][I]: out[o][a2*I + i] = Σ_k in[o*A*I + k*A2*I + a2*I + i]
-                k_sum_axis<F29T><<<dim3(ceil_div((uint64_t)O * A2 * I, 256), wins), 256, 0, st>>>(src, dst, O, A2 * I, f, A * I, A2 * I, src_win, dst_win);
-                CG_KERNEL_CHECK();
-                src = dst;
-                src_win = dst_win;
-                A = A2;
-                to_a = !to_a;
-            }
-        };
-        // rows: [R][C][1] -> Row[R];  columns: [1][R][C] -> Col[C]
-        uint32_t* rows = rows_buf.p;
-        uint32_t* cols = cols_buf.p;
-        sum_axis(bucket_sums.p, nb, R, C, 1, rows, R);
-        sum_axis(bucket_sums.p, nb, 1, R, C, cols, C);
-        // weighted sums: Σ_r r·Row_r and Σ_col (col+1)·Col_col, each to one point per window
-        auto weighted = [&](const uint32_t* in, uint32_t n, uint32_t offset, uint32_t slot) {
-            uint32_t blocks = ceil_div(n, 256);
-            uint32_t threads = 256;
-            if (n < 256) { threads = 64; while (threads < n) threads <<= 1; }
-            uint32_t* tmp = (slot == 0) ? red_a.p : red_b.p;
-            uint32_t* dst = (blocks == 1) ? result.p + (size_t)slot * ACC : tmp;
-            uint32_t dst_win = (blocks == 1) ? 2 : blocks;
-            k_weighted_sum<F29T><<<dim3(blocks, wins), threads, (size_t)threads * ACC * 4, st>>>(in, n, offset, n, dst, dst_win);
-            CG_KERNEL_CHECK();
-            if (blocks > 1) {
-                uint32_t t2 = 64;
-                while (t2 < blocks) t2 <<= 1;   // blocks <= 2^22 / 2^10 / 256 <= 16
-                k_sum_points<F29T><<<dim3(1, wins), t2, (size_t)t2 * ACC * 4, st>>>(tmp, blocks, result.p + (size_t)slot * ACC, 2);
-                CG_KERNEL_CHECK();
-            }
-        };
-        weighted(rows, R, 0, 0);
-        weighted(cols, C, 1, 1);
-    }
-    CG_HIP(hipMemcpyAsync(h_result.p, result.p, (size_t)wins * 2 * ACC * 4, hipMemcpyDeviceToHost, st));
+    const uint32_t C = 1u << red_cbits(bases->c), R = nb / C;
+    const size_t lds = (size_t)256 * ACC * 4;
+    k_bucket_rows_cols<F29T><<<dim3(R + C, wins), 256, lds, st>>>(bucket_sums.p, R, C, rows_buf.p, cols_buf.p);
+    CG_KERNEL_CHECK();
+    const uint32_t nbits = (uint32_t)(red_rbits + red_cbits1);
+    k_bit_sums<F29T><<<dim3(nbits, wins), 256, lds, st>>>(rows_buf.p, R, (uint32_t)red_rbits, cols_buf.p, C, result.p);
+    CG_KERNEL_CHECK();
+    CG_HIP(hipMemcpyAsync(h_result.p, result.p, (size_t)wins * nbits * ACC * 4, hipMemcpyDeviceToHost, st));
 }
 
 // ---- host: lazy 29-bit accumulator -> saturated Montgomery(2^256) XYZZ ---------------------------------
@@ -939,26 +956,36 @@ static XYZZ<F> xyzz_from_words(const uint32_t* w, int acc_words) {
     return r;
 }
 
-// one window's sum: 2^cbits · (rows part) + (columns part)
+// Σ_k 2^k·B_k over the per-bit sums B_0 .. B_{n-1} (Horner from the top bit)
 template <class F>
-static XYZZ<F> window_value(const uint32_t* two_acc, int acc_words, int cbits) {
-    XYZZ<F> rows = xyzz_from_words<F>(two_acc, acc_words);
-    XYZZ<F> cols = xyzz_from_words<F>(two_acc + acc_words, acc_words);
-    for (int k = 0; k < cbits; ++k) rows = dbl(rows);
+static XYZZ<F> fold_bits(const uint32_t* bit_sums, int n, int acc_words) {
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int k = n - 1; k >= 0; --k) {
+        acc = dbl(acc);
+        add(acc, xyzz_from_words<F>(bit_sums + (size_t)k * acc_words, acc_words));
+    }
+    return acc;
+}
+// one window's sum: 2^cbits · Σ_r r·Row_r + Σ_col (col+1)·Col_col from the per-bit sums of rows and columns
+template <class F>
+static XYZZ<F> window_value(const uint32_t* bit_sums, int acc_words, int rbits, int cbits1) {
+    XYZZ<F> rows = fold_bits<F>(bit_sums, rbits, acc_words);
+    XYZZ<F> cols = fold_bits<F>(bit_sums + (size_t)rbits * acc_words, cbits1, acc_words);
+    for (int k = 0; k < cbits1 - 1; ++k) rows = dbl(rows);
     add(rows, cols);
     return rows;
 }
 
 template <class F>
 XYZZ<F> MsmEngine<F>::value() const {
-    const int cbits = (bases->c - 1 + 1) / 2 > 10 ? 10 : (bases->c - 1 + 1) / 2;
-    if (bases->precomputed) return window_value<F>(h_result.p, ACC, cbits);
+    const int nbits = red_rbits + red_cbits1;
+    if (bases->precomputed) return window_value<F>(h_result.p, ACC, red_rbits, red_cbits1);
     // Horner over the windows: Σ_j 2^(c j) S_j
     const int W = bases->W, c = bases->c;
     XYZZ<F> acc = XYZZ<F>::inf();
     for (int j = W - 1; j >= 0; --j) {
         for (int k = 0; k < c; ++k) acc = dbl(acc);
-        add(acc, window_value<F>(h_result.p + (size_t)j * 2 * ACC, ACC, cbits));
+        add(acc, window_value<F>(h_result.p + (size_t)j * nbits * ACC, ACC, red_rbits, red_cbits1));
     }
     return acc;
 }

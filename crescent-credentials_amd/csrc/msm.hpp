@@ -54,9 +54,9 @@ struct MsmEngine {
     DevBuf<uint32_t> bucket_sums;     // nbuckets_total * ACC
     DevBuf<uint32_t> part_keys_a, part_keys_b;
     DevBuf<uint32_t> part_pts_a, part_pts_b;
-    DevBuf<uint32_t> red_a, red_b;
     DevBuf<uint32_t> rows_buf, cols_buf;   // row / column sums of the bucket matrix (bucket reduction)
-    DevBuf<uint32_t> result;          // W_keyspace accumulators (1 when precomputed)
+    int red_rbits = 0, red_cbits1 = 0;     // bits of the row weights r < R and of the column weights col + 1 <= C
+    DevBuf<uint32_t> result;          // per window: red_rbits + red_cbits1 per-bit sums of the rows / the columns
     PinnedBuf<uint64_t> h_count;      // low word: entries, high word: scalars with a non-zero digit
     PinnedBuf<uint32_t> h_result;
     bool dense = false;       // expect (nearly) no zero digits: fixed-stride emission, no count / prefix sum / host wait

@@ -96,6 +96,7 @@ def test_groth16_prove_call_shape_and_cache(cc, oracle, af, cache_dir):
     pp = cc.ProverParams.from_bytes(cache_dir["pp"])
     r1cs = cc.R1CSFile(cache_dir["r1cs"])
     circuit = cc.CircomCircuit(r1cs, cache_dir["w"])
+    cc.Groth16.clear_cache()
     try:
         p1 = cc.Groth16.prove(pp.groth16_params, circuit, random.Random(5))
         p2 = cc.Groth16.prove(pp.groth16_params, circuit, random.Random(5))
