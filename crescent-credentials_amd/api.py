@@ -143,12 +143,27 @@ _SIGNATURES = {
 _lib = None
 
 
+def _init_torch_runtime_first() -> None:
+    """A Python process that uses torch tensors next to this library holds TWO HIP runtimes: the ROCm one
+    libcrescent_gpu.so links and the copy bundled in the torch wheel (different SONAMEs, so the loader keeps both).
+    Measured on the MI355X pool: with the bundled runtime initialised first both work; the other way round torch then
+    reports "No HIP GPUs are available".  So when torch is present its runtime is brought up before the library is
+    loaded.  Hosts without torch (the Rust shim) are not affected."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+
+
 def lib() -> C.CDLL:
     """The HIP library.  Raises if it has not been built: there is deliberately no fallback."""
     global _lib
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             raise CrescentGpuError(-2, "%s not found; run `python -c 'import __graft_entry__ as g; g.build()'`" % _LIB_PATH)
+        _init_torch_runtime_first()
         L = C.CDLL(_LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)
