@@ -5,25 +5,22 @@
 // the signed-digit recoding and the order of additions are free design choices; only the final
 // affine point is observable (prover.rs:131-135).
 //
-// Pipeline (all on one stream):
-//   digits   : every canonical scalar -> W signed c-bit digits; zero digits and identity bases are
-//              dropped; survivors become one 64-bit entry each (bucket << 32 | table index | sign),
-//              compacted with a deterministic prefix sum - or, for uniform scalars (the h MSM), written
-//              at a fixed window-major stride with a filler key for the rare zero digit (no count, no
-//              prefix sum, no host wait).
-//   sort     : rocPRIM Onesweep on the key bits only (c-1, +1 in the dense form), ten bits per pass.
-//   accumulate: the sorted list is cut into equal segments, one per lane, so every lane of every
+// Pipeline (all on one stream, no step waits for the host):
+//   group    : every canonical scalar -> W signed c-bit digits; zero digits and identity bases are dropped;
+//              survivors become one 64-bit entry each (bucket << 32 | table index | sign) and are PLACED
+//              next to the other entries of their bucket by a two-level counting partition with the digit
+//              extraction fused into both of its passes (k_part_*): no sort, no compaction scan.
+//   accumulate: the grouped list is cut into equal segments, one per lane, so every lane of every
 //              wave performs the same number of mixed additions regardless of how skewed the
 //              buckets are (circom witnesses are dominated by 0/1 wires).  A lane flushes runs that
 //              lie wholly inside its segment straight to the bucket array and hands the first/last
-//              run up as a partial; partials are reduced by the same kernel recursively.
-//   reduce   : Σ (b+1)·S_b through row and column sums of the bucket matrix (all tree-parallel) and two
-//              short weighted sums.
+//              run up as a piece; pieces are combined 64 segments per wave (k_combine_wave).
+//   reduce   : Σ (b+1)·S_b through row and column sums of the bucket matrix and per-bit sums of those,
+//              folded on the host.
 // All curve arithmetic here runs on the lazy 29-bit-limb representation (field29.cuh / curve29.cuh).
 #include "msm.hpp"
 
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 
 namespace cg {
 
@@ -245,65 +242,219 @@ __device__ __forceinline__ void for_each_digit(const uint32_t s[8], int c, int W
     }
 }
 
-__global__ void __launch_bounds__(256) k_digit_count(const Fr* __restrict__ scalars, const uint8_t* __restrict__ valid,
-                                                     uint64_t n, int c, int W, uint64_t* __restrict__ counts) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t cnt = 0;
-    if (valid[i]) {
-        Fr s = scalars[i];
-        for_each_digit(s.l, c, W, [&](int, int32_t d) { cnt += (d != 0); });
-    }
-    // the high word counts the scalars that contribute at all (statistics for the window choice); one scan sums both
-    counts[i] = (uint64_t)cnt | ((uint64_t)(cnt != 0) << 32);
-}
+// ---------------------------------------------------------------------------------------------
+// grouping the digit entries by bucket: a two-level counting partition, no sort
+//
+// The accumulation only needs the entries of a bucket to be contiguous; their order inside the bucket and the order of
+// the buckets do not matter (the sum is a group element).  So the entries are never sorted: they are PLACED.
+//   level 1  k_part_count   every block walks its tile of scalars, extracts the signed digits and counts them by the
+//                           high bits of the bucket key in LDS; the block's counts go to its row of `blk_hist` and,
+//                           with one atomic per non-empty bin, to the global histogram
+//            k_part_plan    one block: entry total, segment length and count for the accumulation, bin starts
+//                           (exclusive scan), and the chunk table of level 2
+//            k_part_place   the same walk again; a block reserves its range of every bin with one global atomic and
+//                           hands out slots inside it with LDS atomics: digit extraction is fused into the placement,
+//                           so the entry list is written once and never read back by a "sort"
+//   level 2  k_part_count2 / k_part_place2   the same on the low key bits inside every level-1 bin, chunk by chunk
+//                           (a chunk is at most PART_CHUNK entries of one bin, so a dominant bucket - the 0/1 wires
+//                           of a circom witness - is spread over many blocks)
+// Key spaces of at most PART_MAX_BITS bits take level 1 only.  Everything the later kernels need to know about the
+// entry count lives in `plan` on the device: no kernel launch waits for the host.
+// ---------------------------------------------------------------------------------------------
+static constexpr int PART_MAX_BITS = 12;          // bins of one level: at most 4096 LDS counters
+static constexpr uint32_t PART_TILE = 1024;       // scalars per block, level 1
+static constexpr uint32_t PART_CHUNK = 8192;      // entries per block, level 2
+enum { PLAN_N = 0, PLAN_L = 1, PLAN_T = 2, PLAN_NONZERO = 3, PLAN_CHUNKS = 4, PLAN_WORDS = 8 };
 
-__global__ void __launch_bounds__(256) k_digit_emit(const Fr* __restrict__ scalars, const uint8_t* __restrict__ valid,
-                                                    uint64_t n, int c, int W, const uint64_t* __restrict__ incl,
-                                                    uint64_t* __restrict__ entries, int precomputed, uint64_t row_stride) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+struct PartShape {
+    uint32_t n;            // scalars
+    int c, W;              // window bits, windows
+    int precomputed;       // 1: key = |d| - 1, value = j * row_stride + i;  0: key = j * nb + |d| - 1, value = i
+    uint32_t row_stride;
+    int bits1, bits2;      // key bits taken by level 1 (high) and level 2 (low; 0 = single level)
+};
+
+template <class Fn>
+__device__ __forceinline__ void for_each_entry(const PartShape& sh, const Fr* __restrict__ scalars, const uint8_t* __restrict__ valid,
+                                               uint32_t i, Fn f) {
     if (!valid[i]) return;
-    uint32_t pos = i ? (uint32_t)incl[i - 1] : 0u;
-    Fr s = scalars[i];
-    const uint32_t nb = 1u << (c - 1);
-    for_each_digit(s.l, c, W, [&](int j, int32_t d) {
-        if (d != 0) {
-            uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-            uint32_t sign = d < 0 ? 0x80000000u : 0u;
-            if (precomputed) entries[pos] = ((uint64_t)(mag - 1u) << 32) | ((uint32_t)((uint64_t)j * row_stride + i) | sign);
-            else entries[pos] = ((uint64_t)((uint32_t)j * nb + (mag - 1u)) << 32) | ((uint32_t)i | sign);
-            ++pos;
-        }
+    const Fr s = scalars[i];
+    const uint32_t nb = 1u << (sh.c - 1);
+    for_each_digit(s.l, sh.c, sh.W, [&](int j, int32_t d) {
+        if (d == 0) return;
+        const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+        const uint32_t sign = d < 0 ? 0x80000000u : 0u;
+        if (sh.precomputed) f(mag - 1u, ((uint32_t)j * sh.row_stride + i) | sign);
+        else f((uint32_t)j * nb + (mag - 1u), i | sign);
     });
 }
 
-// Dense form for scalar populations without zero digits to speak of (the h MSM: uniform field elements): entry
-// slot = window * n + scalar, so the writes of a wave are contiguous, no count / prefix sum is needed and the host
-// knows the entry count in advance.  A zero digit or an identity base leaves a filler record whose key is the
-// bucket count: it sorts behind every real entry and the accumulation skips it.
-__global__ void __launch_bounds__(256) k_digit_emit_dense(const Fr* __restrict__ scalars, const uint8_t* __restrict__ valid,
-                                                          uint64_t n, int c, int W, uint64_t* __restrict__ entries,
-                                                          uint64_t row_stride) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t nb = 1u << (c - 1);
-    const uint64_t filler = (uint64_t)nb << 32;
-    int next = 0;                                   // windows below `next` are written
-    if (valid[i]) {
-        Fr s = scalars[i];
-        for_each_digit(s.l, c, W, [&](int j, int32_t d) {
-            uint64_t e = filler;
-            if (d != 0) {
-                uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-                uint32_t sign = d < 0 ? 0x80000000u : 0u;
-                e = ((uint64_t)(mag - 1u) << 32) | ((uint32_t)((uint64_t)j * row_stride + i) | sign);
-            }
-            entries[(uint64_t)j * n + i] = e;
-            next = j + 1;
+__global__ void __launch_bounds__(256) k_part_count(PartShape sh, const Fr* __restrict__ scalars, const uint8_t* __restrict__ valid,
+                                                    uint32_t* __restrict__ blk_hist, uint32_t* __restrict__ hist1,
+                                                    uint32_t* __restrict__ plan) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t B1 = 1u << sh.bits1;
+    for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) lds[k] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * PART_TILE;
+    uint32_t nonzero = 0;
+    for (uint32_t k = threadIdx.x; k < PART_TILE; k += blockDim.x) {
+        const uint32_t i = base + k;
+        if (i >= sh.n) break;
+        bool any = false;
+        for_each_entry(sh, scalars, valid, i, [&](uint32_t key, uint32_t) {
+            atomicAdd(&lds[key >> sh.bits2], 1u);
+            any = true;
+        });
+        nonzero += any;
+    }
+    for (int off = 32; off > 0; off >>= 1) nonzero += __shfl_down((int)nonzero, off, 64);
+    if ((threadIdx.x & 63) == 0 && nonzero) atomicAdd(&plan[PLAN_NONZERO], nonzero);
+    __syncthreads();
+    uint32_t* row = blk_hist + (size_t)blockIdx.x * B1;
+    for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) {
+        const uint32_t v = lds[k];
+        row[k] = v;
+        if (v) atomicAdd(&hist1[k], v);
+    }
+}
+
+// exclusive scan of `vals` (n <= 4096, in LDS `sc` of n words) by one block; total returned to every thread
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t* sc, uint32_t n) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t grand;
+    const uint32_t per = (n + blockDim.x - 1) / blockDim.x;
+    const uint32_t lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    uint32_t sum = 0;
+    for (uint32_t k = lo; k < hi; ++k) sum += sc[k];
+    uint32_t incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t v = (uint32_t)__shfl_up((int)incl, off, 64);
+        if ((threadIdx.x & 63) >= (uint32_t)off) incl += v;
+    }
+    if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t w = 0; w < (blockDim.x + 63) / 64; ++w) { uint32_t t = wave_tot[w]; wave_tot[w] = run; run += t; }
+        grand = run;
+    }
+    __syncthreads();
+    uint32_t run = wave_tot[threadIdx.x >> 6] + incl - sum;
+    for (uint32_t k = lo; k < hi; ++k) { uint32_t t = sc[k]; sc[k] = run; run += t; }
+    __syncthreads();
+    return grand;
+}
+
+// start1[b] = first slot of level-1 bin b (B1 + 1 values); chunk0[b] = first level-2 chunk of bin b (B1 + 1 values)
+__global__ void __launch_bounds__(1024) k_part_plan(int bits1, int two_level, const uint32_t* __restrict__ hist1,
+                                                    uint32_t* __restrict__ start1, uint32_t* __restrict__ chunk0,
+                                                    uint32_t* __restrict__ plan, uint32_t target_threads, uint32_t min_L) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t B1 = 1u << bits1;
+    for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) lds[k] = hist1[k];
+    __syncthreads();
+    const uint32_t N = block_exclusive_scan(lds, B1);
+    for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) start1[k] = lds[k];
+    if (threadIdx.x == 0) {
+        start1[B1] = N;
+        uint32_t L = (uint32_t)(((uint64_t)N + target_threads - 1) / target_threads);
+        if (L < min_L) L = min_L;
+        plan[PLAN_N] = N;
+        plan[PLAN_L] = L;
+        plan[PLAN_T] = N ? (N + L - 1) / L : 0;
+    }
+    if (!two_level) return;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) lds[k] = (hist1[k] + PART_CHUNK - 1) / PART_CHUNK;
+    __syncthreads();
+    const uint32_t chunks = block_exclusive_scan(lds, B1);
+    for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) chunk0[k] = lds[k];
+    if (threadIdx.x == 0) { chunk0[B1] = chunks; plan[PLAN_CHUNKS] = chunks; }
+}
+
+__global__ void __launch_bounds__(256) k_part_place(PartShape sh, const Fr* __restrict__ scalars, const uint8_t* __restrict__ valid,
+                                                    const uint32_t* __restrict__ blk_hist, const uint32_t* __restrict__ start1,
+                                                    uint32_t* __restrict__ cur1, uint64_t* __restrict__ out) {
+    extern __shared__ uint32_t lds[];                 // [B1] next slot of the bin for this block
+    const uint32_t B1 = 1u << sh.bits1;
+    const uint32_t* row = blk_hist + (size_t)blockIdx.x * B1;
+    for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) {
+        const uint32_t cnt = row[k];
+        lds[k] = cnt ? start1[k] + atomicAdd(&cur1[k], cnt) : 0u;
+    }
+    __syncthreads();
+    const uint32_t base = blockIdx.x * PART_TILE;
+    for (uint32_t k = threadIdx.x; k < PART_TILE; k += blockDim.x) {
+        const uint32_t i = base + k;
+        if (i >= sh.n) break;
+        for_each_entry(sh, scalars, valid, i, [&](uint32_t key, uint32_t val) {
+            const uint32_t pos = atomicAdd(&lds[key >> sh.bits2], 1u);
+            out[pos] = ((uint64_t)key << 32) | val;
         });
     }
-    for (int j = next; j < W; ++j) entries[(uint64_t)j * n + i] = filler;   // for_each_digit stops above the top limb
+}
+
+// the level-1 bin and the entry range of level-2 chunk `c`
+__device__ __forceinline__ bool chunk_range(uint32_t c, int bits1, const uint32_t* __restrict__ chunk0, const uint32_t* __restrict__ start1,
+                                            uint32_t& bin, uint32_t& beg, uint32_t& end) {
+    const uint32_t B1 = 1u << bits1;
+    if (c >= chunk0[B1]) return false;
+    uint32_t lo = 0, hi = B1;                         // last bin with chunk0[bin] <= c
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (chunk0[mid] <= c) lo = mid; else hi = mid;
+    }
+    bin = lo;
+    beg = start1[bin] + (c - chunk0[bin]) * PART_CHUNK;
+    end = beg + PART_CHUNK < start1[bin + 1] ? beg + PART_CHUNK : start1[bin + 1];
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_part_count2(int bits1, int bits2, const uint64_t* __restrict__ in,
+                                                     const uint32_t* __restrict__ chunk0, const uint32_t* __restrict__ start1,
+                                                     uint32_t* __restrict__ hist2) {
+    extern __shared__ uint32_t lds[];
+    uint32_t bin, beg, end;
+    if (!chunk_range(blockIdx.x, bits1, chunk0, start1, bin, beg, end)) return;
+    const uint32_t B2 = 1u << bits2;
+    for (uint32_t k = threadIdx.x; k < B2; k += blockDim.x) lds[k] = 0;
+    __syncthreads();
+    for (uint32_t k = beg + threadIdx.x; k < end; k += blockDim.x) atomicAdd(&lds[(uint32_t)(in[k] >> 32) & (B2 - 1u)], 1u);
+    __syncthreads();
+    uint32_t* g = hist2 + ((size_t)bin << bits2);
+    for (uint32_t k = threadIdx.x; k < B2; k += blockDim.x) {
+        const uint32_t v = lds[k];
+        if (v) atomicAdd(&g[k], v);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_part_place2(int bits1, int bits2, const uint64_t* __restrict__ in,
+                                                     const uint32_t* __restrict__ chunk0, const uint32_t* __restrict__ start1,
+                                                     const uint32_t* __restrict__ hist2, uint32_t* __restrict__ cur2,
+                                                     uint64_t* __restrict__ out) {
+    extern __shared__ uint32_t lds[];                 // [B2] counts of this chunk, then next slots; [B2] bin starts
+    uint32_t bin, beg, end;
+    if (!chunk_range(blockIdx.x, bits1, chunk0, start1, bin, beg, end)) return;
+    const uint32_t B2 = 1u << bits2;
+    uint32_t* cnt = lds;
+    uint32_t* st = lds + B2;
+    for (uint32_t k = threadIdx.x; k < B2; k += blockDim.x) { cnt[k] = 0; st[k] = hist2[((size_t)bin << bits2) + k]; }
+    __syncthreads();
+    for (uint32_t k = beg + threadIdx.x; k < end; k += blockDim.x) atomicAdd(&cnt[(uint32_t)(in[k] >> 32) & (B2 - 1u)], 1u);
+    (void)block_exclusive_scan(st, B2);               // starts of the fine bins inside this level-1 bin
+    const uint32_t bin_start = start1[bin];
+    uint32_t* g = cur2 + ((size_t)bin << bits2);
+    for (uint32_t k = threadIdx.x; k < B2; k += blockDim.x) {
+        const uint32_t c = cnt[k];
+        cnt[k] = c ? bin_start + st[k] + atomicAdd(&g[k], c) : 0u;
+    }
+    __syncthreads();
+    for (uint32_t k = beg + threadIdx.x; k < end; k += blockDim.x) {
+        const uint64_t e = in[k];
+        const uint32_t pos = atomicAdd(&cnt[(uint32_t)(e >> 32) & (B2 - 1u)], 1u);
+        out[pos] = e;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -323,11 +474,12 @@ __device__ __forceinline__ void flush_run(uint32_t key, const XYZZ29<F29T>& acc,
 }
 
 template <class F29T>
-__global__ void __launch_bounds__(256) k_accum_affine(const uint64_t* __restrict__ entries,
-                                                      uint32_t N, uint32_t L, uint32_t T, const uint32_t* __restrict__ table,
+__global__ void __launch_bounds__(256) k_accum_affine(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ plan,
+                                                      const uint32_t* __restrict__ table,
                                                       uint32_t* __restrict__ bucket_sums, uint32_t* __restrict__ part_keys,
-                                                      uint32_t* __restrict__ part_pts, uint32_t filler_key) {
+                                                      uint32_t* __restrict__ part_pts) {
     constexpr int ACC = Words29<F29T>::ACC;
+    const uint32_t N = plan[PLAN_N], L = plan[PLAN_L], T = plan[PLAN_T];   // written by k_part_plan
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     const bool final_level = (T == 1);
@@ -346,7 +498,6 @@ __global__ void __launch_bounds__(256) k_accum_affine(const uint64_t* __restrict
             inf = true;
             cur = key;
         }
-        if (key == filler_key) continue;         // dense-mode filler (run of the spare bucket; never read back)
         Affine29<F29T> p = load_table_point<F29T>(table, v & 0x7fffffffu, (v >> 31) != 0);
         madd29(acc, inf, p);
     }
@@ -443,13 +594,13 @@ __device__ __forceinline__ void madd29_lds(uint32_t* sl, bool& inf, const uint32
 __device__ __forceinline__ XYZZ29<Fq2_29> lacc_all(const uint32_t* sl) { return {lacc_ld(sl, 0), lacc_ld(sl, 1), lacc_ld(sl, 2), lacc_ld(sl, 3)}; }
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_accum_affine_g2(const uint64_t* __restrict__ entries, uint32_t N, uint32_t L, uint32_t T, const uint32_t* __restrict__ table,
-                  uint32_t* __restrict__ bucket_sums, uint32_t* __restrict__ part_keys, uint32_t* __restrict__ part_pts,
-                  uint32_t filler_key) {
+k_accum_affine_g2(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ plan, const uint32_t* __restrict__ table,
+                  uint32_t* __restrict__ bucket_sums, uint32_t* __restrict__ part_keys, uint32_t* __restrict__ part_pts) {
     typedef Fq2_29 F29T;
     constexpr int ACC = Words29<F29T>::ACC;
     __shared__ uint32_t sm[ACC * 256];
     uint32_t* sl = sm + threadIdx.x;
+    const uint32_t N = plan[PLAN_N], L = plan[PLAN_L], T = plan[PLAN_T];
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     const bool final_level = (T == 1);
@@ -467,7 +618,6 @@ k_accum_affine_g2(const uint64_t* __restrict__ entries, uint32_t N, uint32_t L, 
             inf = true;
             cur = key;
         }
-        if (key == filler_key) continue;
         madd29_lds(sl, inf, table, v & 0x7fffffffu, (v >> 31) != 0);
     }
     const XYZZ29<F29T> acc = lacc_all(sl);
@@ -484,13 +634,14 @@ k_accum_affine_g2(const uint64_t* __restrict__ entries, uint32_t N, uint32_t L, 
     }
 }
 
+// T_max: the largest segment count the plan can hold for this engine (lanes beyond the plan's T return at once)
 template <class F29T>
-static void launch_accum_affine(const uint64_t* entries, uint32_t N, uint32_t L, uint32_t T, const uint32_t* table, uint32_t* bucket_sums,
-                                uint32_t* part_keys, uint32_t* part_pts, uint32_t filler_key, hipStream_t st) {
+static void launch_accum_affine(const uint64_t* entries, const uint32_t* plan, uint32_t T_max, const uint32_t* table, uint32_t* bucket_sums,
+                                uint32_t* part_keys, uint32_t* part_pts, hipStream_t st) {
     if constexpr (Words29<F29T>::NF == 2)
-        k_accum_affine_g2<<<ceil_div(T, 256), 256, 0, st>>>(entries, N, L, T, table, bucket_sums, part_keys, part_pts, filler_key);
+        k_accum_affine_g2<<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
     else
-        k_accum_affine<F29T><<<ceil_div(T, 256), 256, 0, st>>>(entries, N, L, T, table, bucket_sums, part_keys, part_pts, filler_key);
+        k_accum_affine<F29T><<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
 }
 
 template <class F29T>
@@ -565,13 +716,22 @@ __device__ __forceinline__ XYZZ29<F29T> shfl_up_acc(const XYZZ29<F29T>& a, unsig
     return r;
 }
 
+// T = the segment count of this level (T_fixed), or, when `plan` is given, the plan's count divided by 64 `level` times
 template <class F29T>
 __global__ void __launch_bounds__(64) k_combine_wave(const uint32_t* __restrict__ in_keys, const uint32_t* __restrict__ in_pts,
-                                                     uint32_t T, uint32_t* __restrict__ bucket_sums,
+                                                     const uint32_t* __restrict__ plan, int level, uint32_t T_fixed,
+                                                     uint32_t* __restrict__ bucket_sums,
                                                      uint32_t* __restrict__ out_keys, uint32_t* __restrict__ out_pts) {
     constexpr int ACC = Words29<F29T>::ACC;
+    uint32_t T = T_fixed;
+    if (plan) {
+        T = plan[PLAN_T];
+        for (int k = 0; k < level; ++k) T = (T + 63u) >> 6;
+    }
+    if (T <= 1) return;                            // nothing left to combine: the level below wrote the buckets itself
     const uint32_t lane = threadIdx.x, wv = blockIdx.x, t = wv * 64u + lane;
-    const bool final_level = gridDim.x == 1;
+    if (wv * 64u >= T) return;
+    const bool final_level = T <= 64;
     uint32_t kF = NO_KEY, kL = NO_KEY;
     XYZZ29<F29T> A, B;
     bool Ainf = true, Binf = true;
@@ -719,19 +879,15 @@ static constexpr uint32_t ACC_LEVEL_L = 8;   // segment length of the partial-co
 // shape of the bucket matrix of a window: nb = R·C buckets, C = 2^cbits columns (at most 1024)
 static int red_cbits(int c) { return (c - 1 + 1) / 2 > 10 ? 10 : (c - 1 + 1) / 2; }
 
-static uint32_t level1_L(uint64_t N) {
-    uint64_t L = (N + ACC_TARGET_THREADS - 1) / ACC_TARGET_THREADS;
-    if (L < ACC_MIN_L) L = ACC_MIN_L;
-    return (uint32_t)L;
+// key bits of an engine's entries and their split over the two partition levels
+static void part_bits(int c, int W, bool precomputed, int& bits1, int& bits2) {
+    int key_bits = c - 1;
+    if (!precomputed) key_bits += ilog2_ceil((uint64_t)W);      // key = window * nb + |d| - 1, with nb a power of two
+    if (key_bits < 1) key_bits = 1;
+    if (key_bits <= PART_MAX_BITS) { bits1 = key_bits; bits2 = 0; return; }
+    bits1 = (key_bits + 1) / 2;
+    bits2 = key_bits - bits1;
 }
-
-// Digit entries are 64-bit records sorted on at most 21 key bits: ten bits per Onesweep pass (two passes instead of
-// rocPRIM's three at its default eight), and Onesweep rather than the ~12-launch merge sort for the small MSMs too.
-using EntrySortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                   rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>,
-                                                                                       rocprim::kernel_config<1024, 8>, 10,
-                                                                                       rocprim::block_radix_rank_algorithm::match>,
-                                                   (size_t)1 << 16>;
 
 template <class F>
 void MsmEngine<F>::init(const MsmBases<F>* b) {
@@ -743,17 +899,22 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
     if (cap_entries == 0) cap_entries = 1;
     const uint32_t nb = 1u << (b->c - 1);
     nbuckets_total = b->precomputed ? nb : nb * (uint32_t)W;
-    ent_a.alloc(cap_entries); ent_b.alloc(cap_entries);
-    thread_counts.alloc(n ? n : 1);
-    // rocPRIM temp sizes for the worst case
-    size_t scan_bytes = 0, sort_bytes = 0;
-    (void)rocprim::inclusive_scan(nullptr, scan_bytes, thread_counts.p, thread_counts.p, (size_t)(n ? n : 1), rocprim::plus<uint64_t>());
-    (void)rocprim::radix_sort_keys<EntrySortConfig>(nullptr, sort_bytes, ent_a.p, ent_b.p, (size_t)cap_entries, 32u, 64u);
-    sort_tmp_bytes = scan_bytes > sort_bytes ? scan_bytes : sort_bytes;
-    sort_tmp.alloc(sort_tmp_bytes ? sort_tmp_bytes : 1);
-    bucket_sums.alloc(((size_t)nbuckets_total + 1) * ACC);     // + the spare bucket of the dense mode's filler records
+    part_bits(b->c, W, b->precomputed, bits1, bits2);
+    if (bits1 > PART_MAX_BITS || bits2 > PART_MAX_BITS) throw HipError(CG_ERR_INVALID_ARGUMENT, "bucket key space too large");
+    ent_a.alloc(cap_entries);
+    ent_b.alloc(bits2 ? cap_entries : 1);
+    const uint32_t B1 = 1u << bits1;
+    const uint64_t tiles = n ? ceil_div(n, PART_TILE) : 1;
+    blk_hist.alloc(tiles * B1);
+    // zeroed per MSM in one fill: plan | level-1 histogram | level-1 cursors | level-2 histogram | level-2 cursors
+    const size_t keyspace = bits2 ? ((size_t)1 << (bits1 + bits2)) : 0;
+    counters.alloc(PLAN_WORDS + 2 * (size_t)B1 + 2 * keyspace);
+    starts.alloc(2 * ((size_t)B1 + 1) + 2);                    // start1[B1 + 1] | chunk0[B1 + 1]
+    max_chunks = bits2 ? (uint32_t)(cap_entries / PART_CHUNK) + B1 + 1 : 0;
+    bucket_sums.alloc(((size_t)nbuckets_total + 1) * ACC);
     uint64_t t1 = (cap_entries + ACC_MIN_L - 1) / ACC_MIN_L;
     if (t1 > ACC_TARGET_THREADS) t1 = ACC_TARGET_THREADS;
+    max_segments = (uint32_t)t1;
     const uint64_t pa = 2 * t1, pb = 2 * ceil_div(t1, 64);   // two pieces per segment, then two per wave of 64 segments
     part_keys_a.alloc(pa); part_pts_a.alloc(pa * ACC);
     part_keys_b.alloc(pb); part_pts_b.alloc(pb * ACC);
@@ -767,12 +928,11 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
         cols_buf.alloc((size_t)C * wins * ACC);
     }
     result.alloc((size_t)wins * (red_rbits + red_cbits1) * ACC);      // per window: the per-bit sums of rows, then of columns
-    h_count.alloc(1);
+    h_plan.alloc(PLAN_WORDS);
+    for (int k = 0; k < PLAN_WORDS; ++k) h_plan.p[k] = 0;
     h_result.alloc((size_t)wins * (red_rbits + red_cbits1) * ACC);
-    if (!ev_count) {
-        CG_HIP(hipEventCreateWithFlags(&ev_count, hipEventDisableTiming));
+    if (!ev_t[0])
         for (auto& e : ev_t) CG_HIP(hipEventCreate(&e));
-    }
 }
 
 static float elapsed_ms(hipEvent_t a, hipEvent_t b) {
@@ -781,88 +941,82 @@ static float elapsed_ms(hipEvent_t a, hipEvent_t b) {
     return ms;
 }
 template <class F> float MsmEngine<F>::ms_total() const { return elapsed_ms(ev_t[0], ev_t[5]); }
-template <class F> float MsmEngine<F>::ms_sort() const { return n_entries ? elapsed_ms(ev_t[1], ev_t[2]) : 0.f; }
-template <class F> float MsmEngine<F>::ms_accum() const { return n_entries ? elapsed_ms(ev_t[3], ev_t[4]) : 0.f; }
+template <class F> float MsmEngine<F>::ms_sort() const { return n_scalars ? elapsed_ms(ev_t[1], ev_t[2]) : 0.f; }
+template <class F> float MsmEngine<F>::ms_accum() const { return n_scalars ? elapsed_ms(ev_t[3], ev_t[4]) : 0.f; }
 
 template <class F>
 MsmEngine<F>::~MsmEngine() {
     if (red_graph) (void)hipGraphExecDestroy(red_graph);
-    if (ev_count) (void)hipEventDestroy(ev_count);
     for (auto& e : ev_t) if (e) (void)hipEventDestroy(e);
 }
 
+// phase 1: the entries of `n` canonical scalars, grouped by bucket (see "grouping the digit entries by bucket")
 template <class F>
 void MsmEngine<F>::digits(const Fr* scalars_dev, uint64_t n, hipStream_t st) {
     if (n > bases->n) n = bases->n;  // msm_bigint zips and truncates to the shorter operand
     n_scalars = n;
-    h_count.p[0] = 0;
+    for (int k = 0; k < PLAN_WORDS; ++k) h_plan.p[k] = 0;
     CG_HIP(hipEventRecord(ev_t[0], st));
     if (!n) return;
-    const int c = bases->c, W = bases->W;
-    dense_now = dense && bases->precomputed && c <= 20;      // the filler key needs one more key bit: keep two sort passes
-    if (dense_now) {
-        k_digit_emit_dense<<<ceil_div(n, 256), 256, 0, st>>>(scalars_dev, bases->valid.p, n, c, W, ent_a.p, bases->n);
+    const uint32_t B1 = 1u << bits1;
+    uint32_t* plan = counters.p;
+    uint32_t* hist1 = plan + PLAN_WORDS;
+    uint32_t* cur1 = hist1 + B1;
+    uint32_t* hist2 = cur1 + B1;
+    uint32_t* cur2 = hist2 + (bits2 ? ((size_t)1 << (bits1 + bits2)) : 0);
+    uint32_t* start1 = starts.p;
+    uint32_t* chunk0 = starts.p + B1 + 1;
+    PartShape sh;
+    sh.n = (uint32_t)n; sh.c = bases->c; sh.W = bases->W; sh.precomputed = bases->precomputed ? 1 : 0;
+    sh.row_stride = (uint32_t)bases->n;          // table row j starts at j * bases->n
+    sh.bits1 = bits1; sh.bits2 = bits2;
+    const uint32_t tiles = ceil_div(n, PART_TILE);
+    CG_HIP(hipEventRecord(ev_t[1], st));
+    fill_zero(counters.p, (counters.bytes() + 15) & ~(size_t)15, st);
+    k_part_count<<<tiles, 256, (size_t)B1 * 4, st>>>(sh, scalars_dev, bases->valid.p, blk_hist.p, hist1, plan);
+    CG_KERNEL_CHECK();
+    k_part_plan<<<1, 1024, (size_t)B1 * 4, st>>>(bits1, bits2 ? 1 : 0, hist1, start1, chunk0, plan, ACC_TARGET_THREADS, ACC_MIN_L);
+    CG_KERNEL_CHECK();
+    k_part_place<<<tiles, 256, (size_t)B1 * 4, st>>>(sh, scalars_dev, bases->valid.p, blk_hist.p, start1, cur1, ent_a.p);
+    CG_KERNEL_CHECK();
+    if (bits2) {
+        const uint32_t B2 = 1u << bits2;
+        k_part_count2<<<max_chunks, 256, (size_t)B2 * 4, st>>>(bits1, bits2, ent_a.p, chunk0, start1, hist2);
         CG_KERNEL_CHECK();
-        return;
+        k_part_place2<<<max_chunks, 256, (size_t)B2 * 8, st>>>(bits1, bits2, ent_a.p, chunk0, start1, hist2, cur2, ent_b.p);
+        CG_KERNEL_CHECK();
     }
-    k_digit_count<<<ceil_div(n, 256), 256, 0, st>>>(scalars_dev, bases->valid.p, n, c, W, thread_counts.p);
-    CG_KERNEL_CHECK();
-    size_t tmp = sort_tmp_bytes;
-    CG_HIP(rocprim::inclusive_scan(sort_tmp.p, tmp, thread_counts.p, thread_counts.p, (size_t)n, rocprim::plus<uint64_t>(), st));
-    CG_HIP(hipMemcpyAsync(h_count.p, thread_counts.p + (n - 1), 8, hipMemcpyDeviceToHost, st));
-    CG_HIP(hipEventRecord(ev_count, st));
-    k_digit_emit<<<ceil_div(n, 256), 256, 0, st>>>(scalars_dev, bases->valid.p, n, c, W, thread_counts.p, ent_a.p,
-                                                  bases->precomputed ? 1 : 0, bases->n);   // table row j starts at j * bases->n
-    CG_KERNEL_CHECK();
+    CG_HIP(hipEventRecord(ev_t[2], st));
 }
 
+// phase 2: accumulate the grouped entries into the buckets, combine the segments, reduce the buckets; the per-bit sums
+// and the plan (entry count, statistics) are copied to pinned memory.  Nothing here waits for the host.
 template <class F>
 void MsmEngine<F>::accumulate(hipStream_t st) {
-    const uint32_t nb = 1u << (bases->c - 1);
-    n_entries = 0;
-    n_nonzero = 0;
-    if (n_scalars && dense_now) {
-        n_entries = (uint32_t)(n_scalars * (uint64_t)bases->W);     // fixed layout: known without asking the device
-        n_nonzero = (uint32_t)n_scalars;
-    } else if (n_scalars) {
-        CG_HIP(hipEventSynchronize(ev_count));
-        n_entries = (uint32_t)h_count.p[0];
-        n_nonzero = (uint32_t)(h_count.p[0] >> 32);
-    }
     fill_zero(bucket_sums.p, bucket_sums.bytes(), st);
-    if (n_entries) {
-        const uint32_t N = n_entries;
-        int key_bits = bases->c - 1;
-        if (dense_now) key_bits += 1;            // the filler key is the bucket count itself
-        if (!bases->precomputed) key_bits += ilog2_ceil((uint64_t)bases->W);
-        if (key_bits < 1) key_bits = 1;
-        size_t tmp = sort_tmp_bytes;
-        CG_HIP(hipEventRecord(ev_t[1], st));
-        // one 64-bit record per entry, sorted on the key bits only (stable: ties keep emission order)
-        CG_HIP(rocprim::radix_sort_keys<EntrySortConfig>(sort_tmp.p, tmp, ent_a.p, ent_b.p, (size_t)N, 32u, 32u + (unsigned)key_bits, st));
-        CG_HIP(hipEventRecord(ev_t[2], st));
-        // level 1
-        uint32_t L = level1_L(N);
-        uint32_t T = ceil_div(N, L);
+    if (n_scalars) {
+        const uint32_t* plan = counters.p;
+        const uint64_t* grouped = bits2 ? ent_b.p : ent_a.p;
         CG_HIP(hipEventRecord(ev_t[3], st));
-        launch_accum_affine<F29T>(ent_b.p, N, L, T, bases->table.p, bucket_sums.p, part_keys_a.p, part_pts_a.p,
-                                  dense_now ? nb : 0xffffffffu, st);
+        launch_accum_affine<F29T>(grouped, plan, max_segments, bases->table.p, bucket_sums.p, part_keys_a.p, part_pts_a.p, st);
         CG_KERNEL_CHECK();
         CG_HIP(hipEventRecord(ev_t[4], st));
-        // combine the segments' pieces wave by wave until one wave covers them all (k_combine_wave)
+        // combine the segments' pieces wave by wave until one wave covers them all (k_combine_wave); the grids cover the
+        // largest plan this engine can see, waves beyond the actual one return at once
         bool from_a = true;
-        uint32_t segs = (T == 1) ? 0 : T;
-        while (segs) {
+        uint32_t segs = max_segments;
+        for (int level = 0; segs > 1; ++level) {
             const uint32_t waves = ceil_div(segs, 64u);
             const uint32_t* ik = from_a ? part_keys_a.p : part_keys_b.p;
             const uint32_t* ip = from_a ? part_pts_a.p : part_pts_b.p;
             uint32_t* ok = from_a ? part_keys_b.p : part_keys_a.p;
             uint32_t* op = from_a ? part_pts_b.p : part_pts_a.p;
-            k_combine_wave<F29T><<<waves, 64, 0, st>>>(ik, ip, segs, bucket_sums.p, ok, op);
+            k_combine_wave<F29T><<<waves, 64, 0, st>>>(ik, ip, plan, level, 0u, bucket_sums.p, ok, op);
             CG_KERNEL_CHECK();
-            segs = (waves == 1) ? 0 : waves;
+            segs = waves;
             from_a = !from_a;
         }
+        CG_HIP(hipMemcpyAsync(h_plan.p, plan, PLAN_WORDS * 4, hipMemcpyDeviceToHost, st));
     }
     // bucket reduction (see the comment above block_tree_sum): two launches and the copy of the per-bit sums, of a fixed
     // shape for a given window size - captured once into a HIP graph and replayed as one submission.

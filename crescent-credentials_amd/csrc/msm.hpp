@@ -47,26 +47,29 @@ struct MsmEngine {
     const MsmBases<F>* bases = nullptr;
     uint64_t cap_entries = 0;
     uint32_t nbuckets_total = 0;  // buckets per window * windows-in-key-space
-    DevBuf<uint64_t> ent_a, ent_b;    // digit entries: bucket key in the high word, table index | sign<<31 in the low word
-    DevBuf<uint64_t> thread_counts;   // per scalar: non-zero digit count (low word) + "has any" flag (high word); then their inclusive scan
-    DevBuf<uint8_t> sort_tmp;
-    size_t sort_tmp_bytes = 0;
+    // digit entries: bucket key in the high word, table index | sign<<31 in the low word; ent_a grouped by the high key
+    // bits (level 1), ent_b by the whole key (level 2; unused when one level covers the key)
+    DevBuf<uint64_t> ent_a, ent_b;
+    int bits1 = 0, bits2 = 0;         // key bits taken by the two partition levels
+    DevBuf<uint32_t> blk_hist;        // per level-1 block: its counts per bin
+    DevBuf<uint32_t> counters;        // plan | level-1 histogram, cursors | level-2 histogram, cursors (zeroed per MSM)
+    DevBuf<uint32_t> starts;          // level-1 bin starts | first level-2 chunk of every bin
+    uint32_t max_chunks = 0;          // launch bound of the level-2 kernels
+    uint32_t max_segments = 0;        // launch bound of the accumulation (the plan's segment count is at most this)
     DevBuf<uint32_t> bucket_sums;     // nbuckets_total * ACC
     DevBuf<uint32_t> part_keys_a, part_keys_b;
     DevBuf<uint32_t> part_pts_a, part_pts_b;
     DevBuf<uint32_t> rows_buf, cols_buf;   // row / column sums of the bucket matrix (bucket reduction)
     int red_rbits = 0, red_cbits1 = 0;     // bits of the row weights r < R and of the column weights col + 1 <= C
     DevBuf<uint32_t> result;          // per window: red_rbits + red_cbits1 per-bit sums of the rows / the columns
-    PinnedBuf<uint64_t> h_count;      // low word: entries, high word: scalars with a non-zero digit
+    PinnedBuf<uint32_t> h_plan;       // the device plan of the last MSM: [0] entries, [3] scalars with a non-zero digit
     PinnedBuf<uint32_t> h_result;
-    bool dense = false;       // expect (nearly) no zero digits: fixed-stride emission, no count / prefix sum / host wait
-    bool dense_now = false;   // ... in effect for the current MSM
     uint64_t n_scalars = 0;
-    uint32_t n_entries = 0;
-    uint32_t n_nonzero = 0;
+    // valid once the stream has been synchronised
+    uint32_t n_entries() const { return h_plan.p ? h_plan.p[0] : 0; }
+    uint32_t n_nonzero() const { return h_plan.p ? h_plan.p[3] : 0; }
     hipGraphExec_t red_graph = nullptr;   // the bucket reduction's launches, captured on first use (reset by init)
     void enqueue_reduction(hipStream_t st);
-    hipEvent_t ev_count = nullptr;
     // timing events (recorded on the MSM's own stream): digits start, sort begin/end, level-1
     // accumulation kernel begin/end, result ready
     hipEvent_t ev_t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -76,10 +79,10 @@ struct MsmEngine {
 
     void init(const MsmBases<F>* b);
     ~MsmEngine();
-    // phase 1: signed-digit extraction of `n` canonical scalars -> compacted (bucket, index) entries;
-    // the entry count is copied to pinned host memory asynchronously.
+    // phase 1: signed-digit extraction of `n` canonical scalars -> (bucket, index) entries grouped by bucket
     void digits(const Fr* scalars_dev, uint64_t n, hipStream_t st);
-    // phase 2 (waits for the count): sort by bucket, accumulate, reduce; result copied to h_result.
+    // phase 2: accumulate, combine, reduce; per-bit sums and the plan copied to pinned memory.  Neither phase waits
+    // for the host.
     void accumulate(hipStream_t st);
     // after the stream has been synchronised: the MSM value (host arithmetic, Montgomery 2^256 form)
     XYZZ<F> value() const;

@@ -347,7 +347,6 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
             }
             CG_HIP(hipEventCreateWithFlags(&sl->ev_w, hipEventDisableTiming));
             for (auto& e : sl->ev_t) CG_HIP(hipEventCreate(&e));
-            sl->eh.dense = true;     // the h MSM's scalars are uniform field elements
             sl->eh.init(&c->bh); sl->el.init(&c->bl); sl->ea.init(&c->ba); sl->eb1.init(&c->bb1); sl->eb2.init(&c->bb2);
             sl->w_canon.alloc(M); sl->h_canon.alloc(D);
             sl->wm.alloc(M, D);
@@ -443,10 +442,10 @@ static int prove_partial_impl(cg_ctx* c, ProofSlot* S, const void* assignment, b
         tm->accum_g1_ms = S->eh.ms_accum() + S->el.ms_accum() + S->ea.ms_accum() + (skip_b1 ? 0.f : S->eb1.ms_accum());
         tm->accum_g2_ms = S->eb2.ms_accum();
         tm->sort_ms = S->eh.ms_sort() + S->el.ms_sort() + S->ea.ms_sort() + (skip_b1 ? 0.f : S->eb1.ms_sort()) + S->eb2.ms_sort();
-        tm->entries_g1 = (uint64_t)S->eh.n_entries + S->el.n_entries + S->ea.n_entries + (skip_b1 ? 0 : S->eb1.n_entries);
-        tm->entries_g2 = S->eb2.n_entries;
-        tm->accum_g1_launches = (S->eh.n_entries != 0) + (S->el.n_entries != 0) + (S->ea.n_entries != 0) + (!skip_b1 && S->eb1.n_entries != 0);
-        tm->accum_g2_launches = S->eb2.n_entries != 0;
+        tm->entries_g1 = (uint64_t)S->eh.n_entries() + S->el.n_entries() + S->ea.n_entries() + (skip_b1 ? 0 : S->eb1.n_entries());
+        tm->entries_g2 = S->eb2.n_entries();
+        tm->accum_g1_launches = (S->eh.n_entries() != 0) + (S->el.n_entries() != 0) + (S->ea.n_entries() != 0) + (!skip_b1 && S->eb1.n_entries() != 0);
+        tm->accum_g2_launches = S->eb2.n_entries() != 0;
         tm->msm_g1_pairs = S->eh.n_scalars + S->el.n_scalars + S->ea.n_scalars + (skip_b1 ? 0 : S->eb1.n_scalars);
         tm->msm_g2_pairs = S->eb2.n_scalars;
         tm->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -525,13 +524,10 @@ static bool retune_query(cg_ctx* c, MsmBases<F>& bases, MsmEngine<F> ProofSlot::
     MsmEngine<F>& e = S->*eng;
     if (!e.n_scalars || !bases.n) return false;
     const int W0 = bases.W;
-    double nz = e.n_nonzero, N = e.n_entries;
+    double nz = e.n_nonzero(), N = e.n_entries();
     double nz_full = W0 > 1 ? (N - nz) / (double)(W0 - 1) : 0.0;
     if (nz_full < 0) nz_full = 0;
     if (nz_full > nz) nz_full = nz;
-    // a population that fills (nearly) every window - uniform scalars - takes the dense digit form from now on
-    const bool dense = N >= 0.98 * (double)e.n_scalars * (double)W0;
-    for (auto& sl : c->slots) ((*sl).*eng).dense = dense;
     int best = msm_best_window(bases.n, nz - nz_full, nz_full);
     if (best == bases.c) return false;
     bases.rebuild(best, st);
@@ -548,7 +544,7 @@ static void maybe_retune(cg_ctx* c) {
     // A degenerate first assignment (all zero, or next to it) says nothing about the proofs to come: its statistics
     // would pick the narrowest window and the widest tables for good.  Keep the size-based windows and wait for a
     // representative proof instead.
-    if ((uint64_t)S->ea.n_nonzero * 64 < S->ea.n_scalars) return;
+    if ((uint64_t)S->ea.n_nonzero() * 64 < S->ea.n_scalars) return;
     CG_HIP(hipSetDevice(c->device));
     hipStream_t st = S->st[0];
     retune_query<Fq>(c, c->bl, &ProofSlot::el, S, st);

@@ -109,8 +109,8 @@ static void fill_msm_timings(const MsmEngine<F>& e, bool g2, cg_timings* tm) {
     (g2 ? tm->accum_g2_ms : tm->accum_g1_ms) = e.ms_accum();
     tm->sort_ms = e.ms_sort();
     (g2 ? tm->msm_g2_pairs : tm->msm_g1_pairs) = e.n_scalars;
-    (g2 ? tm->entries_g2 : tm->entries_g1) = e.n_entries;
-    (g2 ? tm->accum_g2_launches : tm->accum_g1_launches) = e.n_entries != 0;
+    (g2 ? tm->entries_g2 : tm->entries_g1) = e.n_entries();
+    (g2 ? tm->accum_g2_launches : tm->accum_g1_launches) = e.n_entries() != 0;
 }
 
 extern "C" int cg_msm_run(cg_msm_ctx* ctx, const void* scalars, int scalars_on_device, uint64_t n_scalars, uint8_t* out,
