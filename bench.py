@@ -4,16 +4,20 @@
 Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N > 1: launched under
 torch.distributed.run, one rank per GPU, RCCL).  Prints ONE JSON line on rank 0.
 
-A "step" is one full Groth16 proof (witness resident in HBM -> 256-byte proof): the witness map
-(3 SpMV + 7 NTT + pointwise), four G1 MSMs, one G2 MSM and the host finish, with fresh (r, s).
+A "step" is one full Groth16 proof (assignment resident in HBM -> 256-byte proof): the witness map
+(2 sparse products + 4 transforms with the folded key; 3 + 7 in the reference arrangement), four G1
+MSMs, one G2 MSM and the host finish, with fresh (r, s).
 Workload: the rs256-sd circuit's SHAPE (BASELINE.json metric; SURVEY.md §8d "S21": D = 2^21,
-m = 1 480 000, M = 1 500 000, ℓ = 26), synthetic + satisfiable, with a proving key made by the GPU
-setup from a seeded trapdoor.  Real Crescent circuits cannot be built in this environment.
+m = 1 480 000, M = 1 500 000, ℓ = 26), synthetic + satisfiable, ≈11 terms per row (nnz ≈ 16.6 M: the
+circomlib gate mix of crescent-credentials_amd/synth/synth.cpp), with a proving key made by the GPU
+setup from a seeded trapdoor.  Real Crescent circuits cannot be built in this environment.  The timed
+proofs rotate over several device-resident assignments of the same value distribution, so that no step
+repeats the previous step's inputs.
 
-Multi-GPU:  --mode throughput (default): proofs are independent objects, each rank
-proves its own stream of proofs with a full replica of the key -> weak scaling, no data-path
-collective.  --mode sharded: ONE proof at a time, every query range-sharded over the ranks, five
-partial points per rank exchanged with an RCCL all_gather, then assembled (latency mode).
+Multi-GPU: `value` is always the replica throughput — proofs are independent objects,
+each rank proves its own stream with a full copy of the key, no data-path collective (config 5).  With
+N > 1 the same run then measures ONE proof range-sharded over the ranks (cg_prove_partial, a 384-byte
+all_gather, cg_assemble: config 4) and reports it as the `sharded` sub-record.
 """
 import argparse
 import json
@@ -33,19 +37,21 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (guides/MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E (guides/MI355X_MICROARCH.md)
+VALU_PEAK = 256 * 4 * 2.4e9 / 4   # wave-instructions/s: 256 CUs x 4 SIMDs, one VALU instruction per 4 cycles at 2.4 GHz
 G1_PAIR_BYTES = 96             # 64 B affine base + 32 B scalar   
 G2_PAIR_BYTES = 160
+SWEEP_FRACTIONS = (0.0, 0.5, 0.75, 0.9)
 
 
-def pmc_traffic(launches_per_proof):
-    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
-    separate runs of this same command, FETCH_SIZE doubled per guides/MI355X_MICROARCH.md §HBM).  The counters cannot be
-    read from inside this process, so the figure comes from the committed measurement in profiles/ (None if absent)."""
-    path = os.path.join(ROOT, "profiles", "pmc_accum_affine_g1.json")
+def committed_counters(workload_key):
+    """rocprofv3 PMC results cannot be read from inside this process; the figures come from the committed passes in
+    profiles/pmc_counters.json (separate --pmc runs of THIS command, FETCH_SIZE / WRITE_SIZE corrected as
+    guides/MI355X_MICROARCH.md prescribes, SQ_INSTS_VALU per steady-state proof), keyed by workload.  A run whose
+    workload has no committed pass reports null."""
     try:
-        with open(path) as f:
-            return json.load(f)["hbm_bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", "pmc_counters.json")) as f:
+            return json.load(f).get(workload_key)
     except Exception:
         return None
 
@@ -56,21 +62,38 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--shape", default="rs256-sd")
-    ap.add_argument("--mode", default="throughput", choices=["throughput", "sharded"])
-    ap.add_argument("--witness", default="circom", choices=["circom", "uniform"],
-                    help="wire distribution of the headline run: circom = 45%% zero / 45%% one / 10%% uniform")
+    ap.add_argument("--bits", type=float, default=0.9,
+                    help="share of the aux wires that are bit gates' outputs in the headline workload (see DESIGN.md §5)")
     ap.add_argument("--profile", default="gates", choices=["gates", "r1"],
                     help="synthetic matrix mix: gates = circomlib gate mix, ~11 terms per row (SURVEY 8d); r1 = round 1's "
                          "booleanity + short product rows, ~3.4 terms per row (kept for A/B against round-1 numbers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-uniform", action="store_true", help="skip the secondary uniform-witness measurement")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the secondary witness_sweep measurements")
+    ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the sharded-proof sub-record")
+    ap.add_argument("--sharded-steps", type=int, default=20)
+    ap.add_argument("--shard-sim", type=int, default=0,
+                    help="N = 1 only: time one proof split over this many sharded contexts on the one GPU, shard by shard")
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--h-coefficient-basis", action="store_true",
                     help="keep the h query as loaded and run the seventh transform per proof (A/B against the default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for plumbing tests)")
     ap.add_argument("--inflight", type=int, default=4,
-                    help="proofs in flight per GPU (throughput mode): host threads x context proof_slots")
+                    help="proofs in flight per GPU: host threads x context proof_slots")
+    ap.add_argument("--assignments", type=int, default=4, help="device-resident assignments the timed proofs rotate over")
     return ap.parse_args()
+
+
+def permuted_assignments(w_np, l, count, seed):
+    """the satisfying witness plus `count - 1` assignments with its aux wires permuted: the same multiset of values
+    (hence the same digit statistics) in other positions.  The prover's cost does not depend on satisfaction."""
+    out = [w_np]
+    W = w_np.reshape(-1, 32)
+    rng = np.random.default_rng(seed)
+    for _ in range(count - 1):
+        p = W.copy()
+        p[l:] = W[l:][rng.permutation(W.shape[0] - l)]
+        out.append(p.reshape(-1).copy())
+    return out
 
 
 def main():
@@ -81,7 +104,8 @@ def main():
     if a.gpus > 1 and world == 1:
         print("bench.py --gpus %d must be launched under torch.distributed.run" % a.gpus, file=sys.stderr)
         sys.exit(2)
-    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path to measure)"
+    on_gpu = torch.cuda.is_available()
+    assert on_gpu, "bench.py needs a GPU (there is no CPU path to measure)"
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -100,115 +124,163 @@ def main():
     R = cc.api.FR_MODULUS
     l, m, M = wl.SHAPES[a.shape]
     log = (lambda *x: print("[bench]", *x, file=sys.stderr, flush=True)) if rank == 0 else (lambda *x: None)
-
-    # ---- workload (identical on every rank: same seeds) ------------------------------------------
-    t0 = time.time()
-    bits = 0.9 if a.witness == "circom" else 0.0
-    cm, w_np = wl.synthetic_circuit(0xC5E5CE47 + 3, l, m, M, bits, 3, profile=a.profile)
-    rng = random.Random(0xC5E5CE47)
-    trap = [rng.randrange(1, R) for _ in range(4)]
-    pk = cc.generate_parameters_with_qap(cm, *trap)
-    log("workload %s: l=%d m=%d M=%d nnz=%d, key + circuit made in %.1fs" % (a.shape, l, m, M, cm.a.nnz + cm.b.nnz + cm.c.nnz, time.time() - t0))
-    t0 = time.time()
-    sharded = a.mode == "sharded" and world > 1
-    if sharded:
-        prover = cc.Prover(pk, cm, device=local_rank, window_bits=a.window, shard_rank=rank, shard_count=world,
-                           h_coefficient_basis=a.h_coefficient_basis)
-        sp = ShardedProver(prover, dev)
-    else:
-        prover = cc.Prover(pk, cm, device=local_rank, window_bits=a.window, proof_slots=a.inflight,
-                           h_coefficient_basis=a.h_coefficient_basis)
-    log("circuit loaded on GPU in %.1fs (D = %d)" % (time.time() - t0, prover.domain_size))
-    w_dev = torch.from_numpy(w_np).to(dev)            # the witness is resident in HBM before timing starts
-    torch.cuda.synchronize()
-
-    rs_rng = random.Random(1234 + (0 if sharded else rank))
-
-    def one_proof(timings=False):
-        r, s = rs_rng.randrange(R), rs_rng.randrange(R)
-        if sharded:
-            return sp.prove_dev(w_dev.data_ptr(), r, s), None, (r, s)
-        if timings:
-            p, tm = prover.prove_dev(w_dev.data_ptr(), r, s, timings=True)
-            return p, tm, (r, s)
-        return prover.prove_dev(w_dev.data_ptr(), r, s), None, (r, s)
-
     from concurrent.futures import ThreadPoolExecutor
-    inflight = 1 if sharded else max(1, a.inflight)
+    inflight = max(1, a.inflight)
     pool = ThreadPoolExecutor(max_workers=inflight) if inflight > 1 else None
+    rs_rng = random.Random(1234 + rank)
+    trap_rng = random.Random(0xC5E5CE47)
+    trap = [trap_rng.randrange(1, R) for _ in range(4)]
 
-    def run_proofs(count):
-        """`count` proofs with fresh (r, s), up to `inflight` at a time (ctypes releases the GIL inside cg_prove_dev)"""
-        if pool is None:
+    def make_workload(bits, seed_off):
+        cm_, w_ = wl.synthetic_circuit(0xC5E5CE47 + seed_off, l, m, M, bits, 3, profile=a.profile)
+        pk_ = cc.generate_parameters_with_qap(cm_, *trap)
+        return cm_, w_, pk_
+
+    def measure(prover, ws_dev, steps, warmup, sync_ranks):
+        """`steps` proofs with fresh (r, s), `inflight` at a time, rotating over the resident assignments"""
+        state = {"k": 0}
+
+        def run(count):
+            jobs = []
             for _ in range(count):
-                one_proof()
-            return
-        rs = [(rs_rng.randrange(R), rs_rng.randrange(R)) for _ in range(count)]
-        list(pool.map(lambda x: prover.prove_dev(w_dev.data_ptr(), x[0], x[1]), rs))
-
-    def timed_run(steps, warmup):
-        run_proofs(warmup)
-        barrier_sync(world)
-        t_start = time.perf_counter()
-        run_proofs(steps)
+                jobs.append((ws_dev[state["k"] % len(ws_dev)].data_ptr(), rs_rng.randrange(R), rs_rng.randrange(R)))
+                state["k"] += 1
+            if pool is None:
+                for j in jobs:
+                    prover.prove_dev(*j)
+            else:
+                list(pool.map(lambda j: prover.prove_dev(*j), jobs))
+        # the one-time window re-tune that follows a context's first proof belongs to circuit loading, and every proof
+        # slot captures its reduction graphs on first use: both happen before the W warm-up steps
+        prover.prove_dev(ws_dev[0].data_ptr(), 1, 2)
+        run(inflight)
         torch.cuda.synchronize()
-        barrier_sync(world)
+        run(warmup)
+        if sync_ranks:
+            barrier_sync(world)
+        t_start = time.perf_counter()
+        run(steps)
+        torch.cuda.synchronize()
+        if sync_ranks:
+            barrier_sync(world)
         dt = time.perf_counter() - t_start
-        return max_over_ranks(dt, world, dev)
+        return max_over_ranks(dt, world, dev) if sync_ranks else dt
 
-    # one-time per-circuit tuning (the window re-tune that follows the first proof of a context) belongs to circuit
-    # loading, not to the steady state that W warm-up + K timed steps measure: run it before both, whatever W is
-    one_proof()
-    if not sharded:
-        run_proofs(inflight)          # ... and one proof on every slot (each captures its reduction graphs on first use)
+    def phase_record(prover, w_dev, reps=3):
+        accs = [prover.prove_dev(w_dev.data_ptr(), rs_rng.randrange(R), rs_rng.randrange(R), timings=True)[1] for _ in range(reps)]
+        keys = ("witness_map_ms", "msm_h_ms", "msm_l_ms", "msm_a_ms", "msm_b1_ms", "msm_b2_ms", "sort_ms", "accum_g1_ms",
+                "accum_g2_ms", "finish_ms", "total_ms")
+        return accs[-1], {k: round(float(np.mean([t[k] for t in accs])), 3) for k in keys}
+
+    # ---- headline workload (identical on every rank: same seeds) ----------------------------------
+    t0 = time.time()
+    cm, w_np, pk = make_workload(a.bits, 3)
+    nnz = cm.a.nnz + cm.b.nnz + cm.c.nnz
+    wires = wl.wire_stats(w_np)
+    log("workload %s: l=%d m=%d M=%d nnz=%d wires=%s, key + circuit made in %.1fs" % (a.shape, l, m, M, nnz, wires, time.time() - t0))
+    t0 = time.time()
+    prover = cc.Prover(pk, cm, device=local_rank, window_bits=a.window, proof_slots=inflight, h_coefficient_basis=a.h_coefficient_basis)
+    log("circuit loaded on GPU in %.1fs (D = %d)" % (time.time() - t0, prover.domain_size))
+    ws_dev = [torch.from_numpy(x).to(dev) for x in permuted_assignments(w_np, l, max(1, a.assignments), 7)]
     torch.cuda.synchronize()
-    dt = timed_run(a.steps, a.warmup)
-    proofs_total = a.steps * (1 if sharded else world)
-    value = proofs_total / dt
 
-    # ---- per-kernel accounting from HIP events (one extra instrumented proof, not in the timed region) ---
-    roof = None
-    extra = {}
-    if not sharded:
-        accs = []
-        for _ in range(3):
-            _, tm, _ = one_proof(timings=True)
-            accs.append(tm)
-        tm = accs[-1]
-        g1_pairs, g2_pairs = tm["msm_g1_pairs"], tm["msm_g2_pairs"]
-        launches = max(1, tm["accum_g1_launches"])
-        acc_ms = float(np.mean([t["accum_g1_ms"] for t in accs]))
-        alg_bytes = G1_PAIR_BYTES * g1_pairs                       # all four G1 MSMs' operands, touched once
-        achieved = alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
-        roof = {"kernel": "k_accum_affine<Fq> (G1 bucket accumulation)", "bound": "hbm", "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(launches),
-                "launches_per_proof": launches, "avg_launch_ms": round(acc_ms / launches, 4),
-                "algorithmic_bytes_per_launch": int(alg_bytes / launches),
-                "mixed_adds_per_s": round(tm["entries_g1"] / (acc_ms * 1e-3), 1) if acc_ms > 0 else None,
-                "note": "integer-ALU-bound kernel (no MFMA); HBM fraction is reported as the contract asks, see DESIGN.md §5"}
-        extra = {"phase_ms": {k: round(float(np.mean([t[k] for t in accs])), 3) for k in
-                              ("witness_map_ms", "msm_h_ms", "msm_l_ms", "msm_a_ms", "msm_b1_ms", "msm_b2_ms", "sort_ms",
-                               "accum_g1_ms", "accum_g2_ms", "finish_ms", "total_ms")},
-                 "msm_g1_pairs_per_proof": g1_pairs, "msm_g2_pairs_per_proof": g2_pairs,
-                 "entries_g1": tm["entries_g1"], "entries_g2": tm["entries_g2"]}
-        extra["g1_msm_scalar_adds_per_s"] = round(g1_pairs * value, 1)       # pairs consumed per second of whole-job time
+    dt = measure(prover, ws_dev, a.steps, a.warmup, True)
+    value = a.steps * world / dt
+
+    tm, phases = phase_record(prover, ws_dev[0])
+    g1_pairs, g2_pairs = tm["msm_g1_pairs"], tm["msm_g2_pairs"]
+    launches = max(1, tm["accum_g1_launches"])
+    acc_ms = phases["accum_g1_ms"]
+    alg_bytes = G1_PAIR_BYTES * g1_pairs                           # all four G1 MSMs' operands, each touched once
+    achieved = alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
+    workload_key = "%s/%s/bits=%.2f%s" % (a.shape, a.profile, a.bits, "/coeff-basis" if a.h_coefficient_basis else "")
+    pmc = committed_counters(workload_key) or {}
+    roof = {"kernel": "k_accum_affine<Fq> (G1 bucket accumulation)", "bound": "hbm", "achieved": round(achieved, 2),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": pmc.get("accum_affine_g1_hbm_bytes_per_launch"),
+            "launches_per_proof": launches, "avg_launch_ms": round(acc_ms / launches, 4),
+            "algorithmic_bytes_per_launch": int(alg_bytes / launches),
+            "mixed_adds_per_s": round(tm["entries_g1"] / (acc_ms * 1e-3), 1) if acc_ms > 0 else None,
+            "binds": False,
+            "note": "carry-propagating integer work (no MFMA): this kernel is bound by VALU issue, not by HBM - the HBM "
+                    "fraction is reported because the contract asks for it; the binding roofline is `roofline_valu`"}
+    instr = pmc.get("valu_wave_instr_per_proof")
+    roof_valu = {"bound": "valu", "scope": "whole proof (every kernel of the prove path)", "unit": "G wave-instr/s",
+                 "peak": round(VALU_PEAK / 1e9, 1),
+                 "achieved": round(instr * value / world / 1e9, 1) if instr else None,
+                 "frac": round(instr * value / world / VALU_PEAK, 4) if instr else None,
+                 "wave_instr_per_proof": instr,
+                 "note": "SQ_INSTS_VALU per steady-state proof (committed rocprofv3 --pmc pass of this command for this "
+                         "workload; null when none is committed) x proofs/s per GPU, against 256 CU x 4 SIMD x 2.4 GHz / 4"}
 
     out = {
         "metric": "Groth16 proofs/sec (rs256-sd-shaped circuit, BN254), G1 MSM scalar-adds/sec reported alongside",
         "value": round(value, 3), "unit": "proofs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u32 limbs (BN254 Fq/Fr, 254-bit modular integers)",
+        "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (BN254 Fq/Fr, 254-bit modular integers)",
         "data": "synthetic",
-        "config": {"workload": "%s shape: D=2^%d, m=%d, M=%d, l=%d, nnz=%d (%s mix); witness=%s; pk from seeded trapdoor (GPU setup)" %
-                   (a.shape, prover.domain_size.bit_length() - 1, m, M, l, cm.a.nnz + cm.b.nnz + cm.c.nnz, a.profile, a.witness),
-                   "wires": wl.wire_stats(w_np),
-                   "mode": a.mode, "h_query_basis": "coefficient" if a.h_coefficient_basis else "coset evaluation (transformed at load)",
+        "config": {"workload": "%s shape: D=2^%d, m=%d, M=%d, l=%d, nnz=%d (%s mix); bit_fraction=%.2f; pk from seeded trapdoor (GPU setup)" %
+                   (a.shape, prover.domain_size.bit_length() - 1, m, M, l, nnz, a.profile, a.bits),
+                   "wires": wires, "mode": "throughput (one full key replica per GPU)",
+                   "h_query_basis": "coefficient" if a.h_coefficient_basis else "coset evaluation (transformed at load)",
                    "proofs_per_rank": a.steps, "proofs_in_flight_per_gpu": inflight,
-                   "inputs": "witness resident in HBM; (r,s) fresh per proof"},
+                   "inputs": "%d assignments resident in HBM, taken in rotation; (r,s) fresh per proof" % len(ws_dev)},
+        "roofline": roof, "roofline_valu": roof_valu, "phase_ms": phases,
+        "msm_g1_pairs_per_proof": g1_pairs, "msm_g2_pairs_per_proof": g2_pairs,
+        "entries_g1": tm["entries_g1"], "entries_g2": tm["entries_g2"],
+        "g1_msm_scalar_adds_per_s": round(g1_pairs * value, 1),      # pairs consumed per second of whole-job time
     }
-    if roof:
-        out["roofline"] = roof
-    out.update(extra)
+
+    # ---- N > 1: one proof sharded over the ranks (config 4), measured in the same run --------------------------------
+    if world > 1 and not a.no_sharded:
+        sp_ctx = cc.Prover(pk, cm, device=local_rank, window_bits=a.window, shard_rank=rank, shard_count=world,
+                           h_coefficient_basis=a.h_coefficient_basis)
+        sp = ShardedProver(sp_ctx, dev)
+        srng = random.Random(99)                     # the same (r, s) on every rank
+        for _ in range(3):
+            sp.prove_dev(ws_dev[0].data_ptr(), srng.randrange(R), srng.randrange(R))
+        barrier_sync(world)
+        gathers0 = sp.all_gathers
+        t_start = time.perf_counter()
+        for k in range(a.sharded_steps):
+            sp.prove_dev(ws_dev[k % len(ws_dev)].data_ptr(), srng.randrange(R), srng.randrange(R))
+        torch.cuda.synchronize()
+        barrier_sync(world)
+        ds = max_over_ranks(time.perf_counter() - t_start, world, dev)
+        gathers = sp.all_gathers - gathers0
+        # every rank assembled the same bytes as the unsharded context does
+        r_, s_ = srng.randrange(R), srng.randrange(R)
+        same = sp.prove_dev(ws_dev[0].data_ptr(), r_, s_).data == prover.prove_dev(ws_dev[0].data_ptr(), r_, s_).data
+        out["sharded"] = {"mode": "one proof, every query range-sharded over the ranks; 5 partial points per rank",
+                          "ranks": world, "backend": dist.get_backend(), "proofs": a.sharded_steps,
+                          "ms_per_proof": round(ds / a.sharded_steps * 1e3, 3), "proofs_per_s": round(a.sharded_steps / ds, 3),
+                          "all_gathers": gathers, "all_gather_bytes_per_rank": 384,
+                          "scaling": "strong", "bytes_identical_to_unsharded": bool(same)}
+        assert same, "sharded and unsharded proofs differ"
+        sp_ctx.close()
+
+    # ---- N = 1 diagnostic: one proof over k sharded contexts on this one GPU, shard by shard (DESIGN §6) ----------------
+    if world == 1 and a.shard_sim > 1:
+        k = a.shard_sim
+        shards = [cc.Prover(pk, cm, device=local_rank, shard_rank=i, shard_count=k) for i in range(k)]
+        r_, s_ = rs_rng.randrange(R), rs_rng.randrange(R)
+        for sh in shards:
+            sh.prove_partial(ws_dev[0].data_ptr(), r_, on_device=True)
+            sh.prove_partial(ws_dev[0].data_ptr(), r_, on_device=True)
+        per = []
+        for sh in shards:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                sh.prove_partial(ws_dev[0].data_ptr(), r_, on_device=True)
+            per.append((time.perf_counter() - t1) / 5 * 1e3)
+        parts = b"".join(sh.prove_partial(ws_dev[0].data_ptr(), r_, on_device=True) for sh in shards)
+        same = shards[0].assemble(parts, k, r_, s_).data == prover.prove_dev(ws_dev[0].data_ptr(), r_, s_).data
+        _, ph1 = phase_record(prover, ws_dev[0])
+        out["shard_sim"] = {"shards": k, "ms_per_shard_alone_on_the_gpu": [round(x, 3) for x in per], "max_ms": round(max(per), 3),
+                            "unsharded_single_proof_ms": ph1["total_ms"], "bytes_identical": bool(same)}
+        for sh in shards:
+            sh.close()
 
     # ---- CPU baseline: the arkworks-equivalent C restatement on this box's host cores, SAME inputs -------
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -216,60 +288,64 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import cpu_ref
             cores = cpu_ref.num_procs()
-            threads = min(cores, 32)
             r, s = rs_rng.randrange(R), rs_rng.randrange(R)
-            gpu_proof = prover.prove_dev(w_dev.data_ptr(), r, s).data
+            gpu_proof = prover.prove_dev(ws_dev[0].data_ptr(), r, s).data
             t_c = time.perf_counter()
-            cpu_proof, ctm = cpu_ref.prove(pk, (cm.a, cm.b, cm.c), l, m, M, w_np, r, s, nthreads=threads, timings=True)
+            cpu_proof, ctm = cpu_ref.prove(pk, (cm.a, cm.b, cm.c), l, m, M, w_np, r, s, nthreads=cores, timings=True)
             wall = time.perf_counter() - t_c
             same = cpu_proof == gpu_proof
-            out["cpu_baseline"] = {"value": round(1.0 / ctm["total_s"], 5), "unit": "proofs/s", "cores": threads, "kind": "port",
-                                   "sample": "1 full proof of the SAME workload (same key, witness, r, s) by oracle/cpu_ref.c, the "
-                                             "arkworks-equivalent C restatement (Pippenger c=ln(n)+2 with one task per window, so at most "
-                                             "16 of the %d threads work during an MSM; radix-2 NTT; row-parallel SpMV): %.2fs prove "
-                                             "(+ %.2fs key decode, not counted)" % (threads, ctm["total_s"], ctm["load_s"]),
-                                   "host_cores_available": cores, "proof_bytes_identical_to_gpu": bool(same),
-                                   "phase_s": {k: round(v, 3) for k, v in ctm.items()}, "wall_s": round(wall, 2)}
             g1_s = sum(ctm.get(k, 0.0) for k in ("msm_h_s", "msm_l_s", "msm_a_s", "msm_b1_s"))
-            if g1_s > 0 and extra.get("msm_g1_pairs_per_proof"):
-                # the metric's second half on the CPU side: (base, scalar) pairs of the four G1 MSMs per second of MSM time
-                out["cpu_baseline"]["g1_msm_scalar_adds_per_s"] = round(extra["msm_g1_pairs_per_proof"] / g1_s, 1)
+            # one thread: the a-query G1 MSM of the same proof (M - 1 pairs) - a bounded sample; a whole proof on one
+            # thread would take about a minute
+            t1 = time.perf_counter()
+            cpu_ref.msm_g1(pk.a_query[64:], w_np[32:], nthreads=1)
+            one_thread_s = time.perf_counter() - t1
+            out["cpu_baseline"] = {
+                "value": round(1.0 / ctm["total_s"], 5), "unit": "proofs/s", "cores": cores, "kind": "port",
+                "sample": "1 full proof of the SAME workload (same key, assignment, r, s) by oracle/cpu_ref.c, the "
+                          "arkworks-equivalent C restatement, on all %d host threads (Pippenger c = ln(n) + 2 with one task "
+                          "per window as arkworks has it, so <= 16 threads work during an MSM; blocked radix-2 NTT and "
+                          "row-parallel sparse products on all threads): %.2fs prove (+ %.2fs key decode, not counted)"
+                          % (cores, ctm["total_s"], ctm["load_s"]),
+                "proof_bytes_identical_to_gpu": bool(same),
+                "phase_s": {k: round(v, 3) for k, v in ctm.items()}, "wall_s": round(wall, 2),
+                "g1_msm_scalar_adds_per_s": round(g1_pairs / g1_s, 1) if g1_s > 0 else None,
+                "one_thread": {"sample": "the a-query G1 MSM of the same proof (%d pairs) on 1 thread" % (M - 1),
+                               "seconds": round(one_thread_s, 3), "g1_msm_scalar_adds_per_s": round((M - 1) / one_thread_s, 1)},
+                "gpu_over_cpu": round(value / (1.0 / ctm["total_s"]), 1)}
             assert same, "CPU restatement and HIP path disagree on the proof bytes"
         except Exception as e:  # the baseline is a reported number, never the thing measured
             out["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
             if isinstance(e, AssertionError):
                 raise
 
-    # ---- secondary: uniform-witness run (defines the headline G1 scalar-adds/s per SURVEY §8d) --------
-    if rank == 0 and world == 1 and not a.no_uniform and a.witness == "circom":
-        cm_u, wu_np = wl.synthetic_circuit(0xC5E5CE47 + 4, l, m, M, 0.0, 3, profile=a.profile)
-        pk_u = cc.generate_parameters_with_qap(cm_u, *trap)
+    # ---- secondary: the same measurement over the share of bit wires (the headline's one assumption) --------------------
+    if rank == 0 and world == 1 and not a.no_sweep:
         prover.close()
-        pu = cc.Prover(pk_u, cm_u, device=local_rank, window_bits=a.window, proof_slots=inflight,
-                       h_coefficient_basis=a.h_coefficient_basis)
-        wu = torch.from_numpy(wu_np).to(dev)
-        torch.cuda.synchronize()
-        ksteps = max(inflight, a.steps // 2)
-
-        def run_u(count):
-            rs = [(rs_rng.randrange(R), rs_rng.randrange(R)) for _ in range(count)]
-            if pool is None:
-                for r_, s_ in rs:
-                    pu.prove_dev(wu.data_ptr(), r_, s_)
-            else:
-                list(pool.map(lambda x: pu.prove_dev(wu.data_ptr(), x[0], x[1]), rs))
-
-        run_u(inflight)
-        t_start = time.perf_counter()
-        run_u(ksteps)
-        torch.cuda.synchronize()
-        du = time.perf_counter() - t_start
-        _, tmu = pu.prove_dev(wu.data_ptr(), 5, 7, timings=True)
-        out["uniform_witness"] = {"proofs_per_s": round(ksteps / du, 3), "ms_per_proof": round(du / ksteps * 1e3, 3),
-                                  "g1_msm_scalar_adds_per_s": round(tmu["msm_g1_pairs"] * ksteps / du, 1),
-                                  "accum_g1_ms": round(tmu["accum_g1_ms"], 3), "entries_g1": tmu["entries_g1"],
-                                  "g1_mixed_adds_per_s": round(tmu["entries_g1"] / (tmu["accum_g1_ms"] * 1e-3), 1)}
-        pu.close()
+        sweep = []
+        ksteps = max(inflight, a.steps // 4)
+        for bf in SWEEP_FRACTIONS:
+            if abs(bf - a.bits) < 1e-9:
+                sweep.append({"bit_fraction": bf, "wires": wires, "nnz": nnz, "proofs_per_s": round(value, 3),
+                              "g1_msm_scalar_adds_per_s": round(g1_pairs * value, 1), "entries_g1": tm["entries_g1"],
+                              "entries_g2": tm["entries_g2"], "note": "the headline run"})
+                continue
+            cm_s, w_s, pk_s = make_workload(bf, 4 + int(bf * 100))
+            ps = cc.Prover(pk_s, cm_s, device=local_rank, window_bits=a.window, proof_slots=inflight,
+                           h_coefficient_basis=a.h_coefficient_basis)
+            wsd = [torch.from_numpy(x).to(dev) for x in permuted_assignments(w_s, l, 2, 11)]
+            d_s = measure(ps, wsd, ksteps, inflight, False)
+            tms, phs = phase_record(ps, wsd[0], reps=1)
+            sweep.append({"bit_fraction": bf, "wires": wl.wire_stats(w_s), "nnz": cm_s.a.nnz + cm_s.b.nnz + cm_s.c.nnz,
+                          "proofs_per_s": round(ksteps / d_s, 3), "g1_msm_scalar_adds_per_s": round(tms["msm_g1_pairs"] * ksteps / d_s, 1),
+                          "entries_g1": tms["entries_g1"], "entries_g2": tms["entries_g2"],
+                          "accum_g1_ms": phs["accum_g1_ms"], "witness_map_ms": phs["witness_map_ms"]})
+            ps.close()
+            del wsd
+        out["witness_sweep"] = sweep
+        u = [x for x in sweep if x["bit_fraction"] == 0.0]
+        if u:
+            out["g1_msm_scalar_adds_per_s_uniform_scalars"] = u[0]["g1_msm_scalar_adds_per_s"]   # SURVEY §8d's definition
 
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -262,8 +262,10 @@ __device__ __forceinline__ void for_each_digit(const uint32_t s[8], int c, int W
 // entry count lives in `plan` on the device: no kernel launch waits for the host.
 // ---------------------------------------------------------------------------------------------
 static constexpr int PART_MAX_BITS = 12;          // bins of one level: at most 4096 LDS counters
-static constexpr uint32_t PART_TILE = 1024;       // scalars per block, level 1
+static constexpr uint32_t PART_TILE = 8192;       // scalars per block, level 1 (few, large blocks: one global atomic per bin per block)
+static constexpr uint32_t PART_THREADS = 1024;    // threads of a level-1 block
 static constexpr uint32_t PART_CHUNK = 8192;      // entries per block, level 2
+static constexpr uint32_t PART_PAD = 16;          // level-1 global counters sit 64 B apart: atomics of different bins do not share a line
 enum { PLAN_N = 0, PLAN_L = 1, PLAN_T = 2, PLAN_NONZERO = 3, PLAN_CHUNKS = 4, PLAN_WORDS = 8 };
 
 struct PartShape {
@@ -289,7 +291,7 @@ __device__ __forceinline__ void for_each_entry(const PartShape& sh, const Fr* __
     });
 }
 
-__global__ void __launch_bounds__(256) k_part_count(PartShape sh, const Fr* __restrict__ scalars, const uint8_t* __restrict__ valid,
+__global__ void __launch_bounds__(PART_THREADS) k_part_count(PartShape sh, const Fr* __restrict__ scalars, const uint8_t* __restrict__ valid,
                                                     uint32_t* __restrict__ blk_hist, uint32_t* __restrict__ hist1,
                                                     uint32_t* __restrict__ plan) {
     extern __shared__ uint32_t lds[];
@@ -315,7 +317,7 @@ __global__ void __launch_bounds__(256) k_part_count(PartShape sh, const Fr* __re
     for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) {
         const uint32_t v = lds[k];
         row[k] = v;
-        if (v) atomicAdd(&hist1[k], v);
+        if (v) atomicAdd(&hist1[(size_t)k * PART_PAD], v);
     }
 }
 
@@ -352,7 +354,7 @@ __global__ void __launch_bounds__(1024) k_part_plan(int bits1, int two_level, co
                                                     uint32_t* __restrict__ plan, uint32_t target_threads, uint32_t min_L) {
     extern __shared__ uint32_t lds[];
     const uint32_t B1 = 1u << bits1;
-    for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) lds[k] = hist1[k];
+    for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) lds[k] = hist1[(size_t)k * PART_PAD];
     __syncthreads();
     const uint32_t N = block_exclusive_scan(lds, B1);
     for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) start1[k] = lds[k];
@@ -366,14 +368,14 @@ __global__ void __launch_bounds__(1024) k_part_plan(int bits1, int two_level, co
     }
     if (!two_level) return;
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) lds[k] = (hist1[k] + PART_CHUNK - 1) / PART_CHUNK;
+    for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) lds[k] = (hist1[(size_t)k * PART_PAD] + PART_CHUNK - 1) / PART_CHUNK;
     __syncthreads();
     const uint32_t chunks = block_exclusive_scan(lds, B1);
     for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) chunk0[k] = lds[k];
     if (threadIdx.x == 0) { chunk0[B1] = chunks; plan[PLAN_CHUNKS] = chunks; }
 }
 
-__global__ void __launch_bounds__(256) k_part_place(PartShape sh, const Fr* __restrict__ scalars, const uint8_t* __restrict__ valid,
+__global__ void __launch_bounds__(PART_THREADS) k_part_place(PartShape sh, const Fr* __restrict__ scalars, const uint8_t* __restrict__ valid,
                                                     const uint32_t* __restrict__ blk_hist, const uint32_t* __restrict__ start1,
                                                     uint32_t* __restrict__ cur1, uint64_t* __restrict__ out) {
     extern __shared__ uint32_t lds[];                 // [B1] next slot of the bin for this block
@@ -381,7 +383,7 @@ __global__ void __launch_bounds__(256) k_part_place(PartShape sh, const Fr* __re
     const uint32_t* row = blk_hist + (size_t)blockIdx.x * B1;
     for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) {
         const uint32_t cnt = row[k];
-        lds[k] = cnt ? start1[k] + atomicAdd(&cur1[k], cnt) : 0u;
+        lds[k] = cnt ? start1[k] + atomicAdd(&cur1[(size_t)k * PART_PAD], cnt) : 0u;
     }
     __syncthreads();
     const uint32_t base = blockIdx.x * PART_TILE;
@@ -420,7 +422,14 @@ __global__ void __launch_bounds__(256) k_part_count2(int bits1, int bits2, const
     const uint32_t B2 = 1u << bits2;
     for (uint32_t k = threadIdx.x; k < B2; k += blockDim.x) lds[k] = 0;
     __syncthreads();
-    for (uint32_t k = beg + threadIdx.x; k < end; k += blockDim.x) atomicAdd(&lds[(uint32_t)(in[k] >> 32) & (B2 - 1u)], 1u);
+    for (uint32_t k0 = beg + threadIdx.x; k0 < end; k0 += 4 * blockDim.x) {      // four loads in flight per lane
+        uint64_t e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const uint32_t k = k0 + u * blockDim.x; e[u] = k < end ? in[k] : 0ull; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + u * blockDim.x < end) atomicAdd(&lds[(uint32_t)(e[u] >> 32) & (B2 - 1u)], 1u);
+    }
     __syncthreads();
     uint32_t* g = hist2 + ((size_t)bin << bits2);
     for (uint32_t k = threadIdx.x; k < B2; k += blockDim.x) {
@@ -441,7 +450,14 @@ __global__ void __launch_bounds__(256) k_part_place2(int bits1, int bits2, const
     uint32_t* st = lds + B2;
     for (uint32_t k = threadIdx.x; k < B2; k += blockDim.x) { cnt[k] = 0; st[k] = hist2[((size_t)bin << bits2) + k]; }
     __syncthreads();
-    for (uint32_t k = beg + threadIdx.x; k < end; k += blockDim.x) atomicAdd(&cnt[(uint32_t)(in[k] >> 32) & (B2 - 1u)], 1u);
+    for (uint32_t k0 = beg + threadIdx.x; k0 < end; k0 += 4 * blockDim.x) {
+        uint64_t e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const uint32_t k = k0 + u * blockDim.x; e[u] = k < end ? in[k] : 0ull; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + u * blockDim.x < end) atomicAdd(&cnt[(uint32_t)(e[u] >> 32) & (B2 - 1u)], 1u);
+    }
     (void)block_exclusive_scan(st, B2);               // starts of the fine bins inside this level-1 bin
     const uint32_t bin_start = start1[bin];
     uint32_t* g = cur2 + ((size_t)bin << bits2);
@@ -450,10 +466,13 @@ __global__ void __launch_bounds__(256) k_part_place2(int bits1, int bits2, const
         cnt[k] = c ? bin_start + st[k] + atomicAdd(&g[k], c) : 0u;
     }
     __syncthreads();
-    for (uint32_t k = beg + threadIdx.x; k < end; k += blockDim.x) {
-        const uint64_t e = in[k];
-        const uint32_t pos = atomicAdd(&cnt[(uint32_t)(e >> 32) & (B2 - 1u)], 1u);
-        out[pos] = e;
+    for (uint32_t k0 = beg + threadIdx.x; k0 < end; k0 += 4 * blockDim.x) {
+        uint64_t e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const uint32_t k = k0 + u * blockDim.x; e[u] = k < end ? in[k] : 0ull; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + u * blockDim.x < end) out[atomicAdd(&cnt[(uint32_t)(e[u] >> 32) & (B2 - 1u)], 1u)] = e[u];
     }
 }
 
@@ -908,7 +927,7 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
     blk_hist.alloc(tiles * B1);
     // zeroed per MSM in one fill: plan | level-1 histogram | level-1 cursors | level-2 histogram | level-2 cursors
     const size_t keyspace = bits2 ? ((size_t)1 << (bits1 + bits2)) : 0;
-    counters.alloc(PLAN_WORDS + 2 * (size_t)B1 + 2 * keyspace);
+    counters.alloc(PLAN_WORDS + 2 * (size_t)B1 * PART_PAD + 2 * keyspace);
     starts.alloc(2 * ((size_t)B1 + 1) + 2);                    // start1[B1 + 1] | chunk0[B1 + 1]
     max_chunks = bits2 ? (uint32_t)(cap_entries / PART_CHUNK) + B1 + 1 : 0;
     bucket_sums.alloc(((size_t)nbuckets_total + 1) * ACC);
@@ -961,8 +980,8 @@ void MsmEngine<F>::digits(const Fr* scalars_dev, uint64_t n, hipStream_t st) {
     const uint32_t B1 = 1u << bits1;
     uint32_t* plan = counters.p;
     uint32_t* hist1 = plan + PLAN_WORDS;
-    uint32_t* cur1 = hist1 + B1;
-    uint32_t* hist2 = cur1 + B1;
+    uint32_t* cur1 = hist1 + (size_t)B1 * PART_PAD;
+    uint32_t* hist2 = cur1 + (size_t)B1 * PART_PAD;
     uint32_t* cur2 = hist2 + (bits2 ? ((size_t)1 << (bits1 + bits2)) : 0);
     uint32_t* start1 = starts.p;
     uint32_t* chunk0 = starts.p + B1 + 1;
@@ -973,11 +992,11 @@ void MsmEngine<F>::digits(const Fr* scalars_dev, uint64_t n, hipStream_t st) {
     const uint32_t tiles = ceil_div(n, PART_TILE);
     CG_HIP(hipEventRecord(ev_t[1], st));
     fill_zero(counters.p, (counters.bytes() + 15) & ~(size_t)15, st);
-    k_part_count<<<tiles, 256, (size_t)B1 * 4, st>>>(sh, scalars_dev, bases->valid.p, blk_hist.p, hist1, plan);
+    k_part_count<<<tiles, PART_THREADS, (size_t)B1 * 4, st>>>(sh, scalars_dev, bases->valid.p, blk_hist.p, hist1, plan);
     CG_KERNEL_CHECK();
     k_part_plan<<<1, 1024, (size_t)B1 * 4, st>>>(bits1, bits2 ? 1 : 0, hist1, start1, chunk0, plan, ACC_TARGET_THREADS, ACC_MIN_L);
     CG_KERNEL_CHECK();
-    k_part_place<<<tiles, 256, (size_t)B1 * 4, st>>>(sh, scalars_dev, bases->valid.p, blk_hist.p, start1, cur1, ent_a.p);
+    k_part_place<<<tiles, PART_THREADS, (size_t)B1 * 4, st>>>(sh, scalars_dev, bases->valid.p, blk_hist.p, start1, cur1, ent_a.p);
     CG_KERNEL_CHECK();
     if (bits2) {
         const uint32_t B2 = 1u << bits2;

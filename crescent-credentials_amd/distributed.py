@@ -66,10 +66,12 @@ class ShardedProver:
         self.device = device
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.all_gathers = 0          # collectives issued so far (one per proof when world > 1)
 
     def _finish(self, part: bytes, r: int, s: int):
         if self.world > 1:
             parts = gather_partials(part, self.device, self.group)
+            self.all_gathers += 1
         else:
             parts = part
         return self.prover.assemble(parts, self.world, r, s)

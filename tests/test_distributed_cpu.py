@@ -94,6 +94,7 @@ def _worker(rank, world, port, q):
         for case in g["proofs"]:
             proof = sp.prove(w, int(case["r"], 16), int(case["s"], 16))
             ok = ok and proof.hex() == case["proof"]
+        ok = ok and sp.all_gathers == len(g["proofs"])          # exactly one collective per proof
         barrier_sync(world)
         mx = max_over_ranks(float(rank + 1), world, torch.device("cpu"))
         q.put((rank, ok, mx))
