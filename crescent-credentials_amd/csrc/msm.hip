@@ -262,7 +262,7 @@ __device__ __forceinline__ void for_each_digit(const uint32_t s[8], int c, int W
 // entry count lives in `plan` on the device: no kernel launch waits for the host.
 // ---------------------------------------------------------------------------------------------
 static constexpr int PART_MAX_BITS = 12;          // bins of one level: at most 4096 LDS counters
-static constexpr uint32_t PART_TILE = 8192;       // scalars per block, level 1 (few, large blocks: one global atomic per bin per block)
+static constexpr uint32_t PART_TILE = 4096;       // scalars per block, level 1 (few, large blocks: one global atomic per bin per block)
 static constexpr uint32_t PART_THREADS = 1024;    // threads of a level-1 block
 static constexpr uint32_t PART_CHUNK = 8192;      // entries per block, level 2
 static constexpr uint32_t PART_PAD = 16;          // level-1 global counters sit 64 B apart: atomics of different bins do not share a line
@@ -277,10 +277,7 @@ struct PartShape {
 };
 
 template <class Fn>
-__device__ __forceinline__ void for_each_entry(const PartShape& sh, const Fr* __restrict__ scalars, const uint8_t* __restrict__ valid,
-                                               uint32_t i, Fn f) {
-    if (!valid[i]) return;
-    const Fr s = scalars[i];
+__device__ __forceinline__ void for_each_entry(const PartShape& sh, const Fr& s, uint32_t i, Fn f) {
     const uint32_t nb = 1u << (sh.c - 1);
     for_each_digit(s.l, sh.c, sh.W, [&](int j, int32_t d) {
         if (d == 0) return;
@@ -300,19 +297,33 @@ __global__ void __launch_bounds__(PART_THREADS) k_part_count(PartShape sh, const
     __syncthreads();
     const uint32_t base = blockIdx.x * PART_TILE;
     uint32_t nonzero = 0;
-    for (uint32_t k = threadIdx.x; k < PART_TILE; k += blockDim.x) {
-        const uint32_t i = base + k;
-        if (i >= sh.n) break;
+    constexpr int PER = PART_TILE / PART_THREADS;       // scalars per thread: all loaded before any is walked
+    Fr sc[PER];
+    bool ok[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const uint32_t i = base + u * PART_THREADS + threadIdx.x;
+        ok[u] = i < sh.n && valid[i] != 0;
+        sc[u] = ok[u] ? scalars[i] : Fr::zero();
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        if (!ok[u]) continue;
         bool any = false;
-        for_each_entry(sh, scalars, valid, i, [&](uint32_t key, uint32_t) {
+        for_each_entry(sh, sc[u], base + u * PART_THREADS + threadIdx.x, [&](uint32_t key, uint32_t) {
             atomicAdd(&lds[key >> sh.bits2], 1u);
             any = true;
         });
         nonzero += any;
     }
+    // one atomic per block: same-address atomics serialise at ~10 ns each
+    __shared__ uint32_t nz_block;
+    if (threadIdx.x == 0) nz_block = 0;
     for (int off = 32; off > 0; off >>= 1) nonzero += __shfl_down((int)nonzero, off, 64);
-    if ((threadIdx.x & 63) == 0 && nonzero) atomicAdd(&plan[PLAN_NONZERO], nonzero);
     __syncthreads();
+    if ((threadIdx.x & 63) == 0 && nonzero) atomicAdd(&nz_block, nonzero);
+    __syncthreads();
+    if (threadIdx.x == 0 && nz_block) atomicAdd(&plan[PLAN_NONZERO], nz_block);
     uint32_t* row = blk_hist + (size_t)blockIdx.x * B1;
     for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) {
         const uint32_t v = lds[k];
@@ -385,12 +396,21 @@ __global__ void __launch_bounds__(PART_THREADS) k_part_place(PartShape sh, const
         const uint32_t cnt = row[k];
         lds[k] = cnt ? start1[k] + atomicAdd(&cur1[(size_t)k * PART_PAD], cnt) : 0u;
     }
-    __syncthreads();
     const uint32_t base = blockIdx.x * PART_TILE;
-    for (uint32_t k = threadIdx.x; k < PART_TILE; k += blockDim.x) {
-        const uint32_t i = base + k;
-        if (i >= sh.n) break;
-        for_each_entry(sh, scalars, valid, i, [&](uint32_t key, uint32_t val) {
+    constexpr int PER = PART_TILE / PART_THREADS;
+    Fr sc[PER];
+    bool ok[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const uint32_t i = base + u * PART_THREADS + threadIdx.x;
+        ok[u] = i < sh.n && valid[i] != 0;
+        sc[u] = ok[u] ? scalars[i] : Fr::zero();
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        if (!ok[u]) continue;
+        for_each_entry(sh, sc[u], base + u * PART_THREADS + threadIdx.x, [&](uint32_t key, uint32_t val) {
             const uint32_t pos = atomicAdd(&lds[key >> sh.bits2], 1u);
             out[pos] = ((uint64_t)key << 32) | val;
         });
@@ -438,41 +458,51 @@ __global__ void __launch_bounds__(256) k_part_count2(int bits1, int bits2, const
     }
 }
 
+// A chunk is staged in LDS grouped by fine bin and written out run by run: the lanes of a wave store consecutive
+// slots of the same bin, instead of 64 slots of 64 bins.
 __global__ void __launch_bounds__(256) k_part_place2(int bits1, int bits2, const uint64_t* __restrict__ in,
                                                      const uint32_t* __restrict__ chunk0, const uint32_t* __restrict__ start1,
                                                      const uint32_t* __restrict__ hist2, uint32_t* __restrict__ cur2,
                                                      uint64_t* __restrict__ out) {
-    extern __shared__ uint32_t lds[];                 // [B2] counts of this chunk, then next slots; [B2] bin starts
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t bin, beg, end;
     if (!chunk_range(blockIdx.x, bits1, chunk0, start1, bin, beg, end)) return;
     const uint32_t B2 = 1u << bits2;
-    uint32_t* cnt = lds;
-    uint32_t* st = lds + B2;
+    uint32_t* cnt = lds;                 // [B2] entries of this chunk per fine bin, then the fill cursor
+    uint32_t* off = lds + B2;            // [B2] first staging slot of the bin
+    uint32_t* st = lds + 2 * B2;         // [B2] the bin's count over the whole level-1 bin, then its start inside it
+    uint32_t* gb = lds + 3 * B2;         // [B2] global slot of the first entry this chunk contributes to the bin
+    uint64_t* stage = reinterpret_cast<uint64_t*>(lds + 4 * B2);      // [PART_CHUNK]
     for (uint32_t k = threadIdx.x; k < B2; k += blockDim.x) { cnt[k] = 0; st[k] = hist2[((size_t)bin << bits2) + k]; }
     __syncthreads();
-    for (uint32_t k0 = beg + threadIdx.x; k0 < end; k0 += 4 * blockDim.x) {
-        uint64_t e[4];
+    constexpr int PER = PART_CHUNK / 256;
+    uint64_t e[PER];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const uint32_t k = k0 + u * blockDim.x; e[u] = k < end ? in[k] : 0ull; }
+    for (int u = 0; u < PER; ++u) { const uint32_t k = beg + u * 256 + threadIdx.x; e[u] = k < end ? in[k] : ~0ull; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (k0 + u * blockDim.x < end) atomicAdd(&cnt[(uint32_t)(e[u] >> 32) & (B2 - 1u)], 1u);
-    }
+    for (int u = 0; u < PER; ++u)
+        if (e[u] != ~0ull) atomicAdd(&cnt[(uint32_t)(e[u] >> 32) & (B2 - 1u)], 1u);
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < B2; k += blockDim.x) off[k] = cnt[k];
     (void)block_exclusive_scan(st, B2);               // starts of the fine bins inside this level-1 bin
+    (void)block_exclusive_scan(off, B2);              // starts of the fine bins inside the staging area
     const uint32_t bin_start = start1[bin];
     uint32_t* g = cur2 + ((size_t)bin << bits2);
     for (uint32_t k = threadIdx.x; k < B2; k += blockDim.x) {
         const uint32_t c = cnt[k];
-        cnt[k] = c ? bin_start + st[k] + atomicAdd(&g[k], c) : 0u;
+        gb[k] = c ? bin_start + st[k] + atomicAdd(&g[k], c) : 0u;
+        cnt[k] = off[k];
     }
     __syncthreads();
-    for (uint32_t k0 = beg + threadIdx.x; k0 < end; k0 += 4 * blockDim.x) {
-        uint64_t e[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const uint32_t k = k0 + u * blockDim.x; e[u] = k < end ? in[k] : 0ull; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (k0 + u * blockDim.x < end) out[atomicAdd(&cnt[(uint32_t)(e[u] >> 32) & (B2 - 1u)], 1u)] = e[u];
+    for (int u = 0; u < PER; ++u)
+        if (e[u] != ~0ull) stage[atomicAdd(&cnt[(uint32_t)(e[u] >> 32) & (B2 - 1u)], 1u)] = e[u];
+    __syncthreads();
+    const uint32_t total = end - beg;
+    for (uint32_t k = threadIdx.x; k < total; k += blockDim.x) {
+        const uint64_t v = stage[k];
+        const uint32_t f = (uint32_t)(v >> 32) & (B2 - 1u);
+        out[gb[f] + (k - off[f])] = v;
     }
 }
 
@@ -1002,7 +1032,7 @@ void MsmEngine<F>::digits(const Fr* scalars_dev, uint64_t n, hipStream_t st) {
         const uint32_t B2 = 1u << bits2;
         k_part_count2<<<max_chunks, 256, (size_t)B2 * 4, st>>>(bits1, bits2, ent_a.p, chunk0, start1, hist2);
         CG_KERNEL_CHECK();
-        k_part_place2<<<max_chunks, 256, (size_t)B2 * 8, st>>>(bits1, bits2, ent_a.p, chunk0, start1, hist2, cur2, ent_b.p);
+        k_part_place2<<<max_chunks, 256, (size_t)B2 * 16 + (size_t)PART_CHUNK * 8, st>>>(bits1, bits2, ent_a.p, chunk0, start1, hist2, cur2, ent_b.p);
         CG_KERNEL_CHECK();
     }
     CG_HIP(hipEventRecord(ev_t[2], st));

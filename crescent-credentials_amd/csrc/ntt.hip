@@ -174,14 +174,6 @@ void DevCsr::upload(const cg_csr& m, uint64_t rows_, uint64_t num_variables) {
     for (auto& c : dict_h) c = to_mont(c);
     row_ptr.alloc(rows + 1);
     {
-        // counting sort of the rows by their length (stable; lengths above 255 share the last class)
-        std::vector<uint32_t> start(257, 0), order(rows ? rows : 1);
-        auto cls = [&](uint64_t i) { uint32_t len = rp[i + 1] - rp[i]; return len > 255u ? 255u : len; };
-        for (uint64_t i = 0; i < rows; ++i) start[cls(i) + 1]++;
-        for (int k = 0; k < 256; ++k) start[k + 1] += start[k];
-        for (uint64_t i = 0; i < rows; ++i) order[start[cls(i)]++] = (uint32_t)i;
-        row_order.alloc(rows ? rows : 1);
-        if (rows) CG_HIP(hipMemcpy(row_order.p, order.data(), rows * 4, hipMemcpyHostToDevice));
         std::vector<uint32_t> lr;
         for (uint64_t i = 0; i < rows; ++i) if (rp[i + 1] - rp[i] > 4096u) lr.push_back((uint32_t)i);
         n_long_rows = lr.size();
@@ -197,6 +189,73 @@ void DevCsr::upload(const cg_csr& m, uint64_t rows_, uint64_t num_variables) {
         CG_HIP(hipMemcpy(coef_idx.p, idx.data(), nnz * 4, hipMemcpyHostToDevice));
     }
     CG_HIP(hipMemcpy(dict.p, dict_h.data(), dict_h.size() * sizeof(Fr), hipMemcpyHostToDevice));
+    build_sell(rp, m.col, idx);
+}
+
+// the sliced layout of ntt.hpp's SellLevel, built on the host once per matrix
+void DevCsr::build_sell(const std::vector<uint32_t>& rp, const uint32_t* col_h, const std::vector<uint32_t>& idx) {
+    struct Item { uint32_t row, first, len; };              // a row of the current level: `len` terms from `first`
+    std::vector<uint32_t> cur_col(col_h, col_h + nnz), cur_idx(idx);
+    std::vector<Item> items;
+    items.reserve(rows);
+    for (uint64_t i = 0; i < rows; ++i)
+        if (rp[i + 1] > rp[i]) items.push_back({(uint32_t)i, rp[i], rp[i + 1] - rp[i]});
+    n_sell = 0;
+    sell_scratch = 0;
+    while (!items.empty()) {
+        if (n_sell >= 6) throw HipError(CG_ERR_INVALID_ARGUMENT, "matrix row too long for the sliced layout");
+        SellLevel& L = sell[n_sell++];
+        struct Piece { uint32_t first, len, dst; };
+        std::vector<Piece> pieces;
+        std::vector<Item> next_items;
+        std::vector<uint32_t> next_col;
+        uint32_t partials = 0;
+        for (const Item& it : items) {
+            const uint32_t np = (it.len + SELL_PIECE - 1) / SELL_PIECE;
+            if (np == 1) {
+                pieces.push_back({it.first, it.len, it.row | SELL_FINAL});
+                continue;
+            }
+            next_items.push_back({it.row, (uint32_t)next_col.size(), np});
+            for (uint32_t k = 0; k < np; ++k) {
+                const uint32_t b = it.first + k * SELL_PIECE;
+                const uint32_t l = it.len - k * SELL_PIECE < SELL_PIECE ? it.len - k * SELL_PIECE : SELL_PIECE;
+                pieces.push_back({b, l, partials});
+                next_col.push_back(partials++);
+            }
+        }
+        // longest pieces first, so that a slice holds pieces of (nearly) one length
+        std::vector<uint32_t> start(SELL_PIECE + 2, 0);
+        for (const Piece& p : pieces) start[SELL_PIECE - p.len + 1]++;
+        for (uint32_t k = 0; k <= SELL_PIECE; ++k) start[k + 1] += start[k];
+        std::vector<Piece> sorted(pieces.size());
+        for (const Piece& p : pieces) sorted[start[SELL_PIECE - p.len]++] = p;
+        const uint32_t np = (uint32_t)sorted.size(), ns = (np + 63) / 64;
+        std::vector<uint32_t> sp(ns + 1, 0), dst(np);
+        for (uint32_t s = 0; s < ns; ++s) sp[s + 1] = sp[s] + 64 * sorted[(size_t)s * 64].len;   // the slice's first piece is its longest
+        std::vector<uint32_t> lc(sp[ns] ? sp[ns] : 1, 0), li(sp[ns] ? sp[ns] : 1, SELL_PAD);
+        for (uint32_t p = 0; p < np; ++p) {
+            const Piece& pc = sorted[p];
+            dst[p] = pc.dst;
+            const uint32_t base = sp[p / 64] + (p & 63);
+            for (uint32_t t = 0; t < pc.len; ++t) {
+                lc[base + t * 64] = cur_col[pc.first + t];
+                li[base + t * 64] = cur_idx[pc.first + t];
+            }
+        }
+        L.n_pieces = np;
+        L.n_partials = partials;
+        if (partials > sell_scratch) sell_scratch = partials;
+        L.slice_ptr.alloc(ns + 1); L.col.alloc(lc.size()); L.cidx.alloc(li.size()); L.dst.alloc(np ? np : 1);
+        CG_HIP(hipMemcpy(L.slice_ptr.p, sp.data(), (ns + 1) * 4, hipMemcpyHostToDevice));
+        CG_HIP(hipMemcpy(L.col.p, lc.data(), lc.size() * 4, hipMemcpyHostToDevice));
+        CG_HIP(hipMemcpy(L.cidx.p, li.data(), li.size() * 4, hipMemcpyHostToDevice));
+        if (np) CG_HIP(hipMemcpy(L.dst.p, dst.data(), np * 4, hipMemcpyHostToDevice));
+        // the next level sums the partials: unit coefficients over this level's scratch vector
+        items.swap(next_items);
+        cur_col.swap(next_col);
+        cur_idx.assign(cur_col.size(), 0u);
+    }
 }
 
 static constexpr uint32_t SPMV_LONG_ROW = 4096;

@@ -25,19 +25,38 @@ Fr fr_root_of_unity(int logn);  // primitive 2^logn-th root, = 5^((r-1)/2^28) ^ 
 // out[p] = scale * base^(bitrev ? rev(p) : p), p < n (Montgomery form)
 void fr_pow_table(Fr* out, const Fr& base, const Fr& scale, uint64_t n, bool bitrev, int logn, hipStream_t st);
 
+// One level of the sliced layout the prove path's sparse product runs on (wmap29.hip k_sell29).  A row is cut into
+// PIECES of at most SELL_PIECE terms; a lane takes one piece, so no lane walks more than SELL_PIECE terms however long
+// the row is (circom's substituted adder rows carry hundreds of terms).  Pieces are sorted by length and stored in
+// slices of 64 with the terms of a slice interleaved (term t of the 64 pieces side by side): the index loads of a
+// wave are contiguous.  A row of one piece is finished by that piece; the pieces of a longer row leave partial sums
+// in a scratch vector and the row becomes a row of the next level, whose "terms" are those partial sums.
+static constexpr uint32_t SELL_PIECE = 8;
+static constexpr uint32_t SELL_FINAL = 0x80000000u;    // dst flag: the piece is its row's only piece; low bits = row
+static constexpr uint32_t SELL_PAD = 0xffffffffu;      // coefficient index of a padding slot
+struct SellLevel {
+    uint32_t n_pieces = 0, n_partials = 0;   // partials written to the scratch vector by this level
+    DevBuf<uint32_t> slice_ptr;  // n_slices + 1 slot offsets (multiples of 64)
+    DevBuf<uint32_t> col;        // level 0: wire index; level k > 0: partial index in the previous level's scratch
+    DevBuf<uint32_t> cidx;       // dictionary index (0 = the literal one), SELL_PAD for padding
+    DevBuf<uint32_t> dst;        // per piece: row | SELL_FINAL, or its slot in this level's scratch vector
+};
+
 // CSR sparse matrix (device) with a coefficient dictionary: coef_idx 0 is the literal one
 // (the reference's `coeff.is_one()` shortcut, r1cs_to_qap.rs:31-35).
 struct DevCsr {
     uint64_t rows = 0, nnz = 0;
     DevBuf<uint32_t> row_ptr;   // rows + 1  (nnz < 2^32 enforced at load)
-    DevBuf<uint32_t> row_order; // rows sorted by length: lane t of the sparse product takes row row_order[t], so the
-                                // lanes of a wave run the same number of terms (its output is scattered anyway)
     DevBuf<uint32_t> long_rows; // rows with more than 4096 terms (saturated spmv: one workgroup each)
     uint64_t n_long_rows = 0;
     DevBuf<uint32_t> col;
     DevBuf<uint32_t> coef_idx;
     DevBuf<Fr> dict;            // Montgomery
+    SellLevel sell[6];          // the sliced layout, level by level (rows of up to 8^6 terms)
+    int n_sell = 0;
+    uint32_t sell_scratch = 0;  // largest partial count of any level
     void upload(const cg_csr& m, uint64_t rows, uint64_t num_variables);
+    void build_sell(const std::vector<uint32_t>& rp, const uint32_t* col_h, const std::vector<uint32_t>& idx);
 };
 // host-side transpose of a CSR view (rows x cols): CSR of the transpose, terms of one column kept in row order
 struct HostCsc {

@@ -349,7 +349,7 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
             for (auto& e : sl->ev_t) CG_HIP(hipEventCreate(&e));
             sl->eh.init(&c->bh); sl->el.init(&c->bl); sl->ea.init(&c->ba); sl->eb1.init(&c->bb1); sl->eb2.init(&c->bb2);
             sl->w_canon.alloc(M); sl->h_canon.alloc(D);
-            sl->wm.alloc(M, D);
+            sl->wm.alloc(M, D, std::max(c->A.sell_scratch, std::max(c->B.sell_scratch, c->C.sell_scratch)));
             c->slots.push_back(std::move(sl));
         }
         *out = c.release();

@@ -278,7 +278,7 @@ extern "C" int cg_qap_load(cg_qap_ctx** out, const cg_csr abc[3], uint64_t num_i
         CG_HIP(hipStreamSynchronize(c->st));
         c->dom.tw_fwd.release(); c->dom.tw_inv.release(); c->dom.coset_br.release(); c->dom.icoset_br.release();
         c->A.dict.release(); c->B.dict.release(); c->C.dict.release();
-        c->wm.alloc(c->M, c->D);
+        c->wm.alloc(c->M, c->D, std::max(c->A.sell_scratch, std::max(c->B.sell_scratch, c->C.sell_scratch)));
         c->w_canon.alloc(c->M);
         c->h_canon.alloc(c->D);
         *out = c.release();

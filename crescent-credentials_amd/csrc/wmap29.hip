@@ -137,26 +137,30 @@ __global__ void __launch_bounds__(256) k_w_to29(const Fr* __restrict__ w, uint32
 
 // out[rev(i)] = <M_i, w>, i < rows  (evaluate_constraint, r1cs_to_qap.rs:16-45); the output vector is the
 // bit-reversed input the first transform wants.
-__global__ void __launch_bounds__(256) k_spmv29(const uint32_t* __restrict__ row_order, const uint32_t* __restrict__ row_ptr,
-                                                const uint32_t* __restrict__ col,
-                                                const uint32_t* __restrict__ cidx, const uint32_t* __restrict__ dict,
-                                                const uint32_t* __restrict__ w29, uint32_t* __restrict__ out, uint64_t rows, int logn) {
-    const uint64_t lane = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= rows) return;
-    const uint64_t i = row_order[lane];     // rows of equal length share a wave
-    uint32_t b = row_ptr[i], e = row_ptr[i + 1];
+// One level of the sliced sparse product (ntt.hpp SellLevel): lane = piece, at most SELL_PIECE terms, the slice's
+// index arrays read 64 lanes wide.  src: the witness (level 0) or the previous level's partial sums, packed R' form.
+__global__ void __launch_bounds__(256) k_sell29(const uint32_t* __restrict__ slice_ptr, const uint32_t* __restrict__ col,
+                                                const uint32_t* __restrict__ cidx, const uint32_t* __restrict__ dst,
+                                                const uint32_t* __restrict__ dict, const uint32_t* __restrict__ src,
+                                                uint32_t* __restrict__ out, uint32_t* __restrict__ scratch, uint32_t n_pieces, int logn) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pieces) return;
+    const uint32_t s = p >> 6, lane = p & 63u;
+    const uint32_t base = slice_ptr[s], len = (slice_ptr[s + 1] - base) >> 6;
     Fr29 acc = Fr29::zero();
     uint32_t cnt = 0;
-    for (uint32_t t = b; t < e; ++t) {
-        Fr29 v = load_packed29(w29, col[t]);
-        uint32_t ci = cidx[t];
+    for (uint32_t t = 0; t < len; ++t) {
+        const uint32_t ci = cidx[base + t * 64 + lane];
+        if (ci == SELL_PAD) continue;
+        Fr29 v = load_packed29(src, col[base + t * 64 + lane]);
         if (ci != 0) v = mul(v, load_packed29(dict, ci));      // index 0 is the literal one (is_one() shortcut :31-35)
         acc = add(acc, v);
-        ++cnt;
-        if ((cnt & 3u) == 0) acc = normalize(acc);              // limbs stay below 5·2^29
-        if ((cnt & 63u) == 0) acc = mul(acc, Fr29::one());      // value back under 2N every 64 terms
+        if ((++cnt & 3u) == 0) acc = normalize(acc);            // limbs stay below 5·2^29
     }
-    store_packed29(out, brev((uint32_t)i, logn), canonical(normalize(acc)));
+    const uint32_t d = dst[p];
+    const Fr29 r = canonical(normalize(acc));
+    if (d & SELL_FINAL) store_packed29(out, brev(d & ~SELL_FINAL, logn), r);
+    else store_packed29(scratch, d, r);
 }
 // rows m .. m+l of `a` hold the instance assignment (r1cs_to_qap.rs:173-177)
 __global__ void k_place_inputs29(const uint32_t* __restrict__ w29, uint32_t* __restrict__ out, uint64_t m, uint64_t l, int logn) {
@@ -375,10 +379,17 @@ void wm29_run(const Wm29Domain& dom, const DevCsr& A, const DevCsr& B, const Dev
     const int nvec = coset_values ? 2 : 3;       // c's share of the quotient lives in the folded l query
     for (int k = 0; k < nvec; ++k) {
         fill_zero(v[k], D * 32, st);
-        if (mats[k]->rows) {
-            k_spmv29<<<ceil_div(mats[k]->rows, 256), 256, 0, st>>>(mats[k]->row_order.p, mats[k]->row_ptr.p, mats[k]->col.p, mats[k]->coef_idx.p, dicts[k]->dict.p,
-                                                                   buf.w29.p, v[k], mats[k]->rows, logn);
-            CG_KERNEL_CHECK();
+        const uint32_t* src = buf.w29.p;
+        for (int lv = 0; lv < mats[k]->n_sell; ++lv) {
+            const SellLevel& L = mats[k]->sell[lv];
+            uint32_t* scratch = (lv & 1) ? buf.sp_b.p : buf.sp_a.p;
+            if (L.n_partials > buf.sp_cap) throw HipError(CG_ERR_INVALID_ARGUMENT, "sparse-product scratch smaller than the matrix needs");
+            if (L.n_pieces) {
+                k_sell29<<<ceil_div(L.n_pieces, 256), 256, 0, st>>>(L.slice_ptr.p, L.col.p, L.cidx.p, L.dst.p, dicts[k]->dict.p, src, v[k],
+                                                                    scratch, L.n_pieces, logn);
+                CG_KERNEL_CHECK();
+            }
+            src = scratch;
         }
     }
     k_place_inputs29<<<ceil_div(l, 256), 256, 0, st>>>(buf.w29.p, buf.va.p, m, l, logn);

@@ -9,7 +9,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 export CG_SERIAL_STREAMS=1
 cd /tmp
-FLAGS="--steps 8 --warmup 2 --no-uniform --no-cpu-baseline --inflight 1 $*"
+FLAGS="--steps 8 --warmup 2 --no-sweep --no-cpu-baseline --inflight 1 $*"
 rocprofv3 --kernel-trace -d "$OUT/trace" -o t -- python3 "$ROOT/bench.py" $FLAGS > "$OUT/trace_line.json" 2> "$OUT/trace.log"
 rocprofv3 --pmc SQ_INSTS_VALU -d "$OUT/pmc" -o p -- python3 "$ROOT/bench.py" $FLAGS > "$OUT/pmc_line.json" 2> "$OUT/pmc.log"
 T=$(find "$OUT/trace" -name '*.db' | head -1); P=$(find "$OUT/pmc" -name '*.db' | head -1)
