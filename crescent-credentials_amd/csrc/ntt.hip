@@ -135,7 +135,7 @@ void csr_transpose(const cg_csr& m, uint64_t rows, uint64_t cols, HostCsc& out) 
 }
 
 
-void DevCsr::upload(const cg_csr& m, uint64_t rows_, uint64_t num_variables) {
+void DevCsr::upload(const cg_csr& m, uint64_t rows_, uint64_t num_variables, bool sliced) {
     rows = rows_;
     nnz = m.nnz;
     if (nnz >= (1ull << 32)) throw HipError(CG_ERR_INVALID_ARGUMENT, "matrix with >= 2^32 non-zeros");
@@ -189,7 +189,7 @@ void DevCsr::upload(const cg_csr& m, uint64_t rows_, uint64_t num_variables) {
         CG_HIP(hipMemcpy(coef_idx.p, idx.data(), nnz * 4, hipMemcpyHostToDevice));
     }
     CG_HIP(hipMemcpy(dict.p, dict_h.data(), dict_h.size() * sizeof(Fr), hipMemcpyHostToDevice));
-    build_sell(rp, m.col, idx);
+    if (sliced) build_sell(rp, m.col, idx);
 }
 
 // the sliced layout of ntt.hpp's SellLevel, built on the host once per matrix
@@ -203,7 +203,7 @@ void DevCsr::build_sell(const std::vector<uint32_t>& rp, const uint32_t* col_h, 
     n_sell = 0;
     sell_scratch = 0;
     while (!items.empty()) {
-        if (n_sell >= 6) throw HipError(CG_ERR_INVALID_ARGUMENT, "matrix row too long for the sliced layout");
+        if (n_sell >= 8) throw HipError(CG_ERR_INVALID_ARGUMENT, "matrix row too long for the sliced layout");
         SellLevel& L = sell[n_sell++];
         struct Piece { uint32_t first, len, dst; };
         std::vector<Piece> pieces;

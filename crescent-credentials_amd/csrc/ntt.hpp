@@ -52,10 +52,11 @@ struct DevCsr {
     DevBuf<uint32_t> col;
     DevBuf<uint32_t> coef_idx;
     DevBuf<Fr> dict;            // Montgomery
-    SellLevel sell[6];          // the sliced layout, level by level (rows of up to 8^6 terms)
+    SellLevel sell[8];          // the sliced layout, level by level (rows of up to 8^8 terms)
     int n_sell = 0;
     uint32_t sell_scratch = 0;  // largest partial count of any level
-    void upload(const cg_csr& m, uint64_t rows, uint64_t num_variables);
+    // sliced = false: skip the sliced layout (the generator's transposed matrices only run the saturated product)
+    void upload(const cg_csr& m, uint64_t rows, uint64_t num_variables, bool sliced = true);
     void build_sell(const std::vector<uint32_t>& rp, const uint32_t* col_h, const std::vector<uint32_t>& idx);
 };
 // host-side transpose of a CSR view (rows x cols): CSR of the transpose, terms of one column kept in row order
