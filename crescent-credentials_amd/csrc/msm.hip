@@ -922,7 +922,7 @@ __global__ void __launch_bounds__(256) k_bit_sums(const uint32_t* __restrict__ r
 // engine
 // ---------------------------------------------------------------------------------------------
 static constexpr uint32_t ACC_TARGET_THREADS = 256u * 4u * 4u * 64u;  // CUs x SIMDs x waves x lanes: one fully resident round
-static constexpr uint32_t ACC_MIN_L = 16;
+static constexpr uint32_t ACC_MIN_L = 64;   // shortest segment: fewer, longer lanes for the small MSMs (their pieces cost a wave-wide addition each to combine)
 static constexpr uint32_t ACC_LEVEL_L = 8;   // segment length of the partial-combining levels
 
 // shape of the bucket matrix of a window: nb = R·C buckets, C = 2^cbits columns (at most 1024)
