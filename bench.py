@@ -274,11 +274,13 @@ def main():
             for _ in range(5):
                 sh.prove_partial(ws_dev[0].data_ptr(), r_, on_device=True)
             per.append((time.perf_counter() - t1) / 5 * 1e3)
+        _, tm_shard = shards[k // 2].prove_partial(ws_dev[0].data_ptr(), r_, on_device=True, timings=True)
         parts = b"".join(sh.prove_partial(ws_dev[0].data_ptr(), r_, on_device=True) for sh in shards)
         same = shards[0].assemble(parts, k, r_, s_).data == prover.prove_dev(ws_dev[0].data_ptr(), r_, s_).data
         _, ph1 = phase_record(prover, ws_dev[0])
         out["shard_sim"] = {"shards": k, "ms_per_shard_alone_on_the_gpu": [round(x, 3) for x in per], "max_ms": round(max(per), 3),
-                            "unsharded_single_proof_ms": ph1["total_ms"], "bytes_identical": bool(same)}
+                            "unsharded_single_proof_ms": ph1["total_ms"], "bytes_identical": bool(same),
+                            "phase_ms_of_one_shard": {kk: round(float(vv), 3) for kk, vv in tm_shard.items() if kk.endswith("_ms")}}
         for sh in shards:
             sh.close()
 

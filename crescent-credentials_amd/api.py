@@ -367,7 +367,7 @@ class Prover:
         p = Proof(out.tobytes())
         return (p, tm.as_dict()) if timings else p
 
-    def prove_partial(self, assignment, r: int, on_device: bool = False) -> bytes:
+    def prove_partial(self, assignment, r: int, on_device: bool = False, timings: bool = False):
         out = np.zeros(384, dtype=np.uint8)
         rb = _u8(fr_to_bytes(r))
         if on_device:
@@ -375,8 +375,9 @@ class Prover:
         else:
             w = _u8(assignment, self.num_variables * 32)
             ptr = C.c_void_p(_ptr(w))
-        _check(lib().cg_prove_partial(self._h, ptr, 1 if on_device else 0, _ptr(rb), _ptr(out), None))
-        return out.tobytes()
+        tm = CgTimings()
+        _check(lib().cg_prove_partial(self._h, ptr, 1 if on_device else 0, _ptr(rb), _ptr(out), C.byref(tm) if timings else None))
+        return (out.tobytes(), tm.as_dict()) if timings else out.tobytes()
 
     def assemble(self, partials: bytes, n_shards: int, r: int, s: int) -> Proof:
         pb = _u8(partials, 384 * n_shards)

@@ -922,7 +922,9 @@ __global__ void __launch_bounds__(256) k_bit_sums(const uint32_t* __restrict__ r
 // engine
 // ---------------------------------------------------------------------------------------------
 static constexpr uint32_t ACC_TARGET_THREADS = 256u * 4u * 4u * 64u;  // CUs x SIMDs x waves x lanes: one fully resident round
-static constexpr uint32_t ACC_MIN_L = 64;   // shortest segment: fewer, longer lanes for the small MSMs (their pieces cost a wave-wide addition each to combine)
+// shortest segment.  Throughput: 64 - fewer, longer lanes for the small MSMs, whose pieces cost a wave-wide addition
+// each to combine (they run beside the h MSM, which fills the chip).  Latency (a shard of one proof): 16.
+static constexpr uint32_t ACC_MIN_L = 64, ACC_MIN_L_LATENCY = 16;
 static constexpr uint32_t ACC_LEVEL_L = 8;   // segment length of the partial-combining levels
 
 // shape of the bucket matrix of a window: nb = R·C buckets, C = 2^cbits columns (at most 1024)
@@ -961,7 +963,8 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
     starts.alloc(2 * ((size_t)B1 + 1) + 2);                    // start1[B1 + 1] | chunk0[B1 + 1]
     max_chunks = bits2 ? (uint32_t)(cap_entries / PART_CHUNK) + B1 + 1 : 0;
     bucket_sums.alloc(((size_t)nbuckets_total + 1) * ACC);
-    uint64_t t1 = (cap_entries + ACC_MIN_L - 1) / ACC_MIN_L;
+    const uint32_t min_L = latency_mode ? ACC_MIN_L_LATENCY : ACC_MIN_L;
+    uint64_t t1 = (cap_entries + min_L - 1) / min_L;
     if (t1 > ACC_TARGET_THREADS) t1 = ACC_TARGET_THREADS;
     max_segments = (uint32_t)t1;
     const uint64_t pa = 2 * t1, pb = 2 * ceil_div(t1, 64);   // two pieces per segment, then two per wave of 64 segments
@@ -1024,7 +1027,8 @@ void MsmEngine<F>::digits(const Fr* scalars_dev, uint64_t n, hipStream_t st) {
     fill_zero(counters.p, (counters.bytes() + 15) & ~(size_t)15, st);
     k_part_count<<<tiles, PART_THREADS, (size_t)B1 * 4, st>>>(sh, scalars_dev, bases->valid.p, blk_hist.p, hist1, plan);
     CG_KERNEL_CHECK();
-    k_part_plan<<<1, 1024, (size_t)B1 * 4, st>>>(bits1, bits2 ? 1 : 0, hist1, start1, chunk0, plan, ACC_TARGET_THREADS, ACC_MIN_L);
+    k_part_plan<<<1, 1024, (size_t)B1 * 4, st>>>(bits1, bits2 ? 1 : 0, hist1, start1, chunk0, plan, ACC_TARGET_THREADS,
+                                                      latency_mode ? ACC_MIN_L_LATENCY : ACC_MIN_L);
     CG_KERNEL_CHECK();
     k_part_place<<<tiles, PART_THREADS, (size_t)B1 * 4, st>>>(sh, scalars_dev, bases->valid.p, blk_hist.p, start1, cur1, ent_a.p);
     CG_KERNEL_CHECK();

@@ -65,6 +65,7 @@ struct MsmEngine {
     PinnedBuf<uint32_t> h_plan;       // the device plan of the last MSM: [0] entries, [3] scalars with a non-zero digit
     PinnedBuf<uint32_t> h_result;
     uint64_t n_scalars = 0;
+    bool latency_mode = false;        // set before init(): short segments (one proof at a time matters more than proofs per second)
     // valid once the stream has been synchronised
     uint32_t n_entries() const { return h_plan.p ? h_plan.p[0] : 0; }
     uint32_t n_nonzero() const { return h_plan.p ? h_plan.p[3] : 0; }

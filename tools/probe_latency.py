@@ -1,0 +1,23 @@
+"""wall-clock of one cg_prove_dev call at a time vs the library's own total_ms (host overhead outside the timed region)"""
+import os, sys, time, random
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, numpy as np
+import crescent_credentials_amd as cc
+from crescent_credentials_amd import workloads as wl
+cc.lib().cg_init(0, None)
+R = cc.api.FR_MODULUS
+l, m, M = wl.SHAPES["rs256-sd"]
+cm, w = wl.synthetic_circuit(3, l, m, M, 0.9, 3, profile="gates")
+rng = random.Random(1)
+pk = cc.generate_parameters_with_qap(cm, *[rng.randrange(1, R) for _ in range(4)])
+shard = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+p = cc.Prover(pk, cm, shard_rank=0, shard_count=shard) if shard > 1 else cc.Prover(pk, cm)
+wd = torch.from_numpy(w).cuda()
+f = (lambda t=False: p.prove_partial(wd.data_ptr(), 5, on_device=True, timings=t)) if shard > 1 else (lambda t=False: p.prove_dev(wd.data_ptr(), 5, 7, timings=t))
+for _ in range(4):
+    f()
+ws, ts = [], []
+for _ in range(10):
+    t0 = time.perf_counter(); _, tm = f(True); ws.append((time.perf_counter() - t0) * 1e3); ts.append(tm["total_ms"])
+print("shards", shard, "wall ms", round(float(np.median(ws)), 3), "library total_ms", round(float(np.median(ts)), 3), {k: round(v, 3) for k, v in tm.items() if k.endswith("_ms")})
