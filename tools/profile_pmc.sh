@@ -1,0 +1,18 @@
+#!/bin/bash
+# The three counter passes behind profiles/pmc_counters.json (one counter per pass, kernel trace off), every kernel of a
+# proof on one stream.   usage: tools/profile_pmc.sh <out-dir> <workload-key> [bench.py flags...]
+set -u
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+OUT="$ROOT/$1"; KEY="$2"; shift; shift
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+export CG_SERIAL_STREAMS=1
+cd /tmp
+FLAGS="--steps 6 --warmup 2 --no-sweep --no-cpu-baseline --inflight 1 $*"
+for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
+  rocprofv3 --pmc $C -d "$OUT/$C" -o p -- python3 "$ROOT/bench.py" $FLAGS > "$OUT/$C.line.json" 2> "$OUT/$C.log"
+done
+F=$(find "$OUT/FETCH_SIZE" -name '*.db' | head -1); W=$(find "$OUT/WRITE_SIZE" -name '*.db' | head -1); V=$(find "$OUT/SQ_INSTS_VALU" -name '*.db' | head -1)
+python3 "$ROOT/tools/make_pmc_json.py" "$KEY" "$F" "$W" "$V" "CG_SERIAL_STREAMS=1 rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU> -- python3 bench.py $FLAGS" "$OUT/pmc_counters.json"
+python3 "$ROOT/tools/rocpd_pmc.py" "$V" SQ_INSTS_VALU "$OUT/valu_per_proof.md" > /dev/null
+rm -rf "$OUT/FETCH_SIZE" "$OUT/WRITE_SIZE" "$OUT/SQ_INSTS_VALU"
