@@ -290,10 +290,14 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import cpu_ref
             cores = cpu_ref.num_procs()
+            # threads: the restatement's best configuration on the GPU boxes' 256-thread hosts (profiles/
+            # r02_cpu_thread_scaling.txt: witness map 0.63 s at 16 threads, 0.71 s at 32, 1.2 s at 64, 13 s at 256 - the
+            # transforms' per-stage barriers do not survive oversubscription; the MSMs have 16 window tasks at most)
+            threads = min(cores, 32)
             r, s = rs_rng.randrange(R), rs_rng.randrange(R)
             gpu_proof = prover.prove_dev(ws_dev[0].data_ptr(), r, s).data
             t_c = time.perf_counter()
-            cpu_proof, ctm = cpu_ref.prove(pk, (cm.a, cm.b, cm.c), l, m, M, w_np, r, s, nthreads=cores, timings=True)
+            cpu_proof, ctm = cpu_ref.prove(pk, (cm.a, cm.b, cm.c), l, m, M, w_np, r, s, nthreads=threads, timings=True)
             wall = time.perf_counter() - t_c
             same = cpu_proof == gpu_proof
             g1_s = sum(ctm.get(k, 0.0) for k in ("msm_h_s", "msm_l_s", "msm_a_s", "msm_b1_s"))
@@ -303,12 +307,13 @@ def main():
             cpu_ref.msm_g1(pk.a_query[64:], w_np[32:], nthreads=1)
             one_thread_s = time.perf_counter() - t1
             out["cpu_baseline"] = {
-                "value": round(1.0 / ctm["total_s"], 5), "unit": "proofs/s", "cores": cores, "kind": "port",
+                "value": round(1.0 / ctm["total_s"], 5), "unit": "proofs/s", "cores": threads, "host_threads_available": cores,
+                "kind": "port",
                 "sample": "1 full proof of the SAME workload (same key, assignment, r, s) by oracle/cpu_ref.c, the "
-                          "arkworks-equivalent C restatement, on all %d host threads (Pippenger c = ln(n) + 2 with one task "
-                          "per window as arkworks has it, so <= 16 threads work during an MSM; blocked radix-2 NTT and "
-                          "row-parallel sparse products on all threads): %.2fs prove (+ %.2fs key decode, not counted)"
-                          % (cores, ctm["total_s"], ctm["load_s"]),
+                          "arkworks-equivalent C restatement, on %d threads - its fastest configuration on this %d-thread host "
+                          "(Pippenger c = ln(n) + 2 with one task per window as arkworks has it, so <= 16 threads work during "
+                          "an MSM; blocked radix-2 NTT and row-parallel sparse products on all threads): %.2fs prove "
+                          "(+ %.2fs key decode, not counted)" % (threads, cores, ctm["total_s"], ctm["load_s"]),
                 "proof_bytes_identical_to_gpu": bool(same),
                 "phase_s": {k: round(v, 3) for k, v in ctm.items()}, "wall_s": round(wall, 2),
                 "g1_msm_scalar_adds_per_s": round(g1_pairs / g1_s, 1) if g1_s > 0 else None,
