@@ -963,7 +963,11 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
     starts.alloc(2 * ((size_t)B1 + 1) + 2);                    // start1[B1 + 1] | chunk0[B1 + 1]
     max_chunks = bits2 ? (uint32_t)(cap_entries / PART_CHUNK) + B1 + 1 : 0;
     bucket_sums.alloc(((size_t)nbuckets_total + 1) * ACC);
-    const uint32_t min_L = latency_mode ? ACC_MIN_L_LATENCY : ACC_MIN_L;
+    min_L = latency_mode ? ACC_MIN_L_LATENCY : ACC_MIN_L;
+    if (const char* e = getenv("CG_MIN_SEGMENT")) {          // tuning aid, like CG_SERIAL_STREAMS
+        const int v = atoi(e);
+        if (v >= 1 && v <= 4096) min_L = (uint32_t)v;
+    }
     uint64_t t1 = (cap_entries + min_L - 1) / min_L;
     if (t1 > ACC_TARGET_THREADS) t1 = ACC_TARGET_THREADS;
     max_segments = (uint32_t)t1;
@@ -1027,8 +1031,7 @@ void MsmEngine<F>::digits(const Fr* scalars_dev, uint64_t n, hipStream_t st) {
     fill_zero(counters.p, (counters.bytes() + 15) & ~(size_t)15, st);
     k_part_count<<<tiles, PART_THREADS, (size_t)B1 * 4, st>>>(sh, scalars_dev, bases->valid.p, blk_hist.p, hist1, plan);
     CG_KERNEL_CHECK();
-    k_part_plan<<<1, 1024, (size_t)B1 * 4, st>>>(bits1, bits2 ? 1 : 0, hist1, start1, chunk0, plan, ACC_TARGET_THREADS,
-                                                      latency_mode ? ACC_MIN_L_LATENCY : ACC_MIN_L);
+    k_part_plan<<<1, 1024, (size_t)B1 * 4, st>>>(bits1, bits2 ? 1 : 0, hist1, start1, chunk0, plan, ACC_TARGET_THREADS, min_L);
     CG_KERNEL_CHECK();
     k_part_place<<<tiles, PART_THREADS, (size_t)B1 * 4, st>>>(sh, scalars_dev, bases->valid.p, blk_hist.p, start1, cur1, ent_a.p);
     CG_KERNEL_CHECK();

@@ -55,6 +55,7 @@ struct MsmEngine {
     DevBuf<uint32_t> counters;        // plan | level-1 histogram, cursors | level-2 histogram, cursors (zeroed per MSM)
     DevBuf<uint32_t> starts;          // level-1 bin starts | first level-2 chunk of every bin
     uint32_t max_chunks = 0;          // launch bound of the level-2 kernels
+    uint32_t min_L = 16;              // shortest segment (entries per lane) the plan may choose
     uint32_t max_segments = 0;        // launch bound of the accumulation (the plan's segment count is at most this)
     DevBuf<uint32_t> bucket_sums;     // nbuckets_total * ACC
     DevBuf<uint32_t> part_keys_a, part_keys_b;

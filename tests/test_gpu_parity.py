@@ -258,6 +258,51 @@ def test_msm_context_matches_one_shot_and_closed_form(cc, oracle, group):
             ctx.close()
 
 
+@pytest.mark.parametrize("group,n", [(1, 200_003), (2, 40_001)])
+def test_msm_grouping_and_combine_edge_cases(cc, oracle, group, n):
+    """The entry grouping (two-level counting partition) and the wave-level piece combination on the populations that
+    stress them, each against the closed form (Σ s_i k_i)·G:  one bucket holding every entry (a single run across all
+    segments and all three combine levels), two alternating scalars, every scalar 1, a few non-zero scalars among
+    zeros, uniform scalars; n is odd and neither a multiple of the level-1 tile (4096 scalars) nor of the level-2 chunk;
+    window sizes that give a one-level key space (c <= 13), a two-level one, and the size-based default."""
+    nrng = np.random.default_rng(1000 + group)
+    kb = nrng.integers(0, 256, (n, 32), dtype=np.uint8)
+    kb[:, 31] &= 0x1F                                                      # < 2^253 < r
+    kb[7] = 0                                                               # an identity base
+    ks = [int.from_bytes(kb[i].tobytes(), "little") for i in range(n)]
+    bases = (cc.fixed_base_g1 if group == 1 else cc.fixed_base_g2)(kb.reshape(-1))
+    curve, gen, packed = (oracle.G1, oracle.G1_GEN, oracle.g1_packed) if group == 1 else (oracle.G2, oracle.G2_GEN, oracle.g2_packed)
+    rng = random.Random(7 * group)
+    big = rng.randrange(oracle.R)
+    pops = {
+        "one value everywhere": [big] * n,
+        "all ones": [1] * n,
+        "two values": [big if i & 1 else oracle.R - 1 for i in range(n)],
+        "sparse": [rng.randrange(oracle.R) if i % 9973 == 0 else 0 for i in range(n)],
+        "short (fewer scalars than bases)": [rng.randrange(oracle.R) for _ in range(4097)],
+        "small values": [rng.randrange(256) for _ in range(n)],
+    }
+    ub = nrng.integers(0, 256, (n, 32), dtype=np.uint8)
+    ub[:, 31] &= 0x1F
+    pops["uniform"] = None
+    for wb in ((9, 16, 0) if group == 1 else (11, 0)):
+        ctx = cc.MsmContext(bases, group=group, window_bits=wb)
+        try:
+            for name, sc in pops.items():
+                if sc is None:
+                    arr = ub.reshape(-1)
+                    vals = [int.from_bytes(ub[i].tobytes(), "little") for i in range(n)]
+                else:
+                    arr, vals = _scalars(sc), sc
+                e = sum(k * s_ for k, s_ in zip(ks, vals)) % oracle.R
+                exp = packed(curve.to_affine(curve.mul_affine(gen, e))) if e else bytes(64 * group)
+                got, tm = ctx.run(arr, timings=True)
+                assert got == exp, (group, wb, name)
+                assert got == ctx.run(arr), (group, wb, name, "second run on the same engine")
+        finally:
+            ctx.close()
+
+
 # ------------------------------------------------------------------------------------------- setup
 def _pk_from_json(cc, j):
     a = lambda h: np.frombuffer(bytes.fromhex(h), dtype=np.uint8).copy()
