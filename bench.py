@@ -98,6 +98,11 @@ def permuted_assignments(w_np, l, count, seed):
 
 def main():
     a = parse()
+    # the contract is ONE JSON line on stdout: whatever the runtime libraries print there on the way (gloo's connection
+    # banner, for one) is sent to stderr instead; stdout is restored for the line itself
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -354,9 +359,12 @@ def main():
         if u:
             out["g1_msm_scalar_adds_per_s_uniform_scalars"] = u[0]["g1_msm_scalar_adds_per_s"]   # SURVEY §8d's definition
 
+    sys.stdout.flush()
+    os.dup2(stdout_fd, 1)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        os.dup2(2, 1)
         dist.destroy_process_group()
 
 
