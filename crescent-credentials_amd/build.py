@@ -32,7 +32,7 @@ def _newest_header() -> float:
     t = 0.0
     for root in (CSRC, os.path.join(HERE, "..", "include")):
         for f in os.listdir(root):
-            if f.endswith((".cuh", ".hpp", ".h")):
+            if f.endswith((".hpp", ".h")):
                 t = max(t, os.path.getmtime(os.path.join(root, f)))
     return t
 

@@ -11,7 +11,7 @@
 #include <vector>
 
 #include "../../include/crescent_gpu.h"
-#include "curve.cuh"
+#include "curve.hpp"
 
 namespace cg {
 

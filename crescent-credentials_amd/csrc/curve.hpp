@@ -6,7 +6,7 @@
 // nearly all of its time in.  The sums these produce are the same group elements as arkworks'
 // projective results; only the final affine normalisation (prover.rs:131-135) is observable.
 #pragma once
-#include "field.cuh"
+#include "field.hpp"
 
 namespace cg {
 

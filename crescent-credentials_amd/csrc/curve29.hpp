@@ -1,5 +1,5 @@
-// XYZZ group arithmetic over the lazy 29-bit-limb fields (field29.cuh): the formulas the MSM hot
-// kernels run.  Same EFD formulas as curve.cuh (madd-2008-s, add-2008-s, dbl-2008-s-1), but every
+// XYZZ group arithmetic over the lazy 29-bit-limb fields (field29.hpp): the formulas the MSM hot
+// kernels run.  Same EFD formulas as curve.hpp (madd-2008-s, add-2008-s, dbl-2008-s-1), but every
 // subtraction names the multiple of N it adds and every place a carry propagation is needed is
 // explicit.  The bounds (values in units of N, limbs in units of 2^29) are machine-checked by
 // tools/bounds29.py for BOTH coordinate fields with these constants:
@@ -9,8 +9,8 @@
 //
 // Identity is tracked by an explicit flag in registers and stored as ZZ = all-zero limbs.
 #pragma once
-#include "curve.cuh"
-#include "field29.cuh"
+#include "curve.hpp"
+#include "field29.hpp"
 
 namespace cg {
 

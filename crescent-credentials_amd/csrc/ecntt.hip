@@ -5,7 +5,7 @@
 // Layout: n = 2^logn accumulators (XYZZ, 144 B) in one HBM buffer; a decimation-in-time pass per stage, one
 // butterfly per lane, in place (a butterfly owns its two slots).  A butterfly multiplies its second operand by
 // the 254-bit twiddle with a plain double-and-add over the same lazy 29-bit-limb group law the MSM kernels use
-// (csrc/curve29.cuh), so the whole transform is ≈ n/2·log n·380 group operations: ≈1 s at n = 2^21, paid at load.
+// (csrc/curve29.hpp), so the whole transform is ≈ n/2·log n·380 group operations: ≈1 s at n = 2^21, paid at load.
 #include "msm.hpp"
 #include "ntt.hpp"
 

@@ -18,7 +18,7 @@
 // The 32 bytes that reach HBM for a table point are the canonical value x·R' mod N packed as eight
 // u32; accumulators travel as nine u32 per coordinate.
 #pragma once
-#include "field.cuh"
+#include "field.hpp"
 
 namespace cg {
 

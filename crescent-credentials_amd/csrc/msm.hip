@@ -17,7 +17,7 @@
 //              run up as a piece; pieces are combined 64 segments per wave (k_combine_wave).
 //   reduce   : Σ (b+1)·S_b through row and column sums of the bucket matrix and per-bit sums of those,
 //              folded on the host.
-// All curve arithmetic here runs on the lazy 29-bit-limb representation (field29.cuh / curve29.cuh).
+// All curve arithmetic here runs on the lazy 29-bit-limb representation (field29.hpp / curve29.hpp).
 #include "msm.hpp"
 
 #include <cstring>
@@ -601,7 +601,7 @@ __device__ __forceinline__ Fq2_29 load_table_coord2(const uint32_t* __restrict__
     }
     return c;
 }
-// acc (in LDS) += table point   (madd-2008-s in the statement order of curve29.cuh's madd29)
+// acc (in LDS) += table point   (madd-2008-s in the statement order of curve29.hpp's madd29)
 __device__ __forceinline__ void madd29_lds(uint32_t* sl, bool& inf, const uint32_t* __restrict__ table, uint32_t idx, bool negate) {
     typedef Fq2_29 F;
     const F px = load_table_coord2(table, idx, 0, false);

@@ -3,7 +3,7 @@
 // (call sites forks/groth16/src/prover.rs:66,74,266).
 #pragma once
 #include "common.hpp"
-#include "curve29.cuh"
+#include "curve29.hpp"
 #include "ntt.hpp"
 
 namespace cg {

@@ -8,7 +8,7 @@
 // doubling.  The permutations DIT needs are free: the producer of each transform's input writes it
 // bit-reversed (the sparse product scatters its rows; the last pass of a transform scatters its output).
 #pragma once
-#include "field29.cuh"
+#include "field29.hpp"
 #include "ntt.hpp"
 
 namespace cg {

@@ -18,7 +18,7 @@
 
 #include <vector>
 
-#include "../csrc/field.cuh"
+#include "../csrc/field.hpp"
 
 using cg::Fr;
 

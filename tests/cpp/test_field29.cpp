@@ -1,11 +1,11 @@
-// Host-side check of the lazy 29-bit-limb arithmetic (csrc/field29.cuh, csrc/curve29.cuh) against the
-// saturated 8x32 Montgomery arithmetic (csrc/field.cuh, csrc/curve.cuh), which the GPU parity tests pin to the
+// Host-side check of the lazy 29-bit-limb arithmetic (csrc/field29.hpp, csrc/curve29.hpp) against the
+// saturated 8x32 Montgomery arithmetic (csrc/field.hpp, csrc/curve.hpp), which the GPU parity tests pin to the
 // oracle.  Plain g++; exits non-zero on the first mismatch.  Also asserts the bounds tools/bounds29.py proves.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
-#include "../../crescent-credentials_amd/csrc/curve29.cuh"
+#include "../../crescent-credentials_amd/csrc/curve29.hpp"
 
 using namespace cg;
 

@@ -1,5 +1,5 @@
-"""The lazy 29-bit-limb arithmetic the hot kernels run (csrc/field29.cuh, csrc/curve29.cuh) checked on the HOST
-against the saturated 8x32 Montgomery arithmetic (csrc/field.cuh, csrc/curve.cuh) — g++ build of
+"""The lazy 29-bit-limb arithmetic the hot kernels run (csrc/field29.hpp, csrc/curve29.hpp) checked on the HOST
+against the saturated 8x32 Montgomery arithmetic (csrc/field.hpp, csrc/curve.hpp) — g++ build of
 tests/cpp/test_field29.cpp — and its bound analysis (tools/bounds29.py).  Pure CPU."""
 import os
 import subprocess

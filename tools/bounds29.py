@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Bound checker for the lazy 29-bit-limb formulas of csrc/curve29.cuh.
+"""Bound checker for the lazy 29-bit-limb formulas of csrc/curve29.hpp.
 
 Every field value is tracked as (V, L): V = upper bound of the value in units of the modulus N,
 L = upper bound of limbs 0..7 in units of 2^29.  The script replays the exact operation sequence of
@@ -48,7 +48,7 @@ class Fq:
 
     @staticmethod
     def mul_sub(a, b, c, d, K):
-        """a*b - c*d as one dual-product reduction (a b + (K N - c) d)/R'  (curve29.cuh mul_sub, Fq)"""
+        """a*b - c*d as one dual-product reduction (a b + (K N - c) d)/R'  (curve29.hpp mul_sub, Fq)"""
         assert c.L <= 1.0 + 1e-9, "mul_sub: negated operand must be normalised"
         assert c.V <= K - 1 + 1e-9, "mul_sub: value %.2f needs K >= %d" % (c.V, math.ceil(c.V + 1))
         cneg = B(float(K), 2.0)
@@ -112,7 +112,7 @@ class Fq2:
     norm = Fq.norm
 
 
-# ---- the formulas of curve29.cuh, operation by operation ----------------------------------------------
+# ---- the formulas of curve29.hpp, operation by operation ----------------------------------------------
 
 
 def madd(F, inv, k):
@@ -191,7 +191,7 @@ def check(F, inv, k):
 
 
 if __name__ == "__main__":
-    # invariant of stored accumulators (values in units of N) and the K constants of curve29.cuh
+    # invariant of stored accumulators (values in units of N) and the K constants of curve29.hpp
     INV = dict(x=13.0, y=8.0, z=3.0)
     KC = dict(KX=14, KY=9, K1=4, K2=6)
     check(Fq, INV, KC)

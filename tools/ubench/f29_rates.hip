@@ -4,7 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
-#include "../../crescent-credentials_amd/csrc/curve29.cuh"
+#include "../../crescent-credentials_amd/csrc/curve29.hpp"
 using namespace cg;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 

@@ -5,7 +5,7 @@
 #include <stdio.h>
 #include <stdint.h>
 #include <vector>
-#include "../../crescent-credentials_amd/csrc/field.cuh"
+#include "../../crescent-credentials_amd/csrc/field.hpp"
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
