@@ -341,14 +341,22 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
             std::unique_ptr<ProofSlot> sl(new ProofSlot());
             // CG_SERIAL_STREAMS=1 (profiling aid): one stream per slot, so a kernel trace shows stand-alone durations
             const bool serial = getenv("CG_SERIAL_STREAMS") && getenv("CG_SERIAL_STREAMS")[0] == '1';
+            // CG_CHAIN_PRIORITY=1 (experiment): the witness-map -> h-MSM chain, which sets a lone proof's latency, on a
+            // high-priority stream
+            const bool chain_prio = getenv("CG_CHAIN_PRIORITY") && getenv("CG_CHAIN_PRIORITY")[0] == '1';
+            int prio_lo = 0, prio_hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
             for (int i = 0; i < 5; ++i) {
                 if (serial && i) sl->st[i] = sl->st[0];
+                else if (chain_prio && i == 0) CG_HIP(hipStreamCreateWithPriority(&sl->st[i], hipStreamNonBlocking, prio_hi));
                 else CG_HIP(hipStreamCreateWithFlags(&sl->st[i], hipStreamNonBlocking));
             }
             CG_HIP(hipEventCreateWithFlags(&sl->ev_w, hipEventDisableTiming));
             for (auto& e : sl->ev_t) CG_HIP(hipEventCreate(&e));
-            // a shard of one proof is a latency job; whole proofs in flight are a throughput job
-            sl->eh.latency_mode = sl->el.latency_mode = sl->ea.latency_mode = sl->eb1.latency_mode = sl->eb2.latency_mode = c->shard_count > 1;
+            // a shard of one proof, or a context that proves one proof at a time, is a latency job; several proofs in
+            // flight are a throughput job
+            sl->eh.latency_mode = sl->el.latency_mode = sl->ea.latency_mode = sl->eb1.latency_mode = sl->eb2.latency_mode =
+                c->shard_count > 1 || n_slots == 1;
             sl->eh.init(&c->bh); sl->el.init(&c->bl); sl->ea.init(&c->ba); sl->eb1.init(&c->bb1); sl->eb2.init(&c->bb2);
             sl->w_canon.alloc(M); sl->h_canon.alloc(D);
             sl->wm.alloc(M, D, std::max(c->A.sell_scratch, std::max(c->B.sell_scratch, c->C.sell_scratch)));
