@@ -19,6 +19,8 @@ SYNTH_LIB = os.path.join(HERE, "libcg_synth.so")
 
 HIP_SOURCES = ["ntt.hip", "wmap29.hip", "msm.hip", "ecntt.hip", "prover.hip", "unit.hip", "setup.hip", "r1cs.hip", "serialize.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# A/B aid: extra compiler flags (e.g. CG_HIPCC_EXTRA="-DCG_MUL2_ONE_CHAIN"); a change of flags rebuilds every object
+EXTRA_FLAGS = os.environ.get("CG_HIPCC_EXTRA", "").split()
 
 
 def _hipcc() -> str:
@@ -38,22 +40,25 @@ def _newest_header() -> float:
 
 
 def _compile(src: str, obj: str) -> None:
-    cmd = [_hipcc(), *HIPCC_FLAGS, "-c", src, "-o", obj]
+    cmd = [_hipcc(), *HIPCC_FLAGS, *EXTRA_FLAGS, "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
 
 
-def build(verbose: bool = False, jobs: int = 4) -> str:
+def build(verbose: bool = False, jobs: int = int(os.environ.get("CG_BUILD_JOBS", "4"))) -> str:
     os.makedirs(BUILD, exist_ok=True)
     hdr_t = _newest_header()
+    stamp = os.path.join(BUILD, "flags.txt")
+    flags_now = " ".join(HIPCC_FLAGS + EXTRA_FLAGS)
+    flags_changed = (open(stamp).read() if os.path.exists(stamp) else " ".join(HIPCC_FLAGS)) != flags_now
     todo = []
     objs = []
     for s in HIP_SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(BUILD, s.replace(".hip", ".o"))
         objs.append(obj)
-        if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+        if flags_changed or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
             todo.append((src, obj))
     if todo:
         if verbose:
@@ -61,6 +66,8 @@ def build(verbose: bool = False, jobs: int = 4) -> str:
         with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
             for f in [ex.submit(_compile, s, o) for s, o in todo]:
                 f.result()
+        with open(stamp, "w") as f:
+            f.write(flags_now)
     if todo or not os.path.exists(LIB):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)

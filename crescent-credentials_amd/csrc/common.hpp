@@ -79,6 +79,13 @@ struct PinnedBuf {
         if (count) CG_HIP(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault));
         n = count;
     }
+    // the address kernels use to write this host memory directly (results of a few KB: no copy kernel, no extra
+    // submission on the stream; the stream synchronisation that precedes every host read makes the writes visible)
+    T* dev() const {
+        void* d = nullptr;
+        if (p) CG_HIP(hipHostGetDevicePointer(&d, (void*)p, 0));
+        return (T*)d;
+    }
 };
 
 // zero `bytes` (a multiple of 16) of device memory with full-width stores on the whole chip

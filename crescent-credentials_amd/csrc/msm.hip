@@ -896,12 +896,16 @@ __global__ void __launch_bounds__(256) k_bucket_rows_cols(const uint32_t* __rest
 }
 
 // block b < rbits: Σ_{r: bit b of r} Row_r;  block rbits + k: Σ_{col: bit k of (col + 1)} Col_col;  blockIdx.y = window
+// `out` and `plan_out` are HOST memory (PinnedBuf::dev): the MSM's last kernel hands its few KB of per-bit sums and the
+// plan's statistics straight to the host.
 template <class F29T>
 __global__ void __launch_bounds__(256) k_bit_sums(const uint32_t* __restrict__ rows, uint32_t R, uint32_t rbits,
-                                                  const uint32_t* __restrict__ cols, uint32_t C, uint32_t* __restrict__ out) {
+                                                  const uint32_t* __restrict__ cols, uint32_t C, uint32_t* __restrict__ out,
+                                                  const uint32_t* __restrict__ plan, uint32_t* __restrict__ plan_out) {
     constexpr int ACC = Words29<F29T>::ACC;
     extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
     const uint32_t w = blockIdx.y, b = blockIdx.x;
+    if (w == 0 && b == 0 && threadIdx.x < PLAN_WORDS) plan_out[threadIdx.x] = plan[threadIdx.x];
     const bool is_row = b < rbits;
     const uint32_t bit = is_row ? b : b - rbits, n = is_row ? R : C, offset = is_row ? 0u : 1u;
     const uint32_t* src = is_row ? rows + (size_t)w * R * ACC : cols + (size_t)w * C * ACC;
@@ -983,10 +987,9 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
         rows_buf.alloc((size_t)R * wins * ACC);
         cols_buf.alloc((size_t)C * wins * ACC);
     }
-    result.alloc((size_t)wins * (red_rbits + red_cbits1) * ACC);      // per window: the per-bit sums of rows, then of columns
     h_plan.alloc(PLAN_WORDS);
     for (int k = 0; k < PLAN_WORDS; ++k) h_plan.p[k] = 0;
-    h_result.alloc((size_t)wins * (red_rbits + red_cbits1) * ACC);
+    h_result.alloc((size_t)wins * (red_rbits + red_cbits1) * ACC);   // per window: the per-bit sums of rows, then of columns
     if (!ev_t[0])
         for (auto& e : ev_t) CG_HIP(hipEventCreate(&e));
 }
@@ -1013,7 +1016,10 @@ void MsmEngine<F>::digits(const Fr* scalars_dev, uint64_t n, hipStream_t st) {
     n_scalars = n;
     for (int k = 0; k < PLAN_WORDS; ++k) h_plan.p[k] = 0;
     CG_HIP(hipEventRecord(ev_t[0], st));
-    if (!n) return;
+    if (!n) {   // the reduction's last kernel copies the device plan to the host: leave it a zeroed one
+        fill_zero(counters.p, PLAN_WORDS * 4, st);
+        return;
+    }
     const uint32_t B1 = 1u << bits1;
     uint32_t* plan = counters.p;
     uint32_t* hist1 = plan + PLAN_WORDS;
@@ -1072,9 +1078,8 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
             segs = waves;
             from_a = !from_a;
         }
-        CG_HIP(hipMemcpyAsync(h_plan.p, plan, PLAN_WORDS * 4, hipMemcpyDeviceToHost, st));
     }
-    // bucket reduction (see the comment above block_tree_sum): two launches and the copy of the per-bit sums, of a fixed
+    // bucket reduction (see the comment above block_tree_sum): two launches, the second writing the per-bit sums to host memory, of a fixed
     // shape for a given window size - captured once into a HIP graph and replayed as one submission.
     if (!red_graph) {
         hipGraph_t g = nullptr;
@@ -1104,9 +1109,9 @@ void MsmEngine<F>::enqueue_reduction(hipStream_t st) {
     k_bucket_rows_cols<F29T><<<dim3(R + C, wins), 256, lds, st>>>(bucket_sums.p, R, C, rows_buf.p, cols_buf.p);
     CG_KERNEL_CHECK();
     const uint32_t nbits = (uint32_t)(red_rbits + red_cbits1);
-    k_bit_sums<F29T><<<dim3(nbits, wins), 256, lds, st>>>(rows_buf.p, R, (uint32_t)red_rbits, cols_buf.p, C, result.p);
+    k_bit_sums<F29T><<<dim3(nbits, wins), 256, lds, st>>>(rows_buf.p, R, (uint32_t)red_rbits, cols_buf.p, C, h_result.dev(), counters.p,
+                                                          h_plan.dev());
     CG_KERNEL_CHECK();
-    CG_HIP(hipMemcpyAsync(h_result.p, result.p, (size_t)wins * nbits * ACC * 4, hipMemcpyDeviceToHost, st));
 }
 
 // ---- host: lazy 29-bit accumulator -> saturated Montgomery(2^256) XYZZ ---------------------------------

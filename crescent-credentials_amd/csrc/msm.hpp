@@ -62,9 +62,9 @@ struct MsmEngine {
     DevBuf<uint32_t> part_pts_a, part_pts_b;
     DevBuf<uint32_t> rows_buf, cols_buf;   // row / column sums of the bucket matrix (bucket reduction)
     int red_rbits = 0, red_cbits1 = 0;     // bits of the row weights r < R and of the column weights col + 1 <= C
-    DevBuf<uint32_t> result;          // per window: red_rbits + red_cbits1 per-bit sums of the rows / the columns
+    // host memory the reduction's last kernel writes directly:
     PinnedBuf<uint32_t> h_plan;       // the device plan of the last MSM: [0] entries, [3] scalars with a non-zero digit
-    PinnedBuf<uint32_t> h_result;
+    PinnedBuf<uint32_t> h_result;     // per window: red_rbits + red_cbits1 per-bit sums of the rows / the columns
     uint64_t n_scalars = 0;
     bool latency_mode = false;        // set before init(): short segments (one proof at a time matters more than proofs per second)
     // valid once the stream has been synchronised

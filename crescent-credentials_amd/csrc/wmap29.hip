@@ -369,10 +369,10 @@ void wm29_run(const Wm29Domain& dom, const DevCsr& A, const DevCsr& B, const Dev
               hipStream_t st, bool coset_values) {
     const uint64_t D = dom.n;
     const int logn = dom.logn;
-    CG_HIP(hipMemsetAsync(buf.bad_input.p, 0, 4, st));
-    k_w_to29<<<ceil_div(M, 256), 256, 0, st>>>(w_canon, buf.w29.p, M, buf.bad_input.p);
+    // the flag is HOST memory the kernel writes only when it meets a non-canonical element: no memset, no copy back
+    buf.h_bad_input.p[0] = 0;
+    k_w_to29<<<ceil_div(M, 256), 256, 0, st>>>(w_canon, buf.w29.p, M, buf.h_bad_input.dev());
     CG_KERNEL_CHECK();
-    CG_HIP(hipMemcpyAsync(buf.h_bad_input.p, buf.bad_input.p, 4, hipMemcpyDeviceToHost, st));
     uint32_t* v[3] = {buf.va.p, buf.vb.p, buf.vc.p};
     const DevCsr* mats[3] = {&A, &B, &C};
     const Csr29* dicts[3] = {&dA, &dB, &dC};
@@ -439,7 +439,6 @@ void Ntt29Unit::build(int logn_, hipStream_t st) {
     k_to_packed29<<<ceil_div(n, 256), 256, 0, st>>>(g.p, gpow.p, n, 0, 0);
     CG_KERNEL_CHECK();
     work.alloc(n * 8);
-    bad_input.alloc(1);
     h_bad_input.alloc(1);
     // plain 1 and plain 1/n as packed constants
     memset(one_plain, 0, 32);
@@ -450,10 +449,9 @@ void Ntt29Unit::build(int logn_, hipStream_t st) {
 }
 
 bool Ntt29Unit::run(Fr* data_dev, bool inverse, bool coset, hipStream_t st) {
-    CG_HIP(hipMemsetAsync(bad_input.p, 0, 4, st));
-    k_unit_in29<<<ceil_div(n, 256), 256, 0, st>>>(data_dev, work.p, n, logn, (!inverse && coset) ? gpow.p : nullptr, bad_input.p);
+    h_bad_input.p[0] = 0;
+    k_unit_in29<<<ceil_div(n, 256), 256, 0, st>>>(data_dev, work.p, n, logn, (!inverse && coset) ? gpow.p : nullptr, h_bad_input.dev());
     CG_KERNEL_CHECK();
-    CG_HIP(hipMemcpyAsync(h_bad_input.p, bad_input.p, 4, hipMemcpyDeviceToHost, st));
     uint32_t* out = reinterpret_cast<uint32_t*>(data_dev);
     if (!inverse) dit29(dom, dom.tw_fwd.p, work.p, nullptr, nullptr, false, work.p, out, nullptr, false, st, one_plain);
     else if (!coset) dit29(dom, dom.tw_inv.p, work.p, nullptr, nullptr, false, work.p, out, nullptr, false, st, ninv_plain);
