@@ -256,7 +256,8 @@ def main():
         # every rank assembled the same bytes as the unsharded context does
         r_, s_ = srng.randrange(R), srng.randrange(R)
         same = sp.prove_dev(ws_dev[0].data_ptr(), r_, s_).data == prover.prove_dev(ws_dev[0].data_ptr(), r_, s_).data
-        out["sharded"] = {"mode": "one proof, every query range-sharded over the ranks; 5 partial points per rank",
+        out["sharded"] = {"mode": "one proof: l/a/b queries range-sharded over the ranks, the h query by coset points j = rank (mod ranks) "
+                                  "(two of a shard's four transforms shrink by the rank count); 5 partial points per rank",
                           "ranks": world, "backend": dist.get_backend(), "proofs": a.sharded_steps,
                           "ms_per_proof": round(ds / a.sharded_steps * 1e3, 3), "proofs_per_s": round(a.sharded_steps / ds, 3),
                           "all_gathers": gathers, "all_gather_bytes_per_rank": 384,

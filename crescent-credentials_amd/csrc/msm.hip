@@ -1231,14 +1231,30 @@ void sum_xyzz_by_key(const uint32_t* keys, const uint32_t* pts, uint64_t count, 
     CG_HIP(hipStreamSynchronize(st));
 }
 
+// packed table points and validity flags first, first + stride, first + 2·stride, ... -> contiguous
+__global__ void __launch_bounds__(256) k_gather_points(const uint32_t* __restrict__ row0, const uint8_t* __restrict__ valid, uint64_t first,
+                                                       uint64_t stride, uint64_t count, uint32_t* __restrict__ out, uint8_t* __restrict__ out_valid) {
+    constexpr int AFF = MsmBases<Fq>::AFF;
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const uint64_t j = first + k * stride;
+    const uint4* src = reinterpret_cast<const uint4*>(row0 + j * AFF);
+    uint4* dst = reinterpret_cast<uint4*>(out + k * AFF);
+#pragma unroll
+    for (int i = 0; i < AFF / 4; ++i) dst[i] = src[i];
+    out_valid[k] = valid[j];
+}
+
 // h query -> coset evaluation basis, C matrix -> l query (ecntt.hip), then the usual window rows over each slice
+// (h: the points h_first + k·h_stride, k < h_count; l: a contiguous range)
 void build_hl_bases_folded(MsmBases<Fq>& out_h, MsmBases<Fq>& out_l, const Affine<Fq>* h_bases_dev, uint64_t n_h, int logn,
                            const Affine<Fq>* l_bases_dev, uint64_t num_inputs, uint64_t M, const cg_csr& c_matrix,
-                           uint64_t num_constraints, const Fr& vanishing_inv, uint64_t h_first, uint64_t h_count, int c_h,
+                           uint64_t num_constraints, const Fr& vanishing_inv, uint64_t h_first, uint64_t h_stride, uint64_t h_count, int c_h,
                            uint64_t l_first, uint64_t l_count, int c_l, hipStream_t st) {
     constexpr int AFF = MsmBases<Fq>::AFF;
     const uint64_t n = 1ull << logn, n_l = M - num_inputs;
-    if (h_first + h_count > n || l_first + l_count > M) throw HipError(CG_ERR_INVALID_ARGUMENT, "range outside the query");
+    if (!h_stride || (h_count && h_first + (h_count - 1) * h_stride >= n) || l_first + l_count > M)
+        throw HipError(CG_ERR_INVALID_ARGUMENT, "range outside the query");
     DevBuf<uint32_t> h_row0(n_h ? n_h * AFF : 4), l_row0(n_l ? n_l * AFF : 4);
     DevBuf<uint8_t> h_valid(n_h ? n_h : 1), l_valid(n_l ? n_l : 1);
     if (n_h) k_table_first<Fq><<<ceil_div(n_h, 256), 256, 0, st>>>(h_bases_dev, h_row0.p, h_valid.p, n_h);
@@ -1248,7 +1264,16 @@ void build_hl_bases_folded(MsmBases<Fq>& out_h, MsmBases<Fq>& out_l, const Affin
         DevBuf<uint32_t> row0t(n * AFF);
         DevBuf<uint8_t> validt(n);
         ec_transform_h_bases(h_row0.p, h_valid.p, n_h, logn, row0t.p, validt.p, st);
-        out_h.build_from_row0(row0t.p + h_first * AFF, validt.p + h_first, h_count, c_h, st);
+        if (h_stride == 1) {
+            out_h.build_from_row0(row0t.p + h_first * AFF, validt.p + h_first, h_count, c_h, st);
+        } else {
+            DevBuf<uint32_t> row0s(h_count ? h_count * AFF : 4);
+            DevBuf<uint8_t> valids(h_count ? h_count : 1);
+            if (h_count) k_gather_points<<<ceil_div(h_count, 256), 256, 0, st>>>(row0t.p, validt.p, h_first, h_stride, h_count, row0s.p, valids.p);
+            CG_KERNEL_CHECK();
+            out_h.build_from_row0(row0s.p, valids.p, h_count, c_h, st);
+            CG_HIP(hipStreamSynchronize(st));   // the gathered copies are released at the end of this scope
+        }
         CG_HIP(hipStreamSynchronize(st));
     }
     {

@@ -112,12 +112,12 @@ void ec_fold_c_into_l(const uint32_t* h_row0, const uint8_t* h_valid, uint64_t n
                       const cg_csr& c_matrix, uint64_t num_constraints, uint64_t num_inputs, uint64_t M,
                       const uint32_t* l_row0, const uint8_t* l_valid, uint32_t* row0_out, uint8_t* valid_out, hipStream_t st);
 void sum_xyzz_by_key(const uint32_t* keys, const uint32_t* pts, uint64_t count, uint32_t* sums, hipStream_t st);
-// window tables of the transformed h query over [h_first, h_first + h_count) of 2^logn and of the folded l query over
-// [l_first, l_first + l_count) of M
+// window tables of the transformed h query over the points h_first + k·h_stride, k < h_count, of 2^logn and of the folded
+// l query over [l_first, l_first + l_count) of M
 void build_hl_bases_folded(MsmBases<Fq>& out_h, MsmBases<Fq>& out_l, const Affine<Fq>* h_bases_dev, uint64_t n_h, int logn,
                            const Affine<Fq>* l_bases_dev, uint64_t num_inputs, uint64_t M, const cg_csr& c_matrix,
-                           uint64_t num_constraints, const Fr& vanishing_inv, uint64_t h_first, uint64_t h_count, int c_h,
-                           uint64_t l_first, uint64_t l_count, int c_l, hipStream_t st);
+                           uint64_t num_constraints, const Fr& vanishing_inv, uint64_t h_first, uint64_t h_stride, uint64_t h_count,
+                           int c_h, uint64_t l_first, uint64_t l_count, int c_l, hipStream_t st);
 
 // import packed affine points (64 B / 128 B each, `coord_form`) into Montgomery Affine<F> on the device
 template <class F>

@@ -162,6 +162,10 @@ struct cg_ctx {
     Csr29 dA, dB, dC;
     NttDomain dom;
     Wm29Domain wdom;
+    // a shard of a folded key over a power-of-two shard count owns the coset points j ≡ shard_rank (mod shard_count) of
+    // the h MSM instead of a contiguous range (wmap29.hpp Wm29Strided): half of its transforms shrink by the shard count
+    bool h_strided = false;
+    Wm29Strided wstr;
     std::vector<std::unique_ptr<ProofSlot>> slots;
     // window tuning: the window of each assignment-driven query is re-chosen once from the digit statistics of
     // the first proof (circom witnesses are mostly 0/1 wires, for which the size-based default is far too wide)
@@ -306,7 +310,13 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         c->fb_delta_g1.build(c->delta_g1);
         c->fb_delta_g2.build(c->delta_g2);
         c->folded = !(opt && (opt->flags & CG_FLAG_H_COEFFICIENT_BASIS));
+        {
+            const int logs = ilog2_ceil((uint64_t)c->shard_count);
+            c->h_strided = c->folded && c->shard_count > 1 && (1 << logs) == c->shard_count && logD - logs >= 4 &&
+                           !(getenv("CG_CONTIGUOUS_SHARDS") && getenv("CG_CONTIGUOUS_SHARDS")[0] == '1');   // A/B aid
+        }
         c->rh = shard_range(c->folded ? D : D - 1, c->shard_rank, c->shard_count);
+        if (c->h_strided) c->rh = {0, D / (uint64_t)c->shard_count};     // positions in the shard's own list of points
         c->rl = shard_range(c->folded ? M : M - l, c->shard_rank, c->shard_count);
         c->ra = shard_range(M - 1, c->shard_rank, c->shard_count);
         c->A.upload(abc[0], m, M);     // validates the CSR views (monotone row_ptr, column range, canonical coefficients)
@@ -320,7 +330,8 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
             import_bases<Fq>(pk->h_query, form, D - 1, th.p, s0);
             import_bases<Fq>(pk->l_query, form, M - l, tl.p, s0);
             const uint64_t nh = c->rh.hi - c->rh.lo, nl = c->rl.hi - c->rl.lo;
-            build_hl_bases_folded(c->bh, c->bl, th.p, D - 1, logD, tl.p, l, M, abc[2], m, c->dom.vanishing_inv, c->rh.lo, nh,
+            build_hl_bases_folded(c->bh, c->bl, th.p, D - 1, logD, tl.p, l, M, abc[2], m, c->dom.vanishing_inv,
+                                  c->h_strided ? (uint64_t)c->shard_rank : c->rh.lo, c->h_strided ? (uint64_t)c->shard_count : 1, nh,
                                   wb > 0 ? wb : msm_default_window(nh ? nh : 1, true), c->rl.lo, nl,
                                   wb > 0 ? wb : msm_default_window(nl ? nl : 1, true), s0);
         } else {
@@ -331,6 +342,7 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         load_query<Fq>(c->bb1, pk->b_g1_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, s0);
         load_query<Fq2>(c->bb2, pk->b_g2_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, s0);
         c->wdom.build(c->dom, s0);
+        if (c->h_strided) c->wstr.build(c->dom, ilog2_ceil((uint64_t)c->shard_count), c->shard_rank, s0);
         c->dA.build(c->A, s0); c->dB.build(c->B, s0); c->dC.build(c->C, s0);
         CG_HIP(hipStreamSynchronize(s0));
         (void)hipStreamDestroy(s0);
@@ -381,7 +393,8 @@ extern "C" void cg_circuit_free(cg_ctx* ctx) {
 // (LibsnarkReduction::witness_map_from_matrices, r1cs_to_qap.rs:150-213)
 // ---------------------------------------------------------------------------------------------
 static void run_witness_map(cg_ctx* c, ProofSlot* S, const Fr* w_canon_dev, hipStream_t st, bool coset_values) {
-    wm29_run(c->wdom, c->A, c->B, c->C, c->dA, c->dB, c->dC, S->wm, w_canon_dev, c->M, c->m, c->l, S->h_canon.p, st, coset_values);
+    wm29_run(c->wdom, c->A, c->B, c->C, c->dA, c->dB, c->dC, S->wm, w_canon_dev, c->M, c->m, c->l, S->h_canon.p, st, coset_values,
+             coset_values && c->h_strided ? &c->wstr : nullptr);
 }
 
 struct Partials {

@@ -99,14 +99,47 @@ void Wm29Domain::build(const NttDomain& d, hipStream_t st) {
     icoset.alloc(n * 8);
     k_to_limbs12<<<ceil_div(half, 256), 256, 0, st>>>(d.tw_fwd.p, tw_fwd.p, half);
     k_to_limbs12<<<ceil_div(half, 256), 256, 0, st>>>(d.tw_inv.p, tw_inv.p, half);
-    // NttDomain keeps the coset tables at bit-reversed positions; here they are indexed naturally
-    k_to_packed29<<<ceil_div(n, 256), 256, 0, st>>>(d.coset_br.p, coset.p, n, 0, logn);
-    k_to_packed29<<<ceil_div(n, 256), 256, 0, st>>>(d.icoset_br.p, icoset.p, n, 1, logn);
+    if (d.coset_br.n) {   // a domain built without coset tables serves plain transforms only (Wm29Strided::sub)
+        // NttDomain keeps the coset tables at bit-reversed positions; here they are indexed naturally
+        k_to_packed29<<<ceil_div(n, 256), 256, 0, st>>>(d.coset_br.p, coset.p, n, 0, logn);
+        k_to_packed29<<<ceil_div(n, 256), 256, 0, st>>>(d.icoset_br.p, icoset.p, n, 1, logn);
+    }
     CG_KERNEL_CHECK();
     Fr29 v = from_mont256<Fr29P>(d.vanishing_inv);   // host arithmetic
     pack29(v, vinv);
     Fr vp = from_mont(d.vanishing_inv);
     memcpy(vinv_plain, vp.l, 32);
+}
+
+void Wm29Strided::build(const NttDomain& big, int logs_, int rank, hipStream_t st) {
+    logs = logs_;
+    d = big.n >> logs;
+    NttDomain small;
+    small.build(big.logn - logs, false, st);
+    sub.build(small, st);
+    // s^e / n, s = g·ω^rank (ω the root of the size-n domain)
+    const Fr s = mul(fr_from_u64(5), fr_pow_u64(fr_root_of_unity(big.logn), (uint64_t)rank));
+    DevBuf<Fr> t(big.n);
+    fr_pow_table(t.p, s, inv(fr_from_u64(big.n)), big.n, false, big.logn, st);
+    fold.alloc(big.n * 8);
+    k_to_packed29<<<ceil_div(big.n, 256), 256, 0, st>>>(t.p, fold.p, big.n, 0, 0);
+    CG_KERNEL_CHECK();
+    CG_HIP(hipStreamSynchronize(st));   // `small` and `t` are released on return
+}
+
+// out[rev_d(i)] = Σ_t a[i + t·d]·T[i + t·d], i < d, t < 2^logs (Wm29Strided): a the unscaled output of the inverse
+// transform (packed, < 2^256), T canonical.  A product is below 1.04 N; limbs are renormalised every fourth term.
+__global__ void __launch_bounds__(256) k_fold29(const uint32_t* __restrict__ a, const uint32_t* __restrict__ T, uint32_t* __restrict__ out,
+                                                uint32_t d, int logd, uint32_t terms) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d) return;
+    Fr29 acc = Fr29::zero();
+    for (uint32_t t = 0; t < terms; ++t) {
+        const uint64_t e = (uint64_t)i + (uint64_t)t * d;
+        acc = add(acc, mul(load_packed29(a, e), load_packed29(T, e)));
+        if ((t & 3u) == 3u) acc = normalize(acc);
+    }
+    store_packed29(out, brev(i, logd), weak_reduce(normalize(acc)));
 }
 
 void Csr29::build(const DevCsr& m, hipStream_t st) {
@@ -366,7 +399,7 @@ static void dit29(const Wm29Domain& d, const uint32_t* tw, const uint32_t* in_a,
 
 void wm29_run(const Wm29Domain& dom, const DevCsr& A, const DevCsr& B, const DevCsr& C, const Csr29& dA, const Csr29& dB,
               const Csr29& dC, Wm29Buffers& buf, const Fr* w_canon, uint64_t M, uint64_t m, uint64_t l, Fr* h_out,
-              hipStream_t st, bool coset_values) {
+              hipStream_t st, bool coset_values, const Wm29Strided* strided) {
     const uint64_t D = dom.n;
     const int logn = dom.logn;
     // the flag is HOST memory the kernel writes only when it meets a non-canonical element: no memset, no copy back
@@ -394,6 +427,23 @@ void wm29_run(const Wm29Domain& dom, const DevCsr& A, const DevCsr& B, const Dev
     }
     k_place_inputs29<<<ceil_div(l, 256), 256, 0, st>>>(buf.w29.p, buf.va.p, m, l, logn);
     CG_KERNEL_CHECK();
+    if (coset_values && strided) {
+        // a shard's own coset points only (Wm29Strided): two transforms of size D, two of size d
+        const Wm29Strided& S = *strided;
+        const uint32_t d = (uint32_t)S.d;
+        const int logd = S.sub.logn;
+        const uint32_t terms = 1u << S.logs;
+        dit29(dom, dom.tw_inv.p, buf.va.p, nullptr, nullptr, false, buf.va.p, buf.vt.p, nullptr, false, st);          // n·a_e, natural order
+        k_fold29<<<ceil_div(d, 256), 256, 0, st>>>(buf.vt.p, S.fold.p, buf.va.p, d, logd, terms);
+        CG_KERNEL_CHECK();
+        dit29(S.sub, S.sub.tw_fwd.p, buf.va.p, nullptr, nullptr, false, buf.va.p, buf.vc.p, nullptr, false, st, dom.vinv_plain);   // vinv·a, plain
+        dit29(dom, dom.tw_inv.p, buf.vb.p, nullptr, nullptr, false, buf.vb.p, buf.vt.p, nullptr, false, st);
+        k_fold29<<<ceil_div(d, 256), 256, 0, st>>>(buf.vt.p, S.fold.p, buf.vb.p, d, logd, terms);
+        CG_KERNEL_CHECK();
+        dit29(S.sub, S.sub.tw_fwd.p, buf.vb.p, nullptr, nullptr, false, buf.vb.p, reinterpret_cast<uint32_t*>(h_out), nullptr, false, st, nullptr,
+              buf.vc.p);
+        return;
+    }
     if (coset_values) {
         // four transforms: q_j = vinv·a(gω^j)·b(gω^j), the scalars of the h MSM over the transformed h query
         dit29(dom, dom.tw_inv.p, buf.va.p, nullptr, nullptr, false, buf.va.p, buf.vt.p, dom.coset.p, true, st);

@@ -25,6 +25,21 @@ struct Wm29Domain {
     void build(const NttDomain& d, hipStream_t st);
 };
 
+// A shard that owns the coset points j ≡ rank (mod 2^logs) of the h MSM (one proof split over 2^logs GPUs).
+// The values it needs, a(g·ω^j) for those j, are a's values on the smaller coset (g·ω^rank)·<ω^(2^logs)> of d = n / 2^logs
+// points: a(x) mod (x^d − s^d) with s = g·ω^rank, evaluated there.  With the coefficients a_e in hand (one inverse
+// transform of size n, as before) that is
+//     a'_i = Σ_t a_{i + t·d} · s^{i + t·d} / n          (i < d; one pass over the vector: k_fold29)
+// followed by a plain transform of size d — instead of the second full-size transform.  Per proof a shard then runs two
+// transforms of size n and two of size d where a contiguous range of j costs four of size n.
+struct Wm29Strided {
+    int logs = 0;                // log2 of the shard count
+    uint64_t d = 0;              // points owned: n >> logs
+    Wm29Domain sub;              // twiddles of the size-d domain (ω^(2^logs))
+    DevBuf<uint32_t> fold;       // s^e / n at natural index e < n, R' form, s = g·ω^rank
+    void build(const NttDomain& big, int logs, int rank, hipStream_t st);
+};
+
 struct Csr29 {     // the matrices' coefficient dictionary in R' form (index arrays are shared with DevCsr)
     DevBuf<uint32_t> dict;
     void build(const DevCsr& m, hipStream_t st);
@@ -64,9 +79,10 @@ struct Ntt29Unit {
 // w_canon: M canonical scalars on the device.  h_out: D canonical scalars (natural order), on the device:
 // the coefficients of h (coset_values = false: the reference's result, seven transforms), or the coset values of the
 // quotient's a∘b part, q_j = vinv·a(g·ω^j)·b(g·ω^j) (coset_values = true: four transforms; for a key whose h query is
-// held in that basis and whose l query carries the C matrix, msm.hpp).
+// held in that basis and whose l query carries the C matrix, msm.hpp).  With `strided` (coset_values only): the d values
+// q_j of the shard's points j = rank + k·2^logs, k < d, in the order of k.
 void wm29_run(const Wm29Domain& dom, const DevCsr& A, const DevCsr& B, const DevCsr& C, const Csr29& dA, const Csr29& dB,
               const Csr29& dC, Wm29Buffers& buf, const Fr* w_canon, uint64_t M, uint64_t m, uint64_t l, Fr* h_out,
-              hipStream_t st, bool coset_values);
+              hipStream_t st, bool coset_values, const Wm29Strided* strided = nullptr);
 
 }  // namespace cg

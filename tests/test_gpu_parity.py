@@ -487,6 +487,31 @@ def test_sharded_partials_assemble_to_same_proof(cc, oracle):
                 p.close()
 
 
+@pytest.mark.parametrize("shape,nshard", [("log11", 2), ("log13", 4), ("log14", 8), ("medium", 8), ("log17", 16)])
+def test_strided_shards_assemble_to_same_proof(cc, oracle, shape, nshard):
+    """A power-of-two shard count gives every shard the coset points j = rank (mod count) of the h MSM (two of its four
+    transforms shrink by the shard count, csrc/wmap29.hpp Wm29Strided); the assembled proof must not change: bytes equal
+    the unsharded context's (itself pinned to oracle/cpu_ref.c below) for satisfying and arbitrary assignments."""
+    from crescent_credentials_amd import workloads as wl
+    l, m, M = _CPU_SHAPES[shape]
+    cm, w = wl.synthetic_circuit(77, l, m, M, 0.5, 3)
+    rng = random.Random(5)
+    tau, alpha, beta, delta = (rng.randrange(1, oracle.R) for _ in range(4))
+    pk = cc.generate_parameters_with_qap(cm, alpha, beta, delta, tau)
+    w_bad = _scalars([rng.randrange(oracle.R) for _ in range(M)])       # does not satisfy the circuit: the identities hold anyway
+    whole = cc.Prover(pk, cm)
+    shards = [cc.Prover(pk, cm, shard_rank=k, shard_count=nshard) for k in range(nshard)]
+    try:
+        for wit in (w, w_bad):
+            for r, s in ((0, 0), (rng.randrange(oracle.R), rng.randrange(oracle.R))):
+                parts = b"".join(p.prove_partial(wit, r) for p in shards)
+                assert shards[-1].assemble(parts, nshard, r, s).data == whole.prove(wit, r, s).data
+    finally:
+        whole.close()
+        for p in shards:
+            p.close()
+
+
 _CPU_SHAPES = {"log11": (4, 1_500, 1_600), "exact12": (6, 4_090, 4_200), "log13": (10, 5_000, 5_100), "log14": (3, 9_000, 16_000),
                "log15": (12, 20_000, 20_500), "medium": (20, 60_000, 61_000), "log17": (8, 100_000, 100_100), "large18": (26, 250_000, 255_000)}
 
