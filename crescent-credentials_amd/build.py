@@ -16,6 +16,10 @@ CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libcrescent_gpu.so")
 SYNTH_LIB = os.path.join(HERE, "libcg_synth.so")
+# the reference-side caller in plain C (integration/c): built here so that every build proves the header is valid C
+# and that the ABI links without Python or torch
+CALLER_SRC = os.path.join(HERE, "..", "integration", "c", "crescent_prove.c")
+CALLER_BIN = os.path.join(HERE, "..", "integration", "c", "crescent_prove")
 
 HIP_SOURCES = ["ntt.hip", "wmap29.hip", "msm.hip", "ecntt.hip", "prover.hip", "unit.hip", "setup.hip", "r1cs.hip", "serialize.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
@@ -80,6 +84,15 @@ def build(verbose: bool = False, jobs: int = int(os.environ.get("CG_BUILD_JOBS",
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("synth build failed:\n" + r.stderr[-4000:])
+    if os.path.exists(CALLER_SRC) and (todo or not os.path.exists(CALLER_BIN) or
+                                       os.path.getmtime(CALLER_BIN) < max(os.path.getmtime(CALLER_SRC), hdr_t)):
+        rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(_hipcc()))), "lib")
+        cmd = ["gcc", "-std=c11", "-D_POSIX_C_SOURCE=200809L", "-O2", "-Wall", "-Wextra", "-Werror", "-pedantic",
+               "-I", os.path.join(HERE, "..", "include"), CALLER_SRC, "-o", CALLER_BIN, "-L", HERE, "-lcrescent_gpu",
+               "-Wl,-rpath,$ORIGIN/../../crescent-credentials_amd", "-Wl,-rpath-link," + rocm_lib, "-Wl,-rpath," + rocm_lib]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("integration/c/crescent_prove build failed:\n" + r.stderr[-4000:])
     return LIB
 
 

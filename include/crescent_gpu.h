@@ -96,10 +96,12 @@ typedef struct cg_options {
     int32_t reserved[2];
 } cg_options;
 
-/* By default cg_circuit_load moves the h query into the evaluation basis of the coset (one inverse DFT over its
- * G1 points, ~1 s at 2^21) so that a proof needs six transforms instead of seven: Σ h_i·H_i of prover.rs:63-66 is
- * computed as Σ q_j·H'_j over the quotient's coset values q_j — the same group element, hence the same proof bytes.
- * This flag keeps the query as loaded and runs the reference's seventh transform (r1cs_to_qap.rs:210) per proof. */
+/* By default cg_circuit_load moves the h query into the evaluation basis of the coset and folds the C matrix into
+ * the l query (two inverse DFTs over the h query's G1 points, ~1.6 s at 2^21), so that a proof needs four transforms
+ * instead of seven and no sparse product with C: Σ h_i·H_i of prover.rs:63-66 is computed as Σ q_j·H'_j over the coset
+ * values q_j = a·b/Z plus a per-wire term carried by the l query — the same group elements, hence the same proof bytes
+ * for any assignment.  This flag keeps both queries as loaded and runs the reference's seven transforms
+ * (r1cs_to_qap.rs:179-210) per proof. */
 enum { CG_FLAG_H_COEFFICIENT_BASIS = 1 };
 
 /* Per-phase wall/GPU times of one cg_prove call, mirroring the reference's `print-trace` phases
@@ -119,7 +121,7 @@ typedef struct cg_timings {
     /* HIP-event durations of the dominant kernels, summed over this proof's launches */
     float accum_g1_ms;     /* bucket-accumulation kernel (k_accum_affine<Fq>), the four G1 MSMs */
     float accum_g2_ms;     /* same kernel over Fq2 (the G2 MSM) */
-    float sort_ms;         /* radix sorts of the digit entries, all five MSMs */
+    float sort_ms;         /* grouping the digit entries by bucket (counting partition), all five MSMs */
     float reserved_ms;
     uint64_t entries_g1;   /* non-zero signed digits (= mixed additions) accumulated, G1 */
     uint64_t entries_g2;
@@ -162,8 +164,11 @@ int cg_prove(cg_ctx* ctx, const uint8_t* full_assignment, const uint8_t r[32], c
 int cg_prove_dev(cg_ctx* ctx, const void* d_full_assignment, const uint8_t r[32], const uint8_t s[32],
                  uint8_t proof_out[256], cg_timings* timings);
 
-/* Multi-GPU: a context loaded with shard_count > 1 owns a contiguous range of every
- * query.  cg_prove_partial computes this shard's five partial sums
+/* Multi-GPU: a context loaded with shard_count > 1 owns a contiguous range of the l, a and b
+ * queries and, of the h query, a contiguous range or — for a power-of-two shard_count — the coset points
+ * j = shard_rank (mod shard_count), which lets two of its four transforms run at 1/shard_count of the size.  Which
+ * points a shard owns is the library's business: the partial sums of all shards add up to the same five values.
+ * cg_prove_partial computes this shard's five partial sums
  *   out = h ‖ l ‖ a ‖ b1 (4 x 64 B G1 affine canonical) ‖ b2 (128 B G2 affine canonical) = 384 B
  * (identity = zeros; b1 is all-zero and skipped when r == 0, prover.rs:102-112).
  * cg_assemble adds the gathered partials of all shards and finishes A, B, C exactly as

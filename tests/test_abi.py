@@ -209,6 +209,32 @@ def _c_struct_fields(name):
     return out
 
 
+def test_header_is_strict_c_and_the_c_caller_links():
+    """include/crescent_gpu.h compiles as C11 with -pedantic -Werror (a C or cgo/bindgen consumer sees no C++), and
+    integration/c/crescent_prove - the reference's create_client_state as a plain C program - is built by build() and
+    reaches its argument check without a GPU."""
+    import subprocess
+    import tempfile
+    inc = os.path.join(ROOT, "include")
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.c")
+        with open(src, "w") as f:
+            f.write('#include <crescent_gpu.h>\nint main(void) { cg_options o; cg_timings t; (void)o; (void)t; return sizeof(cg_proving_key) ? 0 : 1; }\n')
+        r = subprocess.run(["gcc", "-std=c11", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", inc, src],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    exe = os.path.join(ROOT, "integration", "c", "crescent_prove")
+    assert os.path.exists(exe), "integration/c/crescent_prove missing: run __graft_entry__.build()"
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage:" in r.stderr
+    r = subprocess.run([exe, "a", "b", "c", "d", "--rs", "zz", "1"], capture_output=True, text=True)
+    assert r.returncode == 2 and "--rs" in r.stderr
+    # r >= the scalar modulus is refused (r, s cross the ABI as canonical integers)
+    r = subprocess.run([exe, "a", "b", "c", "d", "--rs", "30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001", "1"],
+                       capture_output=True, text=True)
+    assert r.returncode == 2
+
+
 def test_rust_shim_bindings_match_header():
     """integration/rust/crescent-gpu/src/sys.rs (compile-untested: no Rust toolchain here) declares only functions the
     header declares, and its repr(C) structs list the header's fields in the header's order."""

@@ -90,6 +90,47 @@ def test_files_to_verified_client_state(cc, oracle, af, cache_dir):
     assert io.get_public_key_indices() == [4, 5]
 
 
+def test_compiled_c_caller_from_files_to_client_state(cc, oracle, af, cache_dir, tmp_path):
+    """integration/c/crescent_prove: `create_client_state` as a plain C program over include/crescent_gpu.h (no Python or
+    torch in the process).  Files in, client_state.bin out; the oracle's reader verifies it with the prepared key, and
+    the proof bytes equal the C restatement's for the same (r, s)."""
+    import subprocess
+    from conftest import ROOT
+    import os
+    exe = os.path.join(ROOT, "integration", "c", "crescent_prove")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    l, m, M = cache_dir["shape"]
+    (tmp_path / "main_c.r1cs").write_bytes(cache_dir["r1cs"])
+    (tmp_path / "prover_params.bin").write_bytes(cache_dir["pp"])
+    (tmp_path / "witness.bin").write_bytes(cache_dir["w"].tobytes())
+    r, s = 0x1234567890abcdef1234567890abcdef1234567890abcdef1234567890abcdef % oracle.R, 0x0fedcba9876543210fedcba987654321
+    aux = '{"kid": "k1"}'
+    cmd = [exe, str(tmp_path / "main_c.r1cs"), str(tmp_path / "prover_params.bin"), str(tmp_path / "witness.bin"),
+           str(tmp_path / "client_state.bin"), "--rs", "%x" % r, "0x%064X" % s, "--credtype", "mdl", "--aux", aux]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr
+    blob = (tmp_path / "client_state.bin").read_bytes()
+    parsed = af.client_state_from_bytes(blob)
+    wi = [int.from_bytes(cache_dir["w"][32 * i:32 * i + 32].tobytes(), "little") for i in range(M)]
+    assert parsed["inputs"] == wi[1:l] and parsed["credtype"] == "mdl" and parsed["aux"] == aux
+    assert parsed["config_str"] == cache_dir["config"] and parsed["vk"] == cache_dir["ovk"] and parsed["pvk"] == cache_dir["pvk"]
+    assert af.verify_with_processed_vk(parsed["pvk"], parsed["inputs"], parsed["proof"])
+    import cpu_ref
+    cm = cache_dir["cm"]
+    want = cpu_ref.prove(cache_dir["pk"], (cm.a, cm.b, cm.c), l, m, M, cache_dir["w"], r, s, nthreads=8)
+    assert cc.ClientState.from_bytes(blob).proof.data == want
+    # without --rs the randomness comes from /dev/urandom: another proof of the same statement, which verifies too
+    run = subprocess.run(cmd[:5], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr
+    p2 = af.client_state_from_bytes((tmp_path / "client_state.bin").read_bytes())
+    assert p2["proof"] != parsed["proof"] and p2["aux"] is None and p2["credtype"] == "jwt"
+    assert af.verify_with_processed_vk(p2["pvk"], p2["inputs"], p2["proof"])
+    # a witness of the wrong length is refused before the GPU is asked to do anything with it
+    (tmp_path / "witness.bin").write_bytes(cache_dir["w"].tobytes()[:-32])
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert run.returncode != 0 and "wires" in run.stderr
+
+
 def test_groth16_prove_call_shape_and_cache(cc, oracle, af, cache_dir):
     """lib.rs:76-82 `Groth16::prove(pk, circuit, rng)`; prover.rs:160-173 no-zk; AssignmentMissing without a witness"""
     l, m, M = cache_dir["shape"]
