@@ -367,8 +367,9 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
             for (auto& e : sl->ev_t) CG_HIP(hipEventCreate(&e));
             // a shard of one proof, or a context that proves one proof at a time, is a latency job; several proofs in
             // flight are a throughput job
-            sl->eh.latency_mode = sl->el.latency_mode = sl->ea.latency_mode = sl->eb1.latency_mode = sl->eb2.latency_mode =
-                c->shard_count > 1 || n_slots == 1;
+            bool latency = c->shard_count > 1 || n_slots == 1;
+            if (const char* e = getenv("CG_LATENCY_MODE")) latency = e[0] == '1';    // profiling aid: force either segment length
+            sl->eh.latency_mode = sl->el.latency_mode = sl->ea.latency_mode = sl->eb1.latency_mode = sl->eb2.latency_mode = latency;
             sl->eh.init(&c->bh); sl->el.init(&c->bl); sl->ea.init(&c->ba); sl->eb1.init(&c->bb1); sl->eb2.init(&c->bb2);
             sl->w_canon.alloc(M); sl->h_canon.alloc(D);
             sl->wm.alloc(M, D, std::max(c->A.sell_scratch, std::max(c->B.sell_scratch, c->C.sell_scratch)));

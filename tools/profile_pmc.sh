@@ -7,6 +7,7 @@ OUT="$ROOT/$1"; KEY="$2"; shift; shift
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 export CG_SERIAL_STREAMS=1
+export CG_LATENCY_MODE=0   # the segment length of the pipelined run (a one-slot context would pick the latency setting)
 cd /tmp
 FLAGS="--steps 6 --warmup 2 --no-sweep --no-cpu-baseline --inflight 1 $*"
 for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do

@@ -8,6 +8,7 @@ OUT="$ROOT/$1"; shift
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 export CG_SERIAL_STREAMS=1
+export CG_LATENCY_MODE=0   # the segment length of the pipelined run (a one-slot context would pick the latency setting)
 cd /tmp
 FLAGS="--steps 8 --warmup 2 --no-sweep --no-cpu-baseline --inflight 1 $*"
 rocprofv3 --kernel-trace -d "$OUT/trace" -o t -- python3 "$ROOT/bench.py" $FLAGS > "$OUT/trace_line.json" 2> "$OUT/trace.log"
