@@ -65,6 +65,27 @@ CG_HD Affine29<F> load_table_point(const uint32_t* __restrict__ table, uint32_t 
     return a;
 }
 
+// The bucket accumulation's form: a negated y is left as 2N − y limb-wise (limbs below 2^30, value below 2N).  Its only
+// uses in madd29 are one product against a normalised operand (2^30·2^29 stays inside the column bound) and the
+// start of a run, which normalises it; the eight-step carry chain per entry is saved.  Fq only: an Fq2 product wants
+// its smaller operand normalised (field29.hpp).
+CG_HD Affine29<Fq29> load_table_point_lazy_y(const uint32_t* __restrict__ table, uint32_t idx, bool negate) {
+    constexpr int AFF = Words29<Fq29>::AFF;
+    const uint4* p = reinterpret_cast<const uint4*>(table + (size_t)idx * AFF);
+    uint32_t w[AFF];
+#pragma unroll
+    for (int i = 0; i < AFF / 4; ++i) {
+        uint4 v = p[i];
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+    Affine29<Fq29> a;
+    load_coord(a.x, w);
+    load_coord(a.y, w + AFF / 2);
+    Fq29 ny = sub<2, 1>(Fq29::zero(), a.y);
+    if (negate) a.y = ny;
+    return a;
+}
+
 // the same in two steps, so that the (random, HBM-latency) read can be issued an iteration early
 template <class F>
 struct RawPoint29 {
@@ -168,6 +189,11 @@ CG_HD Fq29 mul_sub(const Fq29& a, const Fq29& b, const Fq29& c, const Fq29& d) {
 CG_HD Fq2_29 mul_sub(const Fq2_29& a, const Fq2_29& b, const Fq2_29& c, const Fq2_29& d) {
     return normalize(sub<K1, 1>(mul(a, b), mul(c, d)));
 }
+// the first operand of mul_sub as it may be handed over: Fq's dual product takes limbs up to 3·2^29 against a
+// normalised partner (9·(3 + 2)·2^58 stays below 2^64, tools/bounds29.py), so the carry chain is skipped; an Fq2
+// product wants normalised operands
+CG_HD Fq29 for_mul_sub(const Fq29& a) { return a; }
+CG_HD Fq2_29 for_mul_sub(const Fq2_29& a) { return normalize(a); }
 
 // acc += p (p affine, never the identity)          (madd-2008-s)
 // Statement order keeps at most seven field values live (an Fq2 value is 18 VGPRs).
@@ -175,7 +201,7 @@ CG_HD Fq2_29 mul_sub(const Fq2_29& a, const Fq2_29& b, const Fq2_29& c, const Fq
 template <class F>
 CG_HD void madd29(XYZZ29<F>& acc, bool& inf, const Affine29<F>& p) {
     if (inf) {
-        acc.x = p.x; acc.y = p.y; acc.zz = F::one(); acc.zzz = F::one();
+        acc.x = p.x; acc.y = normalize(p.y); acc.zz = F::one(); acc.zzz = F::one();   // p.y may be a lazy 2N − y
         inf = false;
         return;
     }
@@ -193,7 +219,7 @@ CG_HD void madd29(XYZZ29<F>& acc, bool& inf, const Affine29<F>& p) {
     F R = normalize(sub<KY, 1>(mul(acc.zzz, p.y), acc.y));      // S2 - Y1
     F ZZZ3 = mul(acc.zzz, PPP);
     F X3 = normalize(sub<K2, 2>(sub<K1, 1>(sqr(R), PPP), dbl(Q)));
-    F d = normalize(sub<KX, 1>(Q, X3));
+    F d = for_mul_sub(sub<KX, 1>(Q, X3));
     acc.y = mul_sub(d, R, acc.y, PPP);                          // R·(Q − X3) − Y1·PPP
     acc.x = X3;
     acc.zz = ZZ3;

@@ -134,6 +134,18 @@ CG_HD F29<P> normalize(const F29<P>& a) {
     return r;
 }
 
+// CG_PIN(c): makes the running column sum an opaque value at that point (an llvm.annotation call, which the code
+// generator lowers to its argument: no instruction, no register constraint).  Without it LLVM's reassociation sorts the
+// terms of a column by rank, which puts the shifted carry of the previous column LAST: every column then starts a fresh
+// accumulator at zero and pays one 64-bit addition (v_lshl_add_u64) to bring the carry in - 21 of the 228 instructions
+// of a product.  Pinned, the carry is the addend of the column's first v_mad_u64_u32 and a product is 207 instructions.
+// (An empty inline asm pins just as well but makes the hazard recogniser put a wait state after every pin.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CG_NO_PIN)   // CG_NO_PIN: A/B aid
+#define CG_PIN(c) c = __builtin_annotation(c, "pin")
+#else
+#define CG_PIN(c) ((void)0)
+#endif
+
 // Montgomery product, product scanning with the reduction interleaved.  One 64-bit accumulator.
 // The cores below are always inlined; `mul`/`sqr`/`mul2` wrap them either inline or as real calls (see the end
 // of this block).
@@ -145,9 +157,9 @@ CG_HD F29<P> mul_core(const F29<P>& a, const F29<P>& b) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
 #pragma unroll
-        for (int i = 0; i <= k; ++i) c += (uint64_t)a.l[i] * b.l[k - i];
+        for (int i = 0; i <= k; ++i) { c += (uint64_t)a.l[i] * b.l[k - i]; CG_PIN(c); }
 #pragma unroll
-        for (int i = 0; i < k; ++i) c += (uint64_t)m[i] * P::N[k - i];
+        for (int i = 0; i < k; ++i) { c += (uint64_t)m[i] * P::N[k - i]; CG_PIN(c); }
         m[k] = ((uint32_t)c * P::NINV) & M29;
         c += (uint64_t)m[k] * P::N[0];
         c >>= 29;
@@ -156,8 +168,8 @@ CG_HD F29<P> mul_core(const F29<P>& a, const F29<P>& b) {
     for (int k = 9; k < 17; ++k) {
 #pragma unroll
         for (int i = k - 8; i <= 8; ++i) {
-            c += (uint64_t)a.l[i] * b.l[k - i];
-            c += (uint64_t)m[i] * P::N[k - i];
+            c += (uint64_t)a.l[i] * b.l[k - i]; CG_PIN(c);
+            c += (uint64_t)m[i] * P::N[k - i]; CG_PIN(c);
         }
         r.l[k - 9] = (uint32_t)c & M29;
         c >>= 29;
@@ -176,10 +188,10 @@ CG_HD F29<P> sqr_core(const F29<P>& a) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
 #pragma unroll
-        for (int i = 0; 2 * i < k; ++i) c += (uint64_t)d[i] * a.l[k - i];
-        if ((k & 1) == 0) c += (uint64_t)a.l[k / 2] * a.l[k / 2];
+        for (int i = 0; 2 * i < k; ++i) { c += (uint64_t)d[i] * a.l[k - i]; CG_PIN(c); }
+        if ((k & 1) == 0) { c += (uint64_t)a.l[k / 2] * a.l[k / 2]; CG_PIN(c); }
 #pragma unroll
-        for (int i = 0; i < k; ++i) c += (uint64_t)m[i] * P::N[k - i];
+        for (int i = 0; i < k; ++i) { c += (uint64_t)m[i] * P::N[k - i]; CG_PIN(c); }
         m[k] = ((uint32_t)c * P::NINV) & M29;
         c += (uint64_t)m[k] * P::N[0];
         c >>= 29;
@@ -187,10 +199,10 @@ CG_HD F29<P> sqr_core(const F29<P>& a) {
 #pragma unroll
     for (int k = 9; k < 17; ++k) {
 #pragma unroll
-        for (int i = k - 8; 2 * i < k; ++i) c += (uint64_t)d[i] * a.l[k - i];
-        if ((k & 1) == 0) c += (uint64_t)a.l[k / 2] * a.l[k / 2];
+        for (int i = k - 8; 2 * i < k; ++i) { c += (uint64_t)d[i] * a.l[k - i]; CG_PIN(c); }
+        if ((k & 1) == 0) { c += (uint64_t)a.l[k / 2] * a.l[k / 2]; CG_PIN(c); }
 #pragma unroll
-        for (int i = k - 8; i <= 8; ++i) c += (uint64_t)m[i] * P::N[k - i];
+        for (int i = k - 8; i <= 8; ++i) { c += (uint64_t)m[i] * P::N[k - i]; CG_PIN(c); }
         r.l[k - 9] = (uint32_t)c & M29;
         c >>= 29;
     }
@@ -239,6 +251,11 @@ CG_HD bool is_zero_mod(const F29<P>& a) {
     }
     return z == 0 || e == 0;
 }
+
+// one-limb filter in front of is_zero_mod (same precondition): false for all but 2^-28 of the non-zero values, so the
+// hot loops pay two compares instead of twenty-seven logic operations per test
+template <class P>
+CG_HD bool maybe_zero_mod(const F29<P>& a) { return a.l[0] == 0u || a.l[0] == P::N[0]; }
 
 // 8 x u32 (a 256-bit little-endian integer < 2^256) <-> nine 29-bit limbs
 template <class P>
@@ -319,11 +336,11 @@ CG_HD Fq29 mul2_core(const Fq29& x0, const Fq29& y0, const Fq29& x1, const Fq29&
     for (int k = 0; k < 9; ++k) {
 #pragma unroll
         for (int i = 0; i <= k; ++i) {
-            c += (uint64_t)x0.l[i] * y0.l[k - i];
-            c += (uint64_t)x1.l[i] * y1.l[k - i];
+            c += (uint64_t)x0.l[i] * y0.l[k - i]; CG_PIN(c);
+            c += (uint64_t)x1.l[i] * y1.l[k - i]; CG_PIN(c);
         }
 #pragma unroll
-        for (int i = 0; i < k; ++i) c += (uint64_t)m[i] * P::N[k - i];
+        for (int i = 0; i < k; ++i) { c += (uint64_t)m[i] * P::N[k - i]; CG_PIN(c); }
         m[k] = ((uint32_t)c * P::NINV) & M29;
         c += (uint64_t)m[k] * P::N[0];
         c >>= 29;
@@ -332,9 +349,9 @@ CG_HD Fq29 mul2_core(const Fq29& x0, const Fq29& y0, const Fq29& x1, const Fq29&
     for (int k = 9; k < 17; ++k) {
 #pragma unroll
         for (int i = k - 8; i <= 8; ++i) {
-            c += (uint64_t)x0.l[i] * y0.l[k - i];
-            c += (uint64_t)x1.l[i] * y1.l[k - i];
-            c += (uint64_t)m[i] * P::N[k - i];
+            c += (uint64_t)x0.l[i] * y0.l[k - i]; CG_PIN(c);
+            c += (uint64_t)x1.l[i] * y1.l[k - i]; CG_PIN(c);
+            c += (uint64_t)m[i] * P::N[k - i]; CG_PIN(c);
         }
         r.l[k - 9] = (uint32_t)c & M29;
         c >>= 29;
@@ -355,5 +372,6 @@ CG_HD Fq2_29 sqr(const Fq2_29& a) {
 }
 CG_HD Fq2_29 canonical(const Fq2_29& a) { return {canonical(a.c0), canonical(a.c1)}; }
 CG_HD bool is_zero_mod(const Fq2_29& a) { return is_zero_mod(a.c0) && is_zero_mod(a.c1); }
+CG_HD bool maybe_zero_mod(const Fq2_29& a) { return maybe_zero_mod(a.c0) && maybe_zero_mod(a.c1); }
 
 }  // namespace cg

@@ -547,7 +547,7 @@ __global__ void __launch_bounds__(256) k_accum_affine(const uint64_t* __restrict
             inf = true;
             cur = key;
         }
-        Affine29<F29T> p = load_table_point<F29T>(table, v & 0x7fffffffu, (v >> 31) != 0);
+        Affine29<F29T> p = load_table_point_lazy_y(table, v & 0x7fffffffu, (v >> 31) != 0);
         madd29(acc, inf, p);
     }
     if (final_level) {
@@ -617,7 +617,7 @@ __device__ __forceinline__ void madd29_lds(uint32_t* sl, bool& inf, const uint32
     F P = normalize(sub<KX, 1>(mul(zz, px), x1));
     F PP = sqr(P);
     F ZZ3 = mul(zz, PP);
-    if (is_zero_mod(ZZ3)) {                      // same x: doubling or cancellation (rare)
+    if (maybe_zero_mod(ZZ3) && is_zero_mod(ZZ3)) {   // same x: doubling or cancellation (rare)
         const F py = load_table_coord2(table, idx, 1, negate);
         F R0 = normalize(sub<KY, 1>(mul(lacc_ld(sl, 3), py), lacc_ld(sl, 1)));
         if (is_zero_mod(canonical(R0))) {

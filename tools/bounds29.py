@@ -118,7 +118,9 @@ class Fq2:
 def madd(F, inv, k):
     X1, Y1, ZZ1, ZZZ1 = (B(inv["x"], 1.0), B(inv["y"], 1.0), B(inv["z"], 1.0), B(inv["z"], 1.0))
     X2 = B(1.0, 1.0)
-    Y2 = F.norm(F.sub(B(0.0, 0.0), B(1.0, 1.0), 2, 1))     # table y, possibly negated: 2N - y, normalised
+    Y2 = F.sub(B(0.0, 0.0), B(1.0, 1.0), 2, 1)             # table y, possibly negated: 2N - y ...
+    if F is not Fq:
+        Y2 = F.norm(Y2)                                    # ... left lazy over Fq (load_table_point_lazy_y), normalised over Fq2
     U2 = F.mul(X2, ZZ1)
     S2 = F.mul(Y2, ZZZ1)
     P = F.norm(F.sub(U2, X1, k["KX"], 1))
@@ -129,11 +131,11 @@ def madd(F, inv, k):
     RR = F.sqr(R)
     t = F.sub(RR, PPP, k["K1"], 1)
     X3 = F.norm(F.sub(t, F.dbl(Q), k["K2"], 2))
-    d = F.norm(F.sub(Q, X3, k["KX"], 1))
+    d = F.sub(Q, X3, k["KX"], 1)
     if F is Fq:
-        Y3 = Fq.mul_sub(d, R, Y1, PPP, k["KY"])
+        Y3 = Fq.mul_sub(d, R, Y1, PPP, k["KY"])                # d stays lazy (for_mul_sub): limbs up to 3·2^29
     else:
-        Y3 = F.norm(F.sub(F.mul(R, d), F.mul(Y1, PPP), k["K1"], 1))
+        Y3 = F.norm(F.sub(F.mul(R, F.norm(d)), F.mul(Y1, PPP), k["K1"], 1))
     ZZ3 = F.mul(ZZ1, PP)
     ZZZ3 = F.mul(ZZZ1, PPP)
     return X3, Y3, ZZ3, ZZZ3
