@@ -250,10 +250,9 @@ CG_HD void add29(XYZZ29<F>& acc, bool& inf, const XYZZ29<F>& q, bool qinf) {
     F S1 = mul(acc.y, q.zzz);
     F R = normalize(sub<K1, 1>(mul(q.y, acc.zzz), S1));         // S2 - S1
     F ZZZ3 = mul(mul(acc.zzz, q.zzz), PPP);
-    F T = mul(S1, PPP);
     F X3 = normalize(sub<K2, 2>(sub<K1, 1>(sqr(R), PPP), dbl(Q)));
-    F d = normalize(sub<KX, 1>(Q, X3));
-    acc.y = normalize(sub<K1, 1>(mul(d, R), T));
+    F d = for_mul_sub(sub<KX, 1>(Q, X3));
+    acc.y = mul_sub(d, R, S1, PPP);                             // R·(Q − X3) − S1·PPP (S1 a product: normalised, below 2N)
     acc.x = X3;
     acc.zz = ZZ3;
     acc.zzz = ZZZ3;

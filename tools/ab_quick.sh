@@ -1,0 +1,4 @@
+# quick A/B on one box: parity tests, then the default headline measurement three times
+set -u
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_e2e_files.py -m gpu -x -q 2>&1 | tail -2
+for i in 1 2 3; do python bench.py --steps 80 --no-sweep --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench', d['value'], d['phase_ms']['accum_g1_ms'], d['phase_ms']['witness_map_ms'], d['phase_ms']['total_ms'])"; done

@@ -155,8 +155,11 @@ def add(F, inv, k):
     RR = F.sqr(R)
     t = F.sub(RR, PPP, k["K1"], 1)
     X3 = F.norm(F.sub(t, F.dbl(Q), k["K2"], 2))
-    d = F.norm(F.sub(Q, X3, k["KX"], 1))
-    Y3 = F.norm(F.sub(F.mul(R, d), F.mul(S1, PPP), k["K1"], 1))
+    d = F.sub(Q, X3, k["KX"], 1)
+    if F is Fq:
+        Y3 = Fq.mul_sub(d, R, S1, PPP, k["KY"])                # as in madd: one dual-product reduction, d lazy
+    else:
+        Y3 = F.norm(F.sub(F.mul(R, F.norm(d)), F.mul(S1, PPP), k["K1"], 1))
     ZZ3 = F.mul(F.mul(Z, Z), PP)
     ZZZ3 = F.mul(F.mul(Z, Z), PPP)
     return X3, Y3, ZZ3, ZZZ3
