@@ -895,6 +895,80 @@ __global__ void __launch_bounds__(256) k_bucket_rows_cols(const uint32_t* __rest
     }
 }
 
+// The same sums with no tree at all, for contexts that prove several proofs at a time (instruction count matters, depth
+// does not): a LANE adds up a chunk of RED_CHUNK consecutive buckets of one row, or of one column, serially, and a
+// second launch adds up the chunks of every row and column the same way.  2·nb + (nb / RED_CHUNK)·2 additions, every
+// lane of every wave busy, where the block-per-row scheme spends a third to a half of its additions in half-empty
+// tree levels (1.6 - 2.1 wave-additions per 64 buckets against 1.03 here).  Column lanes of a wave read adjacent
+// buckets; row lanes read RED_CHUNK buckets apart (the kernel is bound by the 3000-instruction additions, not by HBM).
+static constexpr uint32_t RED_CHUNK = 32;
+template <class F29T>
+__global__ void __launch_bounds__(64) k_bucket_chunks(const uint32_t* __restrict__ buckets, uint32_t R, uint32_t C,
+                                                      uint32_t* __restrict__ rowp, uint32_t* __restrict__ colp) {
+    constexpr int ACC = Words29<F29T>::ACC;
+    const uint32_t w = blockIdx.y;
+    const uint32_t KC = (C + RED_CHUNK - 1) / RED_CHUNK, KR = (R + RED_CHUNK - 1) / RED_CHUNK;
+    const uint32_t n_row = (R * KC + 63u) & ~63u;                 // a wave holds row lanes or column lanes, not both
+    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t* src = buckets + (size_t)w * R * C * ACC;
+    XYZZ29<F29T> acc;
+    bool inf = true;
+    if (t < n_row) {
+        if (t >= R * KC) return;
+        const uint32_t r = t / KC, k = t - r * KC;
+        const uint32_t c0 = k * RED_CHUNK, c1 = c0 + RED_CHUNK < C ? c0 + RED_CHUNK : C;
+        for (uint32_t col = c0; col < c1; ++col) {
+            XYZZ29<F29T> q;
+            bool qinf = load_acc(src + ((size_t)r * C + col) * ACC, q);
+            add29(acc, inf, q, qinf);
+        }
+        store_acc(rowp + ((size_t)w * R * KC + t) * ACC, acc, inf);
+    } else {
+        const uint32_t u = t - n_row;
+        if (u >= KR * C) return;
+        const uint32_t k = u / C, col = u - k * C;
+        const uint32_t r0 = k * RED_CHUNK, r1 = r0 + RED_CHUNK < R ? r0 + RED_CHUNK : R;
+        for (uint32_t r = r0; r < r1; ++r) {
+            XYZZ29<F29T> q;
+            bool qinf = load_acc(src + ((size_t)r * C + col) * ACC, q);
+            add29(acc, inf, q, qinf);
+        }
+        store_acc(colp + ((size_t)w * KR * C + u) * ACC, acc, inf);
+    }
+}
+// Row_r = Σ_k rowp[r][k] (KC chunks), Col_col = Σ_k colp[k][col] (KR chunks): one lane each
+template <class F29T>
+__global__ void __launch_bounds__(64) k_bucket_chunk_sums(const uint32_t* __restrict__ rowp, const uint32_t* __restrict__ colp, uint32_t R,
+                                                          uint32_t C, uint32_t* __restrict__ rows, uint32_t* __restrict__ cols) {
+    constexpr int ACC = Words29<F29T>::ACC;
+    const uint32_t w = blockIdx.y;
+    const uint32_t KC = (C + RED_CHUNK - 1) / RED_CHUNK, KR = (R + RED_CHUNK - 1) / RED_CHUNK;
+    const uint32_t n_row = (R + 63u) & ~63u;
+    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+    XYZZ29<F29T> acc;
+    bool inf = true;
+    if (t < n_row) {
+        if (t >= R) return;
+        const uint32_t* src = rowp + ((size_t)w * R + t) * KC * ACC;
+        for (uint32_t k = 0; k < KC; ++k) {
+            XYZZ29<F29T> q;
+            bool qinf = load_acc(src + (size_t)k * ACC, q);
+            add29(acc, inf, q, qinf);
+        }
+        store_acc(rows + ((size_t)w * R + t) * ACC, acc, inf);
+    } else {
+        const uint32_t col = t - n_row;
+        if (col >= C) return;
+        const uint32_t* src = colp + (size_t)w * KR * C * ACC;
+        for (uint32_t k = 0; k < KR; ++k) {
+            XYZZ29<F29T> q;
+            bool qinf = load_acc(src + ((size_t)k * C + col) * ACC, q);
+            add29(acc, inf, q, qinf);
+        }
+        store_acc(cols + ((size_t)w * C + col) * ACC, acc, inf);
+    }
+}
+
 // block b < rbits: Σ_{r: bit b of r} Row_r;  block rbits + k: Σ_{col: bit k of (col + 1)} Col_col;  blockIdx.y = window
 // `out` and `plan_out` are HOST memory (PinnedBuf::dev): the MSM's last kernel hands its few KB of per-bit sums and the
 // plan's statistics straight to the host.
@@ -986,6 +1060,10 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
         red_cbits1 = cbits + 1;                   // weights col + 1 <= C
         rows_buf.alloc((size_t)R * wins * ACC);
         cols_buf.alloc((size_t)C * wins * ACC);
+        if (!latency_mode) {     // chunk sums of the tree-free reduction
+            rowp_buf.alloc((size_t)R * ceil_div(C, RED_CHUNK) * wins * ACC);
+            colp_buf.alloc((size_t)ceil_div(R, RED_CHUNK) * C * wins * ACC);
+        }
     }
     h_plan.alloc(PLAN_WORDS);
     for (int k = 0; k < PLAN_WORDS; ++k) h_plan.p[k] = 0;
@@ -1106,8 +1184,18 @@ void MsmEngine<F>::enqueue_reduction(hipStream_t st) {
     const uint32_t nb = 1u << (bases->c - 1);
     const uint32_t C = 1u << red_cbits(bases->c), R = nb / C;
     const size_t lds = (size_t)256 * ACC * 4;
-    k_bucket_rows_cols<F29T><<<dim3(R + C, wins), 256, lds, st>>>(bucket_sums.p, R, C, rows_buf.p, cols_buf.p);
-    CG_KERNEL_CHECK();
+    static const bool force_tree = getenv("CG_RED_TREE") != nullptr;      // A/B aid
+    if (latency_mode || force_tree) {   // a block per row / column with an LDS tree: depth log, more additions
+        k_bucket_rows_cols<F29T><<<dim3(R + C, wins), 256, lds, st>>>(bucket_sums.p, R, C, rows_buf.p, cols_buf.p);
+        CG_KERNEL_CHECK();
+    } else {                     // a lane per chunk of 32 buckets, then a lane per row / column: fewest additions
+        const uint32_t KC = ceil_div(C, RED_CHUNK), KR = ceil_div(R, RED_CHUNK);
+        const uint32_t lanes_a = ((R * KC + 63u) & ~63u) + KR * C, lanes_b = ((R + 63u) & ~63u) + C;
+        k_bucket_chunks<F29T><<<dim3(ceil_div(lanes_a, 64), wins), 64, 0, st>>>(bucket_sums.p, R, C, rowp_buf.p, colp_buf.p);
+        CG_KERNEL_CHECK();
+        k_bucket_chunk_sums<F29T><<<dim3(ceil_div(lanes_b, 64), wins), 64, 0, st>>>(rowp_buf.p, colp_buf.p, R, C, rows_buf.p, cols_buf.p);
+        CG_KERNEL_CHECK();
+    }
     const uint32_t nbits = (uint32_t)(red_rbits + red_cbits1);
     k_bit_sums<F29T><<<dim3(nbits, wins), 256, lds, st>>>(rows_buf.p, R, (uint32_t)red_rbits, cols_buf.p, C, h_result.dev(), counters.p,
                                                           h_plan.dev());

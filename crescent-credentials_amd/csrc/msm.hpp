@@ -61,6 +61,7 @@ struct MsmEngine {
     DevBuf<uint32_t> part_keys_a, part_keys_b;
     DevBuf<uint32_t> part_pts_a, part_pts_b;
     DevBuf<uint32_t> rows_buf, cols_buf;   // row / column sums of the bucket matrix (bucket reduction)
+    DevBuf<uint32_t> rowp_buf, colp_buf;   // sums of 32-bucket chunks of the rows / columns (throughput contexts)
     int red_rbits = 0, red_cbits1 = 0;     // bits of the row weights r < R and of the column weights col + 1 <= C
     // host memory the reduction's last kernel writes directly:
     PinnedBuf<uint32_t> h_plan;       // the device plan of the last MSM: [0] entries, [3] scalars with a non-zero digit
