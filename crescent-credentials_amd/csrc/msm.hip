@@ -242,6 +242,37 @@ __device__ __forceinline__ void for_each_digit(const uint32_t s[8], int c, int W
     }
 }
 
+// The same walk with the window size known at compile time: every digit's limb index and shift are constants, so a digit
+// costs one funnel shift, the mask, the carry and the sign - no bit buffer, no refills, no dynamic limb selection (the
+// generic walk spends ~40 instructions per digit, most of them on those).  The walk still ends where the scalar does.
+template <int C, class Fn>
+__device__ __forceinline__ void for_each_digit_c(const uint32_t s[8], Fn f) {
+    constexpr int W = (SCALAR_BITS + C - 1) / C;
+    constexpr uint32_t mask = (1u << C) - 1u, half = 1u << (C - 1);
+    int hl = -1;
+    uint32_t top = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        hl = s[i] ? i : hl;
+        top = s[i] ? s[i] : top;
+    }
+    if (hl < 0) return;
+    const int topbit = hl * 32 + 31 - __clz((int)top);         // index of the scalar's highest set bit
+    uint32_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        const int bit = C * j, lo = bit >> 5, sh = bit & 31;
+        if (bit > topbit && carry == 0) break;                  // nothing left above this window
+        uint64_t v = lo < 8 ? s[lo] : 0u;
+        if (lo + 1 < 8) v |= (uint64_t)s[lo + 1] << 32;
+        const uint32_t raw = ((uint32_t)(v >> sh) & mask) + carry;
+        int32_t d;
+        if (raw > half) { d = (int32_t)raw - (int32_t)(1u << C); carry = 1; }
+        else { d = (int32_t)raw; carry = 0; }
+        f(j, d);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // grouping the digit entries by bucket: a two-level counting partition, no sort
 //
@@ -276,18 +307,22 @@ struct PartShape {
     int bits1, bits2;      // key bits taken by level 1 (high) and level 2 (low; 0 = single level)
 };
 
-template <class Fn>
+// C = the window size when the kernel was instantiated for it, 0 = taken from the shape at run time
+template <int C, class Fn>
 __device__ __forceinline__ void for_each_entry(const PartShape& sh, const Fr& s, uint32_t i, Fn f) {
     const uint32_t nb = 1u << (sh.c - 1);
-    for_each_digit(s.l, sh.c, sh.W, [&](int j, int32_t d) {
+    auto emit = [&](int j, int32_t d) {
         if (d == 0) return;
         const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
         const uint32_t sign = d < 0 ? 0x80000000u : 0u;
         if (sh.precomputed) f(mag - 1u, ((uint32_t)j * sh.row_stride + i) | sign);
         else f((uint32_t)j * nb + (mag - 1u), i | sign);
-    });
+    };
+    if constexpr (C > 0) for_each_digit_c<C>(s.l, emit);
+    else for_each_digit(s.l, sh.c, sh.W, emit);
 }
 
+template <int C>
 __global__ void __launch_bounds__(PART_THREADS) k_part_count(PartShape sh, const Fr* __restrict__ scalars, const uint8_t* __restrict__ valid,
                                                     uint32_t* __restrict__ blk_hist, uint32_t* __restrict__ hist1,
                                                     uint32_t* __restrict__ plan) {
@@ -310,7 +345,7 @@ __global__ void __launch_bounds__(PART_THREADS) k_part_count(PartShape sh, const
     for (int u = 0; u < PER; ++u) {
         if (!ok[u]) continue;
         bool any = false;
-        for_each_entry(sh, sc[u], base + u * PART_THREADS + threadIdx.x, [&](uint32_t key, uint32_t) {
+        for_each_entry<C>(sh, sc[u], base + u * PART_THREADS + threadIdx.x, [&](uint32_t key, uint32_t) {
             atomicAdd(&lds[key >> sh.bits2], 1u);
             any = true;
         });
@@ -386,6 +421,7 @@ __global__ void __launch_bounds__(1024) k_part_plan(int bits1, int two_level, co
     if (threadIdx.x == 0) { chunk0[B1] = chunks; plan[PLAN_CHUNKS] = chunks; }
 }
 
+template <int C>
 __global__ void __launch_bounds__(PART_THREADS) k_part_place(PartShape sh, const Fr* __restrict__ scalars, const uint8_t* __restrict__ valid,
                                                     const uint32_t* __restrict__ blk_hist, const uint32_t* __restrict__ start1,
                                                     uint32_t* __restrict__ cur1, uint64_t* __restrict__ out) {
@@ -410,11 +446,32 @@ __global__ void __launch_bounds__(PART_THREADS) k_part_place(PartShape sh, const
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
         if (!ok[u]) continue;
-        for_each_entry(sh, sc[u], base + u * PART_THREADS + threadIdx.x, [&](uint32_t key, uint32_t val) {
+        for_each_entry<C>(sh, sc[u], base + u * PART_THREADS + threadIdx.x, [&](uint32_t key, uint32_t val) {
             const uint32_t pos = atomicAdd(&lds[key >> sh.bits2], 1u);
             out[pos] = ((uint64_t)key << 32) | val;
         });
     }
+}
+
+// the two level-1 kernels, instantiated for the window sizes the prover meets (size-based defaults and re-tuned windows of
+// 10 .. 22 bits); any other window takes the run-time walk
+template <int C>
+static void launch_part_level1_c(bool count, const PartShape& sh, uint32_t tiles, size_t lds, hipStream_t st, const Fr* scalars,
+                                 const uint8_t* valid, uint32_t* blk_hist, uint32_t* hist1, uint32_t* plan, const uint32_t* start1,
+                                 uint32_t* cur1, uint64_t* out) {
+    if (count) k_part_count<C><<<tiles, PART_THREADS, lds, st>>>(sh, scalars, valid, blk_hist, hist1, plan);
+    else k_part_place<C><<<tiles, PART_THREADS, lds, st>>>(sh, scalars, valid, blk_hist, start1, cur1, out);
+}
+static void launch_part_level1(bool count, const PartShape& sh, uint32_t tiles, size_t lds, hipStream_t st, const Fr* scalars,
+                               const uint8_t* valid, uint32_t* blk_hist, uint32_t* hist1, uint32_t* plan, const uint32_t* start1,
+                               uint32_t* cur1, uint64_t* out) {
+#define CG_PART_CASE(C) case C: launch_part_level1_c<C>(count, sh, tiles, lds, st, scalars, valid, blk_hist, hist1, plan, start1, cur1, out); break;
+    switch (sh.c) {
+        CG_PART_CASE(10) CG_PART_CASE(11) CG_PART_CASE(12) CG_PART_CASE(13) CG_PART_CASE(14) CG_PART_CASE(15) CG_PART_CASE(16)
+        CG_PART_CASE(17) CG_PART_CASE(18) CG_PART_CASE(19) CG_PART_CASE(20) CG_PART_CASE(21) CG_PART_CASE(22)
+        default: launch_part_level1_c<0>(count, sh, tiles, lds, st, scalars, valid, blk_hist, hist1, plan, start1, cur1, out);
+    }
+#undef CG_PART_CASE
 }
 
 // the level-1 bin and the entry range of level-2 chunk `c`
@@ -1113,11 +1170,11 @@ void MsmEngine<F>::digits(const Fr* scalars_dev, uint64_t n, hipStream_t st) {
     const uint32_t tiles = ceil_div(n, PART_TILE);
     CG_HIP(hipEventRecord(ev_t[1], st));
     fill_zero(counters.p, (counters.bytes() + 15) & ~(size_t)15, st);
-    k_part_count<<<tiles, PART_THREADS, (size_t)B1 * 4, st>>>(sh, scalars_dev, bases->valid.p, blk_hist.p, hist1, plan);
+    launch_part_level1(true, sh, tiles, (size_t)B1 * 4, st, scalars_dev, bases->valid.p, blk_hist.p, hist1, plan, nullptr, nullptr, nullptr);
     CG_KERNEL_CHECK();
     k_part_plan<<<1, 1024, (size_t)B1 * 4, st>>>(bits1, bits2 ? 1 : 0, hist1, start1, chunk0, plan, ACC_TARGET_THREADS, min_L);
     CG_KERNEL_CHECK();
-    k_part_place<<<tiles, PART_THREADS, (size_t)B1 * 4, st>>>(sh, scalars_dev, bases->valid.p, blk_hist.p, start1, cur1, ent_a.p);
+    launch_part_level1(false, sh, tiles, (size_t)B1 * 4, st, scalars_dev, bases->valid.p, blk_hist.p, nullptr, nullptr, start1, cur1, ent_a.p);
     CG_KERNEL_CHECK();
     if (bits2) {
         const uint32_t B2 = 1u << bits2;

@@ -165,7 +165,9 @@ __global__ void __launch_bounds__(256) k_w_to29(const Fr* __restrict__ w, uint32
     Fr x = w[i];
     // the reference's scalars are field elements by type; across a C ABI they are bytes, so check (x < r)
     if (!fr_lt_modulus(x)) *bad_input = 1u;
-    store_packed29(out, i, from_canonical_bytes<Fr29P>(x));
+    // x·R' as the product leaves it: normalised and below 2N (x < 2^256, R'^2 mod N < N), which is all the packed form
+    // and the sparse product's lazy sums ask for; the canonical representative would cost a second product
+    store_packed29(out, i, mul(unpack29<Fr29P>(x.l), Fr29::from_limbs(Fr29P::R2)));
 }
 
 // out[rev(i)] = <M_i, w>, i < rows  (evaluate_constraint, r1cs_to_qap.rs:16-45); the output vector is the
@@ -191,7 +193,7 @@ __global__ void __launch_bounds__(256) k_sell29(const uint32_t* __restrict__ sli
         if ((++cnt & 3u) == 0) acc = normalize(acc);            // limbs stay below 5·2^29
     }
     const uint32_t d = dst[p];
-    const Fr29 r = canonical(normalize(acc));
+    const Fr29 r = weak_reduce(normalize(acc));     // below 3N: fits the packed form; nothing downstream needs the canonical value
     if (d & SELL_FINAL) store_packed29(out, brev(d & ~SELL_FINAL, logn), r);
     else store_packed29(scratch, d, r);
 }
