@@ -186,8 +186,14 @@ CG_HD XYZZ29<F> dbl29(const XYZZ29<F>& a) {
 CG_HD Fq29 mul_sub(const Fq29& a, const Fq29& b, const Fq29& c, const Fq29& d) {
     return mul2_core(a, b, sub<KY, 1>(Fq29::zero(), c), d);
 }
+// Over Fq2 each component is ONE reduction over four products:
+//   c0 = a0 b0 − a1 b1 − c0 d0 + c1 d1,   c1 = a0 b1 + a1 b0 − c0 d1 − c1 d0
+// with the subtracted factors negated limb-wise first (b: normalised, value < (FQ2_NEGK−1)·N; c: a stored Y, normalised,
+// value < (KY−1)·N).  All of a, b, c, d normalised: the four limb-bound products sum to 1 + 2 + 2 + 1 = 6 units.
 CG_HD Fq2_29 mul_sub(const Fq2_29& a, const Fq2_29& b, const Fq2_29& c, const Fq2_29& d) {
-    return normalize(sub<K1, 1>(mul(a, b), mul(c, d)));
+    const Fq29 nb1 = sub<FQ2_NEGK, 1>(Fq29::zero(), b.c1);
+    const Fq29 nc0 = sub<KY, 1>(Fq29::zero(), c.c0), nc1 = sub<KY, 1>(Fq29::zero(), c.c1);
+    return {mul4_core(a.c0, b.c0, a.c1, nb1, nc0, d.c0, c.c1, d.c1), mul4_core(a.c0, b.c1, a.c1, b.c0, nc0, d.c1, nc1, d.c0)};
 }
 // the first operand of mul_sub as it may be handed over: Fq's dual product takes limbs up to 3·2^29 against a
 // normalised partner (9·(3 + 2)·2^58 stays below 2^64, tools/bounds29.py), so the carry chain is skipped; an Fq2
@@ -206,7 +212,7 @@ CG_HD void madd29(XYZZ29<F>& acc, bool& inf, const Affine29<F>& p) {
         return;
     }
     F P = normalize(sub<KX, 1>(mul(acc.zz, p.x), acc.x));       // U2 - X1
-    F PP = sqr(P);
+    F PP = sqr_loose(P);
     F ZZ3 = mul(acc.zz, PP);
     if (is_zero_mod(ZZ3)) {                      // P ≡ 0: same x.  Rare (repeated base / s and r-s).
         F R0 = normalize(sub<KY, 1>(mul(acc.zzz, p.y), acc.y));
@@ -237,7 +243,7 @@ CG_HD void add29(XYZZ29<F>& acc, bool& inf, const XYZZ29<F>& q, bool qinf) {
     }
     F U1 = mul(acc.x, q.zz);
     F P = normalize(sub<K1, 1>(mul(q.x, acc.zz), U1));          // U2 - U1
-    F PP = sqr(P);
+    F PP = sqr_loose(P);
     F ZZ3 = mul(mul(acc.zz, q.zz), PP);
     if (is_zero_mod(ZZ3)) {
         F R0 = normalize(sub<K1, 1>(mul(q.y, acc.zzz), mul(acc.y, q.zzz)));

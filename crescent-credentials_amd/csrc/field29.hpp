@@ -360,6 +360,45 @@ CG_HD Fq29 mul2_core(const Fq29& x0, const Fq29& y0, const Fq29& x1, const Fq29&
     return r;
 }
 CG_HD Fq29 mul2(const Fq29& x0, const Fq29& y0, const Fq29& x1, const Fq29& y1) { return mul2_core(x0, y0, x1, y1); }
+// (x0 y0 + x1 y1 + x2 y2 + x3 y3) / R' mod N: four products per column term, one reduction.  Needs
+// 9·Σ Lxi·Lyi + 9·2^58 + carry < 2^64, i.e. Σ (limb bounds in units of 2^29) <= 6 (tools/bounds29.py).
+CG_HD Fq29 mul4_core(const Fq29& x0, const Fq29& y0, const Fq29& x1, const Fq29& y1, const Fq29& x2, const Fq29& y2, const Fq29& x3,
+                     const Fq29& y3) {
+    typedef Fq29P P;
+    uint64_t c = 0;
+    uint32_t m[9];
+    Fq29 r;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) {
+            c += (uint64_t)x0.l[i] * y0.l[k - i]; CG_PIN(c);
+            c += (uint64_t)x1.l[i] * y1.l[k - i]; CG_PIN(c);
+            c += (uint64_t)x2.l[i] * y2.l[k - i]; CG_PIN(c);
+            c += (uint64_t)x3.l[i] * y3.l[k - i]; CG_PIN(c);
+        }
+#pragma unroll
+        for (int i = 0; i < k; ++i) { c += (uint64_t)m[i] * P::N[k - i]; CG_PIN(c); }
+        m[k] = ((uint32_t)c * P::NINV) & M29;
+        c += (uint64_t)m[k] * P::N[0];
+        c >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; ++k) {
+#pragma unroll
+        for (int i = k - 8; i <= 8; ++i) {
+            c += (uint64_t)x0.l[i] * y0.l[k - i]; CG_PIN(c);
+            c += (uint64_t)x1.l[i] * y1.l[k - i]; CG_PIN(c);
+            c += (uint64_t)x2.l[i] * y2.l[k - i]; CG_PIN(c);
+            c += (uint64_t)x3.l[i] * y3.l[k - i]; CG_PIN(c);
+            c += (uint64_t)m[i] * P::N[k - i]; CG_PIN(c);
+        }
+        r.l[k - 9] = (uint32_t)c & M29;
+        c >>= 29;
+    }
+    r.l[8] = (uint32_t)c;
+    return r;
+}
 // b must be the operand that is normalised with value < (FQ2_NEGK-1) N; a may have limbs < 2^30.
 CG_HD Fq2_29 mul(const Fq2_29& a, const Fq2_29& b) {
     Fq29 nb1 = sub<FQ2_NEGK, 1>(Fq29::zero(), b.c1);          // K N - b1, limbs < 2^30
@@ -370,6 +409,14 @@ CG_HD Fq2_29 sqr(const Fq2_29& a) {
     Fq29 na1 = sub<FQ2_KS, 1>(Fq29::zero(), a.c1);
     return {mul2(a.c0, a.c0, a.c1, na1), mul(dbl(a.c0), a.c1)};
 }
+// The same value from two SINGLE products, c0 = (a0 + a1)·(a0 + KS·N - a1) (limbs 2·2^29 against 3·2^29: 54 of the 64
+// units of column headroom): 80 instructions fewer, but c0 comes out up to 2·V·(V + KS)/169 + 1 instead of
+// V·(V + KS)/169 + 1 - for squares that only feed further products (PP in the mixed addition), not sums.
+CG_HD Fq2_29 sqr_loose(const Fq2_29& a) {
+    return {mul(add(a.c0, a.c1), sub<FQ2_KS, 1>(a.c0, a.c1)), mul(dbl(a.c0), a.c1)};
+}
+template <class P>
+CG_HD F29<P> sqr_loose(const F29<P>& a) { return sqr_core(a); }
 CG_HD Fq2_29 canonical(const Fq2_29& a) { return {canonical(a.c0), canonical(a.c1)}; }
 CG_HD bool is_zero_mod(const Fq2_29& a) { return is_zero_mod(a.c0) && is_zero_mod(a.c1); }
 CG_HD bool maybe_zero_mod(const Fq2_29& a) { return maybe_zero_mod(a.c0) && maybe_zero_mod(a.c1); }

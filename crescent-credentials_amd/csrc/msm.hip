@@ -672,7 +672,7 @@ __device__ __forceinline__ void madd29_lds(uint32_t* sl, bool& inf, const uint32
     }
     const F zz = lacc_ld(sl, 2), x1 = lacc_ld(sl, 0);
     F P = normalize(sub<KX, 1>(mul(zz, px), x1));
-    F PP = sqr(P);
+    F PP = sqr_loose(P);
     F ZZ3 = mul(zz, PP);
     if (maybe_zero_mod(ZZ3) && is_zero_mod(ZZ3)) {   // same x: doubling or cancellation (rare)
         const F py = load_table_coord2(table, idx, 1, negate);
