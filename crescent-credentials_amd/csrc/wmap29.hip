@@ -263,13 +263,13 @@ template <int LOAD, int STORE>
 __global__ void __launch_bounds__(256) k_ntt29_pass(const uint32_t* __restrict__ in_a, const uint32_t* __restrict__ in_b,
                                                     const uint32_t* __restrict__ in_c, uint32_t* __restrict__ out,
                                                     const uint32_t* __restrict__ tw, const uint32_t* __restrict__ scale,
-                                                    Packed8 vinv_p, Pass29 pp, int store_bitrev, int in_limbs, int out_limbs) {
+                                                    Packed8 vinv_p, Pass29 pp, int store_bitrev) {
     __shared__ uint32_t sm[(1 << TS29) * 9 + (1 << TS29) / 16];
     const uint32_t tile = blockIdx.x;
     const uint32_t tsize = 1u << pp.ts;
     for (uint32_t e = threadIdx.x; e < tsize; e += 256) {
         uint32_t gi = l2g29(e, tile, pp);
-        Fr29 x = in_limbs ? load_tw(in_a, gi) : load_packed29(in_a, gi);     // between passes: nine limbs as they are
+        Fr29 x = load_packed29(in_a, gi);
         if (LOAD == 1) {
             Fr29 bb = load_packed29(in_b, gi), cc = load_packed29(in_c, gi);
             Fr29 vinv = unpack29<Fr29P>(vinv_p.w);
@@ -350,30 +350,21 @@ __global__ void __launch_bounds__(256) k_ntt29_pass(const uint32_t* __restrict__
         if (STORE == 1) y = cond_sub_n(mul(x, load_packed29(scale, gi)));
         else if (STORE == 2) y = cond_sub_n(mul(x, unpack29<Fr29P>(vinv_p.w)));   // one constant for every element
         else if (STORE == 3) y = cond_sub_n(mul(load_packed29(in_b, gi), x));     // x = b on the coset, in_b = vinv·a (plain)
-        else if (out_limbs) {       // not the last pass: the lazy value goes out as its nine (normalised) limbs, 48-byte record
-            uint4* p = reinterpret_cast<uint4*>(out + (uint64_t)gi * 12);
-            p[0] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
-            p[1] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
-            p[2] = make_uint4(x.l[8], 0u, 0u, 0u);
-            continue;
-        } else y = weak_reduce(x);
+        else y = weak_reduce(x);
         store_packed29(out, store_bitrev ? brev(gi, pp.logn) : gi, y);
     }
 }
 
 template <int LOAD, int STORE>
 static void launch_pass(uint32_t tiles, const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t* out, const uint32_t* tw,
-                        const uint32_t* scale, const Packed8& vinv, const Pass29& pp, int store_bitrev, int in_limbs, int out_limbs,
-                        hipStream_t st) {
-    k_ntt29_pass<LOAD, STORE><<<tiles, 256, 0, st>>>(a, b, c, out, tw, scale, vinv, pp, store_bitrev, in_limbs, out_limbs);
+                        const uint32_t* scale, const Packed8& vinv, const Pass29& pp, int store_bitrev, hipStream_t st) {
+    k_ntt29_pass<LOAD, STORE><<<tiles, 256, 0, st>>>(a, b, c, out, tw, scale, vinv, pp, store_bitrev);
     CG_KERNEL_CHECK();
 }
 
 // One DIT transform.  The first pass reads `in_a` (or the three pointwise operands) and writes `work`; middle
-// passes run in place on `work`; the last pass writes `dst`.  `work` holds n records of TWELVE words: between passes
-// a value travels as its nine limbs (a carry chain on the way out, nothing on the way in) instead of being reduced,
-// packed and unpacked again - 80 instructions per element and pass boundary.  A bit-reversing store permutes across
-// tiles, so it must not be in place: callers give dst != in_a for a single-pass transform in that case.
+// passes run in place on `work`; the last pass writes `dst`.  A bit-reversing store permutes across tiles, so
+// it must not be in place: callers give dst != work (and != in_a for a single-pass transform) in that case.
 static void dit29(const Wm29Domain& d, const uint32_t* tw, const uint32_t* in_a, const uint32_t* in_b, const uint32_t* in_c,
                   bool pointwise, uint32_t* work, uint32_t* dst, const uint32_t* scale, bool store_bitrev, hipStream_t st,
                   const uint32_t* const_scale = nullptr, const uint32_t* quot_a = nullptr) {
@@ -399,13 +390,12 @@ static void dit29(const Wm29Domain& d, const uint32_t* tw, const uint32_t* in_a,
         const bool pw = first && pointwise;
         const bool sc = last && scale != nullptr;
         const int sb = last && store_bitrev ? 1 : 0;
-        const int il = first ? 0 : 1, ol = last ? 0 : 1;      // limb records between passes, packed values at the ends
-        if (last && quot_a) launch_pass<0, 3>(tiles, a, quot_a, nullptr, o, tw, nullptr, vinv, plan[i], sb, il, ol, st);
-        else if (last && const_scale) launch_pass<0, 2>(tiles, a, nullptr, nullptr, o, tw, nullptr, vinv, plan[i], sb, il, ol, st);
-        else if (pw && sc) launch_pass<1, 1>(tiles, a, in_b, in_c, o, tw, scale, vinv, plan[i], sb, il, ol, st);
-        else if (pw) launch_pass<1, 0>(tiles, a, in_b, in_c, o, tw, scale, vinv, plan[i], sb, il, ol, st);
-        else if (sc) launch_pass<0, 1>(tiles, a, nullptr, nullptr, o, tw, scale, vinv, plan[i], sb, il, ol, st);
-        else launch_pass<0, 0>(tiles, a, nullptr, nullptr, o, tw, scale, vinv, plan[i], sb, il, ol, st);
+        if (last && quot_a) launch_pass<0, 3>(tiles, a, quot_a, nullptr, o, tw, nullptr, vinv, plan[i], sb, st);
+        else if (last && const_scale) launch_pass<0, 2>(tiles, a, nullptr, nullptr, o, tw, nullptr, vinv, plan[i], sb, st);
+        else if (pw && sc) launch_pass<1, 1>(tiles, a, in_b, in_c, o, tw, scale, vinv, plan[i], sb, st);
+        else if (pw) launch_pass<1, 0>(tiles, a, in_b, in_c, o, tw, scale, vinv, plan[i], sb, st);
+        else if (sc) launch_pass<0, 1>(tiles, a, nullptr, nullptr, o, tw, scale, vinv, plan[i], sb, st);
+        else launch_pass<0, 0>(tiles, a, nullptr, nullptr, o, tw, scale, vinv, plan[i], sb, st);
     }
 }
 
@@ -445,34 +435,34 @@ void wm29_run(const Wm29Domain& dom, const DevCsr& A, const DevCsr& B, const Dev
         const uint32_t d = (uint32_t)S.d;
         const int logd = S.sub.logn;
         const uint32_t terms = 1u << S.logs;
-        dit29(dom, dom.tw_inv.p, buf.va.p, nullptr, nullptr, false, buf.vw.p, buf.vt.p, nullptr, false, st);          // n·a_e, natural order
+        dit29(dom, dom.tw_inv.p, buf.va.p, nullptr, nullptr, false, buf.va.p, buf.vt.p, nullptr, false, st);          // n·a_e, natural order
         k_fold29<<<ceil_div(d, 256), 256, 0, st>>>(buf.vt.p, S.fold.p, buf.va.p, d, logd, terms);
         CG_KERNEL_CHECK();
-        dit29(S.sub, S.sub.tw_fwd.p, buf.va.p, nullptr, nullptr, false, buf.vw.p, buf.vc.p, nullptr, false, st, dom.vinv_plain);   // vinv·a, plain
-        dit29(dom, dom.tw_inv.p, buf.vb.p, nullptr, nullptr, false, buf.vw.p, buf.vt.p, nullptr, false, st);
+        dit29(S.sub, S.sub.tw_fwd.p, buf.va.p, nullptr, nullptr, false, buf.va.p, buf.vc.p, nullptr, false, st, dom.vinv_plain);   // vinv·a, plain
+        dit29(dom, dom.tw_inv.p, buf.vb.p, nullptr, nullptr, false, buf.vb.p, buf.vt.p, nullptr, false, st);
         k_fold29<<<ceil_div(d, 256), 256, 0, st>>>(buf.vt.p, S.fold.p, buf.vb.p, d, logd, terms);
         CG_KERNEL_CHECK();
-        dit29(S.sub, S.sub.tw_fwd.p, buf.vb.p, nullptr, nullptr, false, buf.vw.p, reinterpret_cast<uint32_t*>(h_out), nullptr, false, st, nullptr,
+        dit29(S.sub, S.sub.tw_fwd.p, buf.vb.p, nullptr, nullptr, false, buf.vb.p, reinterpret_cast<uint32_t*>(h_out), nullptr, false, st, nullptr,
               buf.vc.p);
         return;
     }
     if (coset_values) {
         // four transforms: q_j = vinv·a(gω^j)·b(gω^j), the scalars of the h MSM over the transformed h query
-        dit29(dom, dom.tw_inv.p, buf.va.p, nullptr, nullptr, false, buf.vw.p, buf.vt.p, dom.coset.p, true, st);
-        dit29(dom, dom.tw_fwd.p, buf.vt.p, nullptr, nullptr, false, buf.vw.p, buf.va.p, nullptr, false, st, dom.vinv_plain);   // vinv·a, plain
-        dit29(dom, dom.tw_inv.p, buf.vb.p, nullptr, nullptr, false, buf.vw.p, buf.vt.p, dom.coset.p, true, st);
-        dit29(dom, dom.tw_fwd.p, buf.vt.p, nullptr, nullptr, false, buf.vw.p, reinterpret_cast<uint32_t*>(h_out), nullptr, false, st, nullptr,
+        dit29(dom, dom.tw_inv.p, buf.va.p, nullptr, nullptr, false, buf.va.p, buf.vt.p, dom.coset.p, true, st);
+        dit29(dom, dom.tw_fwd.p, buf.vt.p, nullptr, nullptr, false, buf.vt.p, buf.va.p, nullptr, false, st, dom.vinv_plain);   // vinv·a, plain
+        dit29(dom, dom.tw_inv.p, buf.vb.p, nullptr, nullptr, false, buf.vb.p, buf.vt.p, dom.coset.p, true, st);
+        dit29(dom, dom.tw_fwd.p, buf.vt.p, nullptr, nullptr, false, buf.vt.p, reinterpret_cast<uint32_t*>(h_out), nullptr, false, st, nullptr,
               buf.va.p);
         return;
     }
     for (int k = 0; k < 3; ++k) {
         // ifft (bit-reversed in), then x g^i / n, stored bit-reversed for the next transform      :179-185,198-199
-        dit29(dom, dom.tw_inv.p, v[k], nullptr, nullptr, false, buf.vw.p, buf.vt.p, dom.coset.p, true, st);
+        dit29(dom, dom.tw_inv.p, v[k], nullptr, nullptr, false, v[k], buf.vt.p, dom.coset.p, true, st);
         // fft on the coset; stored bit-reversed so the pointwise load below feeds the last transform directly
-        dit29(dom, dom.tw_fwd.p, buf.vt.p, nullptr, nullptr, false, buf.vw.p, v[k], nullptr, true, st);
+        dit29(dom, dom.tw_fwd.p, buf.vt.p, nullptr, nullptr, false, buf.vt.p, v[k], nullptr, true, st);
     }
     // (a∘b - c)/Z(g) on load; coset ifft; x g^-i / n and out of Montgomery form on store           :187,201-210
-    dit29(dom, dom.tw_inv.p, buf.va.p, buf.vb.p, buf.vc.p, true, buf.vw.p, reinterpret_cast<uint32_t*>(h_out), dom.icoset.p, false, st);
+    dit29(dom, dom.tw_inv.p, buf.va.p, buf.vb.p, buf.vc.p, true, buf.va.p, reinterpret_cast<uint32_t*>(h_out), dom.icoset.p, false, st);
 }
 
 // ---- unit-level transform (cg_ntt_*): canonical natural-order data in place -----------------------------------------
@@ -501,7 +491,6 @@ void Ntt29Unit::build(int logn_, hipStream_t st) {
     k_to_packed29<<<ceil_div(n, 256), 256, 0, st>>>(g.p, gpow.p, n, 0, 0);
     CG_KERNEL_CHECK();
     work.alloc(n * 8);
-    work12.alloc(n * 12);
     h_bad_input.alloc(1);
     // plain 1 and plain 1/n as packed constants
     memset(one_plain, 0, 32);
@@ -516,9 +505,9 @@ bool Ntt29Unit::run(Fr* data_dev, bool inverse, bool coset, hipStream_t st) {
     k_unit_in29<<<ceil_div(n, 256), 256, 0, st>>>(data_dev, work.p, n, logn, (!inverse && coset) ? gpow.p : nullptr, h_bad_input.dev());
     CG_KERNEL_CHECK();
     uint32_t* out = reinterpret_cast<uint32_t*>(data_dev);
-    if (!inverse) dit29(dom, dom.tw_fwd.p, work.p, nullptr, nullptr, false, work12.p, out, nullptr, false, st, one_plain);
-    else if (!coset) dit29(dom, dom.tw_inv.p, work.p, nullptr, nullptr, false, work12.p, out, nullptr, false, st, ninv_plain);
-    else dit29(dom, dom.tw_inv.p, work.p, nullptr, nullptr, false, work12.p, out, dom.icoset.p, false, st);
+    if (!inverse) dit29(dom, dom.tw_fwd.p, work.p, nullptr, nullptr, false, work.p, out, nullptr, false, st, one_plain);
+    else if (!coset) dit29(dom, dom.tw_inv.p, work.p, nullptr, nullptr, false, work.p, out, nullptr, false, st, ninv_plain);
+    else dit29(dom, dom.tw_inv.p, work.p, nullptr, nullptr, false, work.p, out, dom.icoset.p, false, st);
     CG_HIP(hipStreamSynchronize(st));
     return h_bad_input.p[0] == 0;
 }

@@ -48,13 +48,12 @@ struct Csr29 {     // the matrices' coefficient dictionary in R' form (index arr
 struct Wm29Buffers {     // per proof slot
     DevBuf<uint32_t> w29;            // witness in R' form, M x 8 words
     DevBuf<uint32_t> va, vb, vc, vt; // D x 8 words each (vt: ping-pong partner of the bit-reversing stores)
-    DevBuf<uint32_t> vw;             // D x 12 words: a transform's values between its passes, nine limbs per 48-byte record
     DevBuf<uint32_t> sp_a, sp_b;     // partial sums of the sliced sparse product, levels alternating (sp_cap x 8 words)
     uint32_t sp_cap = 0;
     PinnedBuf<uint32_t> h_bad_input; // host memory; a kernel sets it to 1 when a witness element is not a canonical field element
     // sparse_scratch: the largest DevCsr::sell_scratch of the matrices this working set will serve
     void alloc(uint64_t M, uint64_t D, uint32_t sparse_scratch) {
-        w29.alloc(M * 8); va.alloc(D * 8); vb.alloc(D * 8); vc.alloc(D * 8); vt.alloc(D * 8); vw.alloc(D * 12);
+        w29.alloc(M * 8); va.alloc(D * 8); vb.alloc(D * 8); vc.alloc(D * 8); vt.alloc(D * 8);
         sp_cap = sparse_scratch;
         sp_a.alloc((size_t)(sparse_scratch ? sparse_scratch : 1) * 8); sp_b.alloc((size_t)(sparse_scratch ? sparse_scratch : 1) * 8);
         h_bad_input.alloc(1);
@@ -69,8 +68,7 @@ struct Ntt29Unit {
     uint64_t n = 0;
     Wm29Domain dom;
     DevBuf<uint32_t> gpow;       // g^i, R' form, natural index
-    DevBuf<uint32_t> work;       // n x 8 words: the input in R' form, bit-reversed
-    DevBuf<uint32_t> work12;     // n x 12 words: between passes
+    DevBuf<uint32_t> work;       // n x 8 words
     PinnedBuf<uint32_t> h_bad_input;
     uint32_t one_plain[8], ninv_plain[8];
     void build(int logn, hipStream_t st);
