@@ -77,8 +77,9 @@ def parse():
     ap.add_argument("--h-coefficient-basis", action="store_true",
                     help="keep the h query as loaded and run the seventh transform per proof (A/B against the default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for plumbing tests)")
-    ap.add_argument("--inflight", type=int, default=4,
-                    help="proofs in flight per GPU: host threads x context proof_slots")
+    ap.add_argument("--inflight", type=int, default=12,
+                    help="proofs in flight per GPU: host threads x context proof_slots (4: 169, 8: 173, 12: 174, 16: 176 proofs/s "
+                         "on one box, profiles/r02_j_inflight_and_tuning.txt)")
     ap.add_argument("--assignments", type=int, default=4, help="device-resident assignments the timed proofs rotate over")
     return ap.parse_args()
 

@@ -1,0 +1,8 @@
+# usage: tools/ab_args.sh REPS "args A" "args B" ...: the headline measurement with each argument set, round-robin on one box
+set -u
+N=$1; shift
+for i in $(seq $N); do
+  for a in "$@"; do
+    python bench.py --steps 100 --no-sweep --no-cpu-baseline $a 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('[$a]', d['value'])"
+  done
+done
