@@ -579,8 +579,13 @@ __device__ __forceinline__ void flush_run(uint32_t key, const XYZZ29<F29T>& acc,
     }
 }
 
+#if defined(CG_ACCUM_WAVES)      // A/B aid: force the occupancy target of the G1 accumulation (default: what 116 VGPRs give, 4)
+#define CG_ACCUM_ATTR __attribute__((amdgpu_waves_per_eu(CG_ACCUM_WAVES, CG_ACCUM_WAVES)))
+#else
+#define CG_ACCUM_ATTR
+#endif
 template <class F29T>
-__global__ void __launch_bounds__(256) k_accum_affine(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ plan,
+__global__ void __launch_bounds__(256) CG_ACCUM_ATTR k_accum_affine(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ plan,
                                                       const uint32_t* __restrict__ table,
                                                       uint32_t* __restrict__ bucket_sums, uint32_t* __restrict__ part_keys,
                                                       uint32_t* __restrict__ part_pts) {

@@ -1,0 +1,11 @@
+# usage: tools/ab_build.sh REPS "<extra hipcc flags>": the headline measurement with the default build and with the flagged build,
+# alternating on one box (the library is rebuilt in place between runs; the default build is restored at the end)
+set -u
+N=$1; FLAGS=$2
+export CG_BUILD_JOBS=16
+run() { python bench.py --steps 100 --no-sweep --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['value'])"; }
+for i in $(seq $N); do
+  python crescent-credentials_amd/build.py > /dev/null 2>&1; run default; run default
+  CG_HIPCC_EXTRA="$FLAGS" python crescent-credentials_amd/build.py > /dev/null 2>&1; run "[$FLAGS]"; run "[$FLAGS]"
+done
+python crescent-credentials_amd/build.py > /dev/null 2>&1
