@@ -158,6 +158,36 @@ def test_msm_large_closed_form(cc, oracle):
         assert cc.msm_bigint_g1(b1, _scalars(sc), window_bits=wb).hex() == exp
 
 
+@pytest.mark.parametrize("group", [1, 2])
+def test_msm_every_window_size(cc, oracle, group):
+    """Every window size 2 .. 22 - each instantiation of the per-window digit walk (10 .. 22), the run-time walk below it,
+    every shape of the bucket matrix (one row, fewer columns than a reduction chunk, 1024 columns) and both partition
+    depths - through the one-shot entry (window-major keys, one bucket matrix per window) and through a resident context
+    (shared buckets), against the closed form (Σ s_i k_i)·G.  Scalars: full width, 0, 1, r − 1 and short ones."""
+    rng = random.Random(2200 + group)
+    n = 700 if group == 1 else 300
+    ks = [rng.randrange(1, oracle.R) for _ in range(n)]
+    ks[3] = 0                                                               # an identity base
+    bases = (cc.fixed_base_g1 if group == 1 else cc.fixed_base_g2)(_scalars(ks))
+    one_shot = cc.msm_bigint_g1 if group == 1 else cc.msm_bigint_g2
+    curve, gen, packed = (oracle.G1, oracle.G1_GEN, oracle.g1_packed) if group == 1 else (oracle.G2, oracle.G2_GEN, oracle.g2_packed)
+    sc = [rng.choice([0, 1, oracle.R - 1, rng.randrange(1 << 20), rng.randrange(oracle.R), rng.randrange(oracle.R)]) for _ in range(n)]
+    e = sum(k * s for k, s in zip(ks, sc)) % oracle.R
+    exp = packed(curve.to_affine(curve.mul_affine(gen, e)))
+    for wb in range(2, 23):
+        if wb <= 21:
+            assert one_shot(bases, _scalars(sc), window_bits=wb) == exp, ("one-shot", group, wb)
+        else:   # window-major keys of 22-bit windows need 25 bits, one more than the two partition levels take: refused, not wrong
+            with pytest.raises(cc.CrescentGpuError):
+                one_shot(bases, _scalars(sc), window_bits=wb)
+        if wb % 3 == 2 or wb >= 20:                                          # resident tables: a subset (each builds 255 / wb rows)
+            ctx = cc.MsmContext(bases, group=group, window_bits=wb)
+            try:
+                assert ctx.run(_scalars(sc)) == exp, ("resident", group, wb)
+            finally:
+                ctx.close()
+
+
 # ------------------------------------------------------------------------------------------- resident-operand unit entry points
 @pytest.mark.parametrize("logn", [0, 1, 2, 3, 5, 9, 10, 11])
 def test_ntt_context_all_modes_vs_oracle(cc, oracle, logn):
