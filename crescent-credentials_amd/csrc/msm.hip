@@ -598,10 +598,21 @@ __global__ void __launch_bounds__(256) CG_ACCUM_ATTR k_accum_affine(const uint64
     uint32_t end = beg + L < N ? beg + L : N;
     XYZZ29<F29T> acc;
     bool inf = true;
+#if defined(CG_NO_ENTRY_PREFETCH)   // A/B aid
     uint32_t cur = (uint32_t)(entries[beg] >> 32);
     bool first = true;
     for (uint32_t k = beg; k < end; ++k) {
         const uint64_t ent = entries[k];
+#else
+    // the next entry is fetched an iteration ahead: the table gather, whose address it holds, can go out as soon as the
+    // iteration starts instead of after a first memory round trip
+    uint64_t next_ent = entries[beg];
+    uint32_t cur = (uint32_t)(next_ent >> 32);
+    bool first = true;
+    for (uint32_t k = beg; k < end; ++k) {
+        const uint64_t ent = next_ent;
+        if (k + 1 < end) next_ent = entries[k + 1];
+#endif
         const uint32_t key = (uint32_t)(ent >> 32), v = (uint32_t)ent;
         if (key != cur) {
             flush_run(cur, acc, inf, first, final_level, t, bucket_sums, part_keys, part_pts);
@@ -718,10 +729,12 @@ k_accum_affine_g2(const uint64_t* __restrict__ entries, const uint32_t* __restri
     uint32_t beg = t * L;
     uint32_t end = beg + L < N ? beg + L : N;
     bool inf = true;
-    uint32_t cur = (uint32_t)(entries[beg] >> 32);
+    uint64_t next_ent = entries[beg];                  // fetched an iteration ahead, as in k_accum_affine
+    uint32_t cur = (uint32_t)(next_ent >> 32);
     bool first = true;
     for (uint32_t k = beg; k < end; ++k) {
-        const uint64_t ent = entries[k];
+        const uint64_t ent = next_ent;
+        if (k + 1 < end) next_ent = entries[k + 1];
         const uint32_t key = (uint32_t)(ent >> 32), v = (uint32_t)ent;
         if (key != cur) {
             flush_run(cur, lacc_all(sl), inf, first, final_level, t, bucket_sums, part_keys, part_pts);
