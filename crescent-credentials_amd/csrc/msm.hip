@@ -598,18 +598,19 @@ __global__ void __launch_bounds__(256) CG_ACCUM_ATTR k_accum_affine(const uint64
     uint32_t end = beg + L < N ? beg + L : N;
     XYZZ29<F29T> acc;
     bool inf = true;
-#if defined(CG_NO_ENTRY_PREFETCH)   // A/B aid
-    uint32_t cur = (uint32_t)(entries[beg] >> 32);
-    bool first = true;
-    for (uint32_t k = beg; k < end; ++k) {
-        const uint64_t ent = entries[k];
-#else
     // the next entry is fetched an iteration ahead: the table gather, whose address it holds, can go out as soon as the
-    // iteration starts instead of after a first memory round trip
+    // iteration starts instead of after a first memory round trip (CG_NO_ENTRY_PREFETCH: A/B aid)
+#if defined(CG_NO_ENTRY_PREFETCH)
+    uint32_t cur = (uint32_t)(entries[beg] >> 32);
+#else
     uint64_t next_ent = entries[beg];
     uint32_t cur = (uint32_t)(next_ent >> 32);
+#endif
     bool first = true;
     for (uint32_t k = beg; k < end; ++k) {
+#if defined(CG_NO_ENTRY_PREFETCH)
+        const uint64_t ent = entries[k];
+#else
         const uint64_t ent = next_ent;
         if (k + 1 < end) next_ent = entries[k + 1];
 #endif
