@@ -517,6 +517,40 @@ def test_sharded_partials_assemble_to_same_proof(cc, oracle):
                 p.close()
 
 
+def test_concurrent_proofs_on_one_context_and_across_contexts(cc, oracle):
+    """SURVEY 8b threading: `create_client_state` runs concurrently from several tasks (sample/client_helper/src/main.rs:
+    177-216), so cg_prove must be re-entrant across contexts and overlap proofs within one.  Twelve host threads drive a
+    six-slot context and a two-slot context of another circuit at the same time - the first proofs race with the one-time
+    window re-tune, the entry grouping runs with concurrent atomics in another order every time - and every proof must
+    be byte-identical to the one a single-slot context makes alone (sums are exact, so order must not matter)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from crescent_credentials_amd import workloads as wl
+    rng = random.Random(31337)
+    circuits = []
+    for seed, (l, m, M), bits in ((1, (9, 30_000, 31_000), 0.9), (2, (5, 12_000, 12_500), 0.3)):
+        cm, w = wl.synthetic_circuit(seed, l, m, M, bits, 3, profile="gates")
+        pk = cc.generate_parameters_with_qap(cm, *(rng.randrange(1, oracle.R) for _ in range(4)))
+        ws = [w, _scalars([rng.randrange(oracle.R) for _ in range(M)])]           # the witness and an arbitrary assignment
+        jobs = [(ws[k % 2], rng.randrange(oracle.R) if k % 5 else 0, rng.randrange(oracle.R)) for k in range(10)]
+        alone = cc.Prover(pk, cm)
+        try:
+            expect = [alone.prove(*j).data for j in jobs]
+        finally:
+            alone.close()
+        circuits.append((pk, cm, jobs, expect))
+    provers = [cc.Prover(circuits[0][0], circuits[0][1], proof_slots=6), cc.Prover(circuits[1][0], circuits[1][1], proof_slots=2)]
+    try:
+        work = [(c, k) for rep in range(4) for c in (0, 1) for k in range(10)]
+        rng.shuffle(work)
+        with ThreadPoolExecutor(max_workers=12) as ex:
+            got = list(ex.map(lambda ck: provers[ck[0]].prove(*circuits[ck[0]][2][ck[1]]).data, work))
+        for (c, k), g in zip(work, got):
+            assert g == circuits[c][3][k], (c, k)
+    finally:
+        for p in provers:
+            p.close()
+
+
 @pytest.mark.parametrize("shape,nshard", [("log11", 2), ("log13", 4), ("log14", 8), ("medium", 8), ("log17", 16)])
 def test_strided_shards_assemble_to_same_proof(cc, oracle, shape, nshard):
     """A power-of-two shard count gives every shard the coset points j = rank (mod count) of the h MSM (two of its four
