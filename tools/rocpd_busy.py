@@ -4,8 +4,8 @@
 import re, sqlite3, sys
 db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 rows = cur.execute("select name, start, end from kernels order by start").fetchall()
-skip = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # ignore the first N ms (setup/load)
-t0 = rows[0][1] + skip * 1_000_000
+skip = int(sys.argv[2]) if len(sys.argv) > 2 else -1   # ignore the first N ms; default: everything up to the last window-table build
+t0 = rows[0][1] + skip * 1_000_000 if skip >= 0 else max([e for n, s, e in rows if "k_table_next" in n] + [rows[0][1]])
 rows = [(re.sub(r"\(.*", "", n).replace("void ", "")[:70], s, e) for n, s, e in rows if s >= t0]
 ev = []
 for i, (n, s, e) in enumerate(rows):

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Soak: N proofs of the full-size headline workload on a throughput context with T host threads, every one compared
+byte for byte with the proof a single-slot (latency) context made for the same (assignment, r, s).  Catches rare
+order-dependence in the grouping / accumulation under load.   usage: python tools/soak.py [N=4000] [T=12]"""
+import os, random, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from concurrent.futures import ThreadPoolExecutor
+import numpy as np, torch
+import crescent_credentials_amd as cc
+from crescent_credentials_amd import workloads as wl
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+assert cc.lib().cg_init(0, None) == 0
+R = cc.api.FR_MODULUS
+l, m, M = wl.SHAPES["rs256-sd"]
+cm, w = wl.synthetic_circuit(0xC5E5CE47 + 3, l, m, M, 0.9, 3, profile="gates")
+rng = random.Random(2024)
+pk = cc.generate_parameters_with_qap(cm, *[rng.randrange(1, R) for _ in range(4)])
+W = w.reshape(-1, 32)
+ws = [w]
+for seed in (1, 2, 3):
+    p = W.copy(); p[l:] = W[l:][np.random.default_rng(seed).permutation(M - l)]; ws.append(p.reshape(-1).copy())
+wd = [torch.from_numpy(x).cuda() for x in ws]
+jobs = [(k % 4, rng.randrange(R) if k % 7 else 0, rng.randrange(R)) for k in range(32)]
+alone = cc.Prover(pk, cm)
+expect = [alone.prove_dev(wd[a].data_ptr(), r, s).data for a, r, s in jobs]
+alone.close()
+prover = cc.Prover(pk, cm, proof_slots=T)
+order = [rng.randrange(32) for _ in range(N)]
+t0 = time.time()
+with ThreadPoolExecutor(max_workers=T) as ex:
+    got = list(ex.map(lambda j: prover.prove_dev(wd[jobs[j][0]].data_ptr(), jobs[j][1], jobs[j][2]).data, order))
+dt = time.time() - t0
+bad = sum(1 for j, g in zip(order, got) if g != expect[j])
+prover.close()
+print("soak: %d proofs, %d threads, %.1f s (%.1f proofs/s), mismatches: %d" % (N, T, dt, N / dt, bad))
+sys.exit(1 if bad else 0)
