@@ -1168,6 +1168,7 @@ template <class F>
 void MsmEngine<F>::digits(const Fr* scalars_dev, uint64_t n, hipStream_t st) {
     if (n > bases->n) n = bases->n;  // msm_bigint zips and truncates to the shorter operand
     n_scalars = n;
+    adopted = nullptr;
     for (int k = 0; k < PLAN_WORDS; ++k) h_plan.p[k] = 0;
     CG_HIP(hipEventRecord(ev_t[0], st));
     if (!n) {   // the reduction's last kernel copies the device plan to the host: leave it a zeroed one
@@ -1205,6 +1206,20 @@ void MsmEngine<F>::digits(const Fr* scalars_dev, uint64_t n, hipStream_t st) {
     CG_HIP(hipEventRecord(ev_t[2], st));
 }
 
+template <class F>
+void MsmEngine<F>::adopt(const uint64_t* grouped_entries, const uint32_t* plan_dev, uint64_t n, hipStream_t st) {
+    if (n > bases->n) n = bases->n;
+    n_scalars = n;
+    for (int k = 0; k < PLAN_WORDS; ++k) h_plan.p[k] = 0;
+    CG_HIP(hipEventRecord(ev_t[0], st));
+    CG_HIP(hipEventRecord(ev_t[1], st));
+    // the plan (entry count, segment geometry, statistics) travels with the entries; everything downstream reads it from
+    // this engine's own counters as usual
+    CG_HIP(hipMemcpyAsync(counters.p, plan_dev, PLAN_WORDS * 4, hipMemcpyDeviceToDevice, st));
+    CG_HIP(hipEventRecord(ev_t[2], st));
+    adopted = n ? grouped_entries : nullptr;
+}
+
 // phase 2: accumulate the grouped entries into the buckets, combine the segments, reduce the buckets; the per-bit sums
 // and the plan (entry count, statistics) are copied to pinned memory.  Nothing here waits for the host.
 template <class F>
@@ -1212,7 +1227,7 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
     fill_zero(bucket_sums.p, bucket_sums.bytes(), st);
     if (n_scalars) {
         const uint32_t* plan = counters.p;
-        const uint64_t* grouped = bits2 ? ent_b.p : ent_a.p;
+        const uint64_t* grouped = adopted ? adopted : (bits2 ? ent_b.p : ent_a.p);
         CG_HIP(hipEventRecord(ev_t[3], st));
         launch_accum_affine<F29T>(grouped, plan, max_segments, bases->table.p, bucket_sums.p, part_keys_a.p, part_pts_a.p, st);
         CG_KERNEL_CHECK();

@@ -84,6 +84,17 @@ struct MsmEngine {
     ~MsmEngine();
     // phase 1: signed-digit extraction of `n` canonical scalars -> (bucket, index) entries grouped by bucket
     void digits(const Fr* scalars_dev, uint64_t n, hipStream_t st);
+    // phase 1 taken over from another engine that grouped the SAME scalars against bases with the same identity pattern,
+    // window and count (the B query in G1 and in G2: b_i(τ)·G1 and b_i(τ)·G2 vanish together, generator.rs:162,168): its
+    // entry list IS this engine's.  `src`'s digits() must be enqueued on a stream `st` already waits for.
+    template <class G>
+    bool can_adopt(const MsmEngine<G>& src) const {
+        return bases->precomputed && src.bases->precomputed && bases->n == src.bases->n && bases->c == src.bases->c &&
+               bits1 == src.bits1 && bits2 == src.bits2;
+    }
+    void adopt(const uint64_t* grouped_entries, const uint32_t* plan_dev, uint64_t n, hipStream_t st);
+    const uint64_t* grouped() const { return bits2 ? ent_b.p : ent_a.p; }
+    const uint64_t* adopted = nullptr;    // non-null: the grouped entries of the engine adopted for the current MSM
     // phase 2: accumulate, combine, reduce; per-bit sums and the plan copied to pinned memory.  Neither phase waits
     // for the host.
     void accumulate(hipStream_t st);

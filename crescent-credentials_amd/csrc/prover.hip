@@ -132,11 +132,13 @@ struct ProofSlot {
     Wm29Buffers wm;
     hipStream_t st[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // 0: witness map + h, 1: l, 2: a, 3: b1, 4: b2
     hipEvent_t ev_w = nullptr;
+    hipEvent_t ev_b1 = nullptr;        // b1's entries are grouped (the G2 MSM adopts them)
     hipEvent_t ev_t[2] = {nullptr, nullptr};
     ~ProofSlot() {
         for (int i = 0; i < 5; ++i)
             if (st[i] && (i == 0 || st[i] != st[0])) (void)hipStreamDestroy(st[i]);
         if (ev_w) (void)hipEventDestroy(ev_w);
+        if (ev_b1) (void)hipEventDestroy(ev_b1);
         for (auto& e : ev_t) if (e) (void)hipEventDestroy(e);
     }
 };
@@ -170,6 +172,7 @@ struct cg_ctx {
     // window tuning: the window of each assignment-driven query is re-chosen once from the digit statistics of
     // the first proof (circom witnesses are mostly 0/1 wires, for which the size-based default is far too wide)
     bool fixed_window = false;
+    bool b_same_identities = false;   // b_g1_query and b_g2_query are the identity at the same indices (true for a generated key)
     std::atomic<bool> tuned{false};   // read outside tune_mu by every finished proof
     std::shared_mutex tune_mu;   // proofs hold it shared; a retune holds it exclusively
     std::mutex pick_mu;
@@ -341,6 +344,18 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         load_query<Fq>(c->ba, pk->a_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, s0);    // query[1..] (prover.rs:266)
         load_query<Fq>(c->bb1, pk->b_g1_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, s0);
         load_query<Fq2>(c->bb2, pk->b_g2_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, s0);
+        {   // the G2 MSM may take over b1's grouped entries only if the two queries vanish together (generator.rs:162,168
+            // makes them b_i(τ)·G1 and b_i(τ)·G2; a key from elsewhere is not trusted to)
+            const uint64_t nb = c->bb1.n;
+            c->b_same_identities = nb == c->bb2.n;
+            if (c->b_same_identities && nb) {
+                std::vector<uint8_t> v1(nb), v2(nb);
+                CG_HIP(hipMemcpyAsync(v1.data(), c->bb1.valid.p, nb, hipMemcpyDeviceToHost, s0));
+                CG_HIP(hipMemcpyAsync(v2.data(), c->bb2.valid.p, nb, hipMemcpyDeviceToHost, s0));
+                CG_HIP(hipStreamSynchronize(s0));
+                c->b_same_identities = v1 == v2;
+            }
+        }
         c->wdom.build(c->dom, s0);
         if (c->h_strided) c->wstr.build(c->dom, ilog2_ceil((uint64_t)c->shard_count), c->shard_rank, s0);
         c->dA.build(c->A, s0); c->dB.build(c->B, s0); c->dC.build(c->C, s0);
@@ -364,6 +379,7 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
                 else CG_HIP(hipStreamCreateWithFlags(&sl->st[i], hipStreamNonBlocking));
             }
             CG_HIP(hipEventCreateWithFlags(&sl->ev_w, hipEventDisableTiming));
+            CG_HIP(hipEventCreateWithFlags(&sl->ev_b1, hipEventDisableTiming));
             for (auto& e : sl->ev_t) CG_HIP(hipEventCreate(&e));
             // a shard of one proof, or a context that proves one proof at a time, is a latency job; several proofs in
             // flight are a throughput job
@@ -434,7 +450,16 @@ static int prove_partial_impl(cg_ctx* c, ProofSlot* S, const void* assignment, b
     S->el.digits(w_dev + (c->folded ? 0 : l) + c->rl.lo, c->rl.hi - c->rl.lo, S->st[1]);   // folded l query: one base per wire
     S->ea.digits(w_dev + 1 + c->ra.lo, c->ra.hi - c->ra.lo, S->st[2]);
     if (!skip_b1) S->eb1.digits(w_dev + 1 + c->ra.lo, c->ra.hi - c->ra.lo, S->st[3]);
-    S->eb2.digits(w_dev + 1 + c->ra.lo, c->ra.hi - c->ra.lo, S->st[4]);
+    // b1 and b2 take the same scalars against bases that vanish together: with equal windows the grouped entry list of
+    // one IS the other's, so the G2 MSM skips its own grouping (five launches, ~0.9 % of a proof's instructions)
+    static const bool no_share = getenv("CG_NO_SHARE_B") != nullptr;        // A/B aid
+    if (!skip_b1 && !no_share && c->b_same_identities && S->eb2.can_adopt(S->eb1) && c->ra.hi > c->ra.lo) {
+        CG_HIP(hipEventRecord(S->ev_b1, S->st[3]));
+        CG_HIP(hipStreamWaitEvent(S->st[4], S->ev_b1, 0));
+        S->eb2.adopt(S->eb1.grouped(), S->eb1.counters.p, c->ra.hi - c->ra.lo, S->st[4]);
+    } else {
+        S->eb2.digits(w_dev + 1 + c->ra.lo, c->ra.hi - c->ra.lo, S->st[4]);
+    }
     // witness map, then h digits, on stream 0
     if (tm) CG_HIP(hipEventRecord(S->ev_t[0], s0));
     run_witness_map(c, S, w_dev, s0, c->folded);   // h_canon: coefficients of h, or the coset values vinv·a·b for a folded key

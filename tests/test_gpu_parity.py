@@ -517,6 +517,36 @@ def test_sharded_partials_assemble_to_same_proof(cc, oracle):
                 p.close()
 
 
+def test_b_queries_share_their_grouping_only_when_they_vanish_together(cc, oracle):
+    """The G2 MSM of a proof takes over the grouped digit entries of the G1 MSM over the same scalars (b_g1_query and
+    b_g2_query are b_i(τ)·G1 and b_i(τ)·G2, generator.rs:162,168: identity at the same indices).  A key from elsewhere is
+    not trusted to have that property: with one b_g1 point zeroed and one b_g2 point zeroed at another index the proof
+    must still be what the reference computes for THAT key (the C restatement's bytes), and with the honest key too."""
+    import copy
+    import cpu_ref
+    from crescent_credentials_amd import workloads as wl
+    l, m, M = 6, 9_000, 9_200
+    cm, w = wl.synthetic_circuit(606, l, m, M, 0.6, 3, profile="gates")
+    rng = random.Random(606)
+    pk = cc.generate_parameters_with_qap(cm, *(rng.randrange(1, oracle.R) for _ in range(4)))
+    odd = copy.copy(pk)
+    odd.b_g1_query = pk.b_g1_query.copy()
+    odd.b_g2_query = pk.b_g2_query.copy()
+    nz = [i for i in range(50, M) if pk.b_g1_query[64 * i:64 * i + 64].any() and w[32 * i:32 * i + 32].any()]
+    i1, i2 = nz[3], nz[40]
+    odd.b_g1_query[64 * i1:64 * i1 + 64] = 0                       # identity in G1 only
+    odd.b_g2_query[128 * i2:128 * i2 + 128] = 0                    # identity in G2 only
+    for key in (pk, odd):
+        prover = cc.Prover(key, cm, proof_slots=2)
+        try:
+            for r, s in ((rng.randrange(oracle.R), rng.randrange(oracle.R)), (0, 5), (rng.randrange(oracle.R), 0)):
+                for _ in range(2):                                  # before and after the one-time window re-tune
+                    got = prover.prove(w, r, s).data
+                assert got == cpu_ref.prove(key, (cm.a, cm.b, cm.c), l, m, M, w, r, s, nthreads=8), (key is odd, r == 0)
+        finally:
+            prover.close()
+
+
 def test_concurrent_proofs_on_one_context_and_across_contexts(cc, oracle):
     """SURVEY 8b threading: `create_client_state` runs concurrently from several tasks (sample/client_helper/src/main.rs:
     177-216), so cg_prove must be re-entrant across contexts and overlap proofs within one.  Twelve host threads drive a
