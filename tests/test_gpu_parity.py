@@ -130,6 +130,23 @@ def test_msm_montgomery_bases_and_truncation(cc, oracle):
     assert cc.msm_bigint_g1(b1, sc[:320]).hex() == exp
 
 
+def test_alt_bn128_doubling_vector_on_the_gpu(cc, oracle):
+    """2·G1 of alt_bn128 as EIP-196's ecAdd test data has it (an external vector, tests/test_oracle_kats.py), through the
+    fixed-base path and through both MSM entries of the HIP library"""
+    x2 = 0x030644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd3
+    y2 = 0x15ed738c0e0a7c92e7845f96b2ae9c0a68a6a449e3538fc7ff3ebf7a5a18a2c4
+    want = x2.to_bytes(32, "little") + y2.to_bytes(32, "little")
+    assert bytes(cc.fixed_base_g1(_scalars([2]))) == want
+    g = oracle.g1_packed(oracle.G1_GEN)
+    assert cc.msm_bigint_g1(g * 2, _scalars([1, 1])) == want
+    assert cc.msm_bigint_g1(g, _scalars([2])) == want
+    ctx = cc.MsmContext(g * 2, group=1)
+    try:
+        assert ctx.run(_scalars([1, 1])) == want
+    finally:
+        ctx.close()
+
+
 def test_msm_empty_and_all_zero(cc, oracle):
     assert cc.msm_bigint_g1(b"", b"") == bytes(64)
     g = oracle.g1_packed(oracle.G1_GEN)

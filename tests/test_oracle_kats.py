@@ -78,6 +78,17 @@ def test_r1cs_rejections(oracle):
         oracle.parse_r1cs(bytes(bad))
 
 
+def test_alt_bn128_doubling_vector(oracle):
+    """An EXTERNAL known answer (not from the reference tree, which pins no group arithmetic): 2·G1 on alt_bn128 / BN254 as
+    every EIP-196 ecAdd test suite carries it.  Pins the oracle's G1 addition law and base field to the public curve."""
+    x2 = 0x030644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd3
+    y2 = 0x15ed738c0e0a7c92e7845f96b2ae9c0a68a6a449e3538fc7ff3ebf7a5a18a2c4
+    assert oracle.G1.to_affine(oracle.G1.mul_affine(oracle.G1_GEN, 2)) == (x2, y2)
+    assert (y2 * y2 - x2 * x2 * x2 - 3) % oracle.Q == 0
+    # and through the MSM path: 1·G + 1·G
+    assert oracle.G1.to_affine(oracle.G1.msm([oracle.G1_GEN, oracle.G1_GEN], [1, 1])) == (x2, y2)
+
+
 def test_pairing_bilinear(oracle):
     from bn254_oracle import _f12_one, _f12_pow
     e1 = oracle.pairing(oracle.G1_GEN, oracle.G2_GEN)
