@@ -7,6 +7,10 @@ arithmetic itself and raises if the HIP library is missing (there is no CPU fall
 """
 from .api import (  # noqa: F401
     CrescentGpuError,
+    HostBuffer,
+    host_register,
+    host_unregister,
+    probe_shader_clock,
     CircomCircuit,
     ClientState,
     IOLocations,

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
 
@@ -67,6 +68,14 @@ class CgTimings(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class CgCtxInfo(C.Structure):
+    _fields_ = [("table_bytes", C.c_uint64), ("matrix_bytes", C.c_uint64), ("slot_bytes", C.c_uint64), ("total_bytes", C.c_uint64),
+                ("device_free_bytes", C.c_uint64), ("device_total_bytes", C.c_uint64), ("proof_slots", C.c_int32),
+                ("window_bits", C.c_int32 * 5), ("tuned", C.c_int32), ("retune_skipped_for_memory", C.c_int32),
+                ("retune_attempts", C.c_int32), ("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("latency_mode", C.c_int32),
+                ("reserved", C.c_int32 * 4)]
+
+
 class _CgProverParamsView(C.Structure):
     _fields_ = [("pk", _CgProvingKey), ("gamma_g2", C.c_void_p), ("gamma_abc_g1", C.c_void_p), ("gamma_abc_len", C.c_uint64),
                 ("vk_bytes", C.c_void_p), ("vk_len", C.c_uint64), ("pvk_bytes", C.c_void_p), ("pvk_len", C.c_uint64),
@@ -100,6 +109,12 @@ _SIGNATURES = {
     "cg_prove_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(CgTimings)]),
     "cg_prove_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(CgTimings)]),
     "cg_assemble": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cg_host_alloc": (C.c_void_p, [C.c_uint64]),
+    "cg_host_free": (None, [C.c_void_p]),
+    "cg_host_register": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "cg_host_unregister": (C.c_int, [C.c_void_p]),
+    "cg_ctx_get_info": (C.c_int, [C.c_void_p, C.POINTER(CgCtxInfo)]),
+    "cg_probe_shader_clock": (C.c_int, [C.c_int32, C.c_uint32, C.POINTER(C.c_double)]),
     "cg_witness_map": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cg_domain_size": (C.c_uint64, [C.c_void_p]),
     "cg_qap_load": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(_CgCsr), C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32]),
@@ -337,11 +352,52 @@ class Prover:
                                  self.num_variables, C.byref(opt)))
         self._h = h
         self.domain_size = int(L.cg_domain_size(h))
+        self._lease_lock = threading.Lock()
+        self._leases = 0                 # callers inside a cached prover (Groth16._prover_for); close() is deferred while > 0
+        self._close_when_idle = False
 
     def close(self):
         if getattr(self, "_h", None):
             lib().cg_circuit_free(self._h)
             self._h = None
+
+    def _lease(self) -> "Prover":
+        with self._lease_lock:
+            self._leases += 1
+        return self
+
+    def _unlease(self) -> None:
+        with self._lease_lock:
+            self._leases -= 1
+            retire = self._leases == 0 and self._close_when_idle
+        if retire:
+            self.close()
+
+    def _retire(self) -> None:
+        """evicted from a cache: closed now if nobody is inside it, otherwise by the last caller to leave"""
+        with self._lease_lock:
+            self._close_when_idle = True
+            idle = self._leases == 0
+        if idle:
+            self.close()
+
+    def info(self) -> dict:
+        """cg_ctx_get_info: resident bytes (tables, matrices, per slot), the current window of each MSM, whether the
+        one-time re-tune happened or was skipped for lack of memory"""
+        ci = CgCtxInfo()
+        _check(lib().cg_ctx_get_info(self._h, C.byref(ci)))
+        d = {k: getattr(ci, k) for k, _ in ci._fields_ if k not in ("window_bits", "reserved")}
+        d["window_bits"] = dict(zip(("h", "l", "a", "b_g1", "b_g2"), list(ci.window_bits)))
+        return d
+
+    def prove_host_ptr(self, ptr: int, r: int, s: int, timings: bool = False):
+        """cg_prove on a raw host address (num_variables x 32 B canonical): pageable or page-locked (HostBuffer)"""
+        out = np.zeros(256, dtype=np.uint8)
+        rb, sb = _u8(fr_to_bytes(r)), _u8(fr_to_bytes(s))
+        tm = CgTimings()
+        _check(lib().cg_prove(self._h, C.c_void_p(ptr), _ptr(rb), _ptr(sb), _ptr(out), C.byref(tm) if timings else None))
+        p = Proof(out.tobytes())
+        return (p, tm.as_dict()) if timings else p
 
     def __del__(self):
         try:
@@ -393,6 +449,47 @@ class Prover:
         return h
 
 
+class HostBuffer:
+    """Page-locked host memory from cg_host_alloc, viewed as a numpy uint8 array (`.array`): where a host lets the
+    witness calculator write the full assignment so that cg_prove's upload is one asynchronous DMA."""
+
+    def __init__(self, nbytes: int):
+        self.nbytes = int(nbytes)
+        self.ptr = lib().cg_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise CrescentGpuError(-4, lib().cg_last_error().decode("utf-8", "replace"))
+        self.array = np.ctypeslib.as_array(C.cast(self.ptr, C.POINTER(C.c_uint8)), shape=(self.nbytes,))
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            lib().cg_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def probe_shader_clock(device: int = -1, window_us: int = 20000) -> float:
+    """GHz the shader engines hold over the next `window_us` (cg_probe_shader_clock); safe to call from a second thread
+    while proofs run"""
+    g = C.c_double(0.0)
+    _check(lib().cg_probe_shader_clock(device, window_us, C.byref(g)))
+    return float(g.value)
+
+
+def host_register(a: np.ndarray) -> None:
+    """pin an existing contiguous numpy buffer in place (cg_host_register); undo with host_unregister before freeing it"""
+    _check(lib().cg_host_register(C.c_void_p(a.ctypes.data), a.nbytes))
+
+
+def host_unregister(a: np.ndarray) -> None:
+    _check(lib().cg_host_unregister(C.c_void_p(a.ctypes.data)))
+
+
 class QapContext:
     """Three constraint matrices resident on one GPU with their domain tables, no proving key (cg_qap_ctx)."""
 
@@ -404,6 +501,13 @@ class QapContext:
         self._h = C.c_void_p()
         _check(lib().cg_qap_load(C.byref(self._h), abc, self.num_inputs, self.num_constraints, self.num_variables, device))
         self.domain_size = int(lib().cg_qap_domain_size(self._h))
+        self._lease_lock = threading.Lock()
+        self._leases = 0
+        self._close_when_idle = False
+
+    _lease = Prover._lease
+    _unlease = Prover._unlease
+    _retire = Prover._retire
 
     def witness_map(self, full_assignment) -> np.ndarray:
         w = _u8(full_assignment, self.num_variables * 32)
@@ -438,27 +542,110 @@ class R1CSToQAP:
         raise NotImplementedError
 
 
+def _content_digest(*arrays) -> bytes:
+    """128-bit digest of the bytes of the given numpy arrays / bytes objects (xxh3 when present - tens of milliseconds for
+    the 0.6 GB of a full-size circuit - else blake2b).  Cache keys only: never part of a proof."""
+    try:
+        import xxhash
+        h = xxhash.xxh3_128()
+    except Exception:
+        import hashlib
+        h = hashlib.blake2b(digest_size=16)
+    for a in arrays:
+        if isinstance(a, np.ndarray):
+            a = np.ascontiguousarray(a)
+            h.update(np.int64(a.size).tobytes())
+            h.update(a.view(np.uint8).reshape(-1).data if a.size else b"")
+        else:
+            h.update(np.int64(len(a)).tobytes())
+            h.update(a)
+    return h.digest()
+
+
+def _matrices_key(m: "ConstraintMatrices") -> tuple:
+    """what the three matrices ARE, not where they live: shape + a digest of every index and coefficient (computed once
+    per object and remembered on it)"""
+    k = getattr(m, "_content_key", None)
+    if k is None:
+        k = (m.num_instance_variables, m.num_witness_variables, m.num_constraints, m.a.nnz, m.b.nnz, m.c.nnz,
+             _content_digest(m.a.row_ptr, m.a.col, m.a.coeff, m.b.row_ptr, m.b.col, m.b.coeff, m.c.row_ptr, m.c.col, m.c.coeff))
+        m._content_key = k
+    return k
+
+
+def _pk_key(pk: "ProvingKey") -> tuple:
+    """a proving key by content: the verifying key's points, the query lengths and a digest of the queries"""
+    k = getattr(pk, "_content_key", None)
+    if k is None:
+        k = (pk.coord_form, pk.a_query.size, pk.h_query.size, pk.l_query.size,
+             _content_digest(pk.vk.alpha_g1, pk.vk.beta_g2, pk.vk.gamma_g2, pk.vk.delta_g1, pk.vk.delta_g2, pk.vk.gamma_abc_g1,
+                             pk.beta_g1, pk.delta_g1, pk.a_query, pk.b_g1_query, pk.b_g2_query, pk.h_query, pk.l_query))
+        pk._content_key = k
+    return k
+
+
+class _ResidentCache:
+    """Resident GPU contexts keyed by the CONTENT of what they were loaded from, least recently used first out, safe to
+    use from several threads: lookups and evictions happen under one lock, a context handed out is leased (see
+    Prover._lease) and an evicted context is closed by the last caller to leave it, never under one."""
+
+    def __init__(self, max_cached: int):
+        self.max_cached = max_cached
+        self._lock = threading.Lock()
+        self._entries = {}          # key -> context; insertion order = recency
+        self._loading = {}          # key -> threading.Event: one thread loads, the others wait for it
+
+    def lease(self, key, make):
+        while True:
+            with self._lock:
+                ctx = self._entries.pop(key, None)
+                if ctx is not None:
+                    self._entries[key] = ctx                  # most recent
+                    return ctx._lease()
+                ev = self._loading.get(key)
+                if ev is None:
+                    ev = self._loading[key] = threading.Event()
+                    break
+            ev.wait()                                         # another thread is loading this very circuit
+        try:
+            ctx = make()                                      # seconds: outside the lock
+        except BaseException:
+            with self._lock:
+                self._loading.pop(key).set()
+            raise
+        evicted = []
+        with self._lock:
+            self._entries[key] = ctx
+            ctx._lease()
+            while len(self._entries) > self.max_cached:
+                evicted.append(self._entries.pop(next(iter(self._entries))))
+            self._loading.pop(key).set()
+        for old in evicted:
+            old._retire()
+        return ctx
+
+    def clear(self):
+        with self._lock:
+            gone = list(self._entries.values())
+            self._entries.clear()
+        for ctx in gone:
+            ctx._retire()
+
+    def __len__(self):
+        with self._lock:
+            return len(self._entries)
+
+    def __contains__(self, key):
+        with self._lock:
+            return key in self._entries
+
+
 class LibsnarkReduction(R1CSToQAP):
     """forks/groth16/src/r1cs_to_qap.rs:100-226, the default QAP type (lib.rs:55), on the GPU.  The reference's call
-    is stateless; the matrices' device copy is kept per matrices object (strong reference, identity-checked, at most
-    MAX_CACHED resident) so that repeated calls only move the assignment."""
+    is stateless; the matrices' device copy is kept per matrices CONTENT (shape + digest of every term, at most MAX_CACHED
+    resident, least recently used first out) so that repeated calls only move the assignment."""
     MAX_CACHED = 4
-    _cache = {}     # id(matrices) -> (matrices, QapContext)
-
-    @classmethod
-    def _context_for(cls, matrices: ConstraintMatrices) -> QapContext:
-        key = id(matrices)
-        hit = cls._cache.pop(key, None)
-        if hit is not None and hit[0] is matrices and hit[1]._h.value:
-            cls._cache[key] = hit
-            return hit[1]
-        if hit is not None:
-            hit[1].close()
-        ctx = QapContext(matrices)
-        cls._cache[key] = (matrices, ctx)
-        while len(cls._cache) > cls.MAX_CACHED:
-            cls._cache.pop(next(iter(cls._cache)))[1].close()
-        return ctx
+    _cache = _ResidentCache(MAX_CACHED)
 
     @classmethod
     def witness_map_from_matrices(cls, matrices: ConstraintMatrices, num_inputs: int, num_constraints: int,
@@ -467,39 +654,32 @@ class LibsnarkReduction(R1CSToQAP):
         with code CG_ERR_POLY_DEGREE_TOO_LARGE where the reference returns PolynomialDegreeTooLarge (:156-157)."""
         if num_inputs != matrices.num_instance_variables or num_constraints != matrices.num_constraints:
             raise ValueError("num_inputs/num_constraints disagree with the matrices")
-        return cls._context_for(matrices).witness_map(full_assignment)
+        cls._cache.max_cached = cls.MAX_CACHED
+        ctx = cls._cache.lease(_matrices_key(matrices), lambda: QapContext(matrices))
+        try:
+            return ctx.witness_map(full_assignment)
+        finally:
+            ctx._unlease()
 
     @classmethod
     def clear_cache(cls):
-        for _, ctx in cls._cache.values():
-            ctx.close()
         cls._cache.clear()
 
 
 class Groth16:
     """forks/groth16/src/lib.rs:55-57 / prover.rs.  The reference's calls are stateless; here a loaded circuit (key
-    tables + matrices in HBM) is kept per (pk, matrices) object pair, since re-uploading a 0.6 GB key for every proof
-    would defeat the point.  The cache holds strong references to both objects (an id() can be reused once an object
-    is collected) and checks identity on a hit; at most `MAX_CACHED` circuits stay resident, the least recently used
-    one is closed first."""
+    tables + matrices in HBM) is kept per (key, matrices) CONTENT, since re-uploading a 0.6 GB key and redoing the 1.6 s
+    change of basis for every proof would defeat the point - also when the caller parses fresh objects from the same
+    files for every call, as `create_client_state` does (creds/src/lib.rs:258,268).  At most `MAX_CACHED` circuits stay
+    resident; the least recently used one is retired first, and closed only once no thread is inside it."""
     MAX_CACHED = 4
-    _cache = {}          # (id(pk), id(matrices)) -> (pk, matrices, Prover); insertion order = recency
+    _cache = _ResidentCache(MAX_CACHED)
 
     @classmethod
     def _prover_for(cls, pk: ProvingKey, matrices: ConstraintMatrices) -> Prover:
-        key = (id(pk), id(matrices))
-        hit = cls._cache.pop(key, None)
-        if hit is not None and hit[0] is pk and hit[1] is matrices and hit[2]._h:
-            cls._cache[key] = hit                      # move to the most-recent end
-            return hit[2]
-        if hit is not None:
-            hit[2].close()
-        pr = Prover(pk, matrices)
-        cls._cache[key] = (pk, matrices, pr)
-        while len(cls._cache) > cls.MAX_CACHED:
-            oldest = next(iter(cls._cache))
-            cls._cache.pop(oldest)[2].close()
-        return pr
+        """a LEASED resident prover for this key and these matrices: the caller must `_unlease()` it"""
+        cls._cache.max_cached = cls.MAX_CACHED
+        return cls._cache.lease((_pk_key(pk), _matrices_key(matrices)), lambda: Prover(pk, matrices))
 
     @classmethod
     def create_proof_with_reduction_and_matrices(cls, pk: ProvingKey, r: int, s: int, matrices: ConstraintMatrices,
@@ -507,7 +687,11 @@ class Groth16:
         """prover.rs:26-51."""
         if num_inputs != matrices.num_instance_variables or num_constraints != matrices.num_constraints:
             raise ValueError("num_inputs/num_constraints disagree with the matrices")
-        return cls._prover_for(pk, matrices).prove(full_assignment, r, s)
+        prover = cls._prover_for(pk, matrices)
+        try:
+            return prover.prove(full_assignment, r, s)
+        finally:
+            prover._unlease()
 
     @classmethod
     def create_proof_with_reduction(cls, circuit: "CircomCircuit", pk: ProvingKey, r: int, s: int) -> Proof:
@@ -535,8 +719,6 @@ class Groth16:
 
     @classmethod
     def clear_cache(cls):
-        for _, _, p in cls._cache.values():
-            p.close()
         cls._cache.clear()
 
 

@@ -27,6 +27,21 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unus
 EXTRA_FLAGS = os.environ.get("CG_HIPCC_EXTRA", "").split()
 
 
+def source_fingerprint() -> str:
+    """sha256 (first 16 hex digits) over every kernel source and header plus the compiler flags in force: what a
+    committed counter pass (profiles/pmc_counters.json) is valid for.  bench.py nulls the figures derived from a pass
+    whose fingerprint differs from the tree it runs on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            with open(os.path.join(CSRC, f), "rb") as fh:
+                h.update(fh.read())
+    h.update(" ".join(HIPCC_FLAGS + EXTRA_FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def _hipcc() -> str:
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):

@@ -37,6 +37,19 @@ struct HipError : std::runtime_error {
 
 #define CG_KERNEL_CHECK() CG_HIP(hipGetLastError())
 
+// Device-memory accounting (cg_ctx_get_info): while an AllocScope is alive on a thread, every DevBuf that thread
+// allocates adds its bytes to the scope's counter and every DevBuf it releases subtracts them, so temporaries made and
+// freed inside a scope cancel out and what is left is what stays resident.
+struct AllocScope {
+    static int64_t*& current() { static thread_local int64_t* cur = nullptr; return cur; }
+    int64_t* prev;
+    explicit AllocScope(int64_t* counter) : prev(current()) { current() = counter; }
+    ~AllocScope() { current() = prev; }
+    AllocScope(const AllocScope&) = delete;
+    AllocScope& operator=(const AllocScope&) = delete;
+    static void note(int64_t delta) { if (int64_t* c = current()) *c += delta; }
+};
+
 // RAII device buffer
 template <class T>
 struct DevBuf {
@@ -56,9 +69,10 @@ struct DevBuf {
         release();
         if (count) CG_HIP(hipMalloc((void**)&p, count * sizeof(T)));
         n = count;
+        AllocScope::note((int64_t)(count * sizeof(T)));
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) { (void)hipFree(p); AllocScope::note(-(int64_t)(n * sizeof(T))); }
         p = nullptr; n = 0;
     }
     size_t bytes() const { return n * sizeof(T); }

@@ -180,15 +180,15 @@ void MsmBases<F>::build_from_row0(const uint32_t* row0_dev, const uint8_t* valid
 }
 
 template <class F>
-void MsmBases<F>::rebuild(int c_new, hipStream_t st) {
-    if (!precomputed || c_new == c || !n) return;
+int MsmBases<F>::rebuild(int c_new, hipStream_t st) {
+    if (!precomputed || c_new == c || !n) return 0;
     const int W_new = (SCALAR_BITS + c_new - 1) / c_new;
-    if ((uint64_t)W_new * n >= (1ull << 31)) return;
+    if ((uint64_t)W_new * n >= (1ull << 31)) return 0;
     {   // the old and the new table coexist until the swap: never re-tune into an out-of-memory failure
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return -1;
         const uint64_t need = (uint64_t)W_new * n * AFF * 4;
-        if (need + (2ull << 30) > free_b) return;
+        if (need + (2ull << 30) > free_b) return -1;
     }
     DevBuf<uint32_t> t2((uint64_t)W_new * n * AFF);
     CG_HIP(hipMemcpyAsync(t2.p, table.p, n * AFF * 4, hipMemcpyDeviceToDevice, st));   // row 0 = the bases themselves
@@ -200,6 +200,7 @@ void MsmBases<F>::rebuild(int c_new, hipStream_t st) {
     table = std::move(t2);
     c = c_new;
     W = W_new;
+    return 1;
 }
 
 // ---------------------------------------------------------------------------------------------

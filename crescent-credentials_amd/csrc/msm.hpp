@@ -27,8 +27,10 @@ struct MsmBases {
     void build(const Affine<F>* bases_dev, uint64_t n, int c, bool precompute, hipStream_t st);
     // the same from packed table points (row 0) and their validity flags already on the device
     void build_from_row0(const uint32_t* row0_dev, const uint8_t* valid_dev, uint64_t n, int c, hipStream_t st);
-    // re-expand the same bases (row 0 of the table) for another window size
-    void rebuild(int c_new, hipStream_t st);
+    // re-expand the same bases (row 0 of the table) for another window size.  Returns 1 when the table was rebuilt, 0 when
+    // there was nothing to do, -1 when the new table would not fit next to the old one in free device memory (the old
+    // window stays in force: never re-tune into an out-of-memory failure)
+    int rebuild(int c_new, hipStream_t st);
     void alloc_rows(uint64_t n, int c, bool precompute);
     void expand_rows(hipStream_t st);
 };

@@ -128,7 +128,7 @@ struct ProofSlot {
     std::mutex busy;
     MsmEngine<Fq> eh, el, ea, eb1;
     MsmEngine<Fq2> eb2;
-    DevBuf<Fr> w_canon, h_canon;
+    DevBuf<Fr> h_canon;
     Wm29Buffers wm;
     hipStream_t st[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // 0: witness map + h, 1: l, 2: a, 3: b1, 4: b2
     hipEvent_t ev_w = nullptr;
@@ -140,6 +140,20 @@ struct ProofSlot {
         if (ev_w) (void)hipEventDestroy(ev_w);
         if (ev_b1) (void)hipEventDestroy(ev_b1);
         for (auto& e : ev_t) if (e) (void)hipEventDestroy(e);
+    }
+};
+
+// The device copy of one assignment on its way into a proof.  A context owns two more of these than proof slots and
+// each has a copy-only stream, so a caller's upload overlaps the proofs in flight WITHOUT holding one of their working
+// sets, and never puts a copy in front of another proof's kernels (see upload_assignment).
+struct Upload {
+    std::mutex busy;
+    DevBuf<Fr> w;
+    hipStream_t st = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    ~Upload() {
+        if (st) (void)hipStreamDestroy(st);
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     }
 };
 
@@ -169,12 +183,33 @@ struct cg_ctx {
     bool h_strided = false;
     Wm29Strided wstr;
     std::vector<std::unique_ptr<ProofSlot>> slots;
+    std::vector<std::unique_ptr<Upload>> uploads;
+    std::mutex up_mu;
+    std::condition_variable up_cv;
+    Upload* acquire_upload() {
+        std::unique_lock<std::mutex> lk(up_mu);
+        for (;;) {
+            for (auto& u : uploads)
+                if (u->busy.try_lock()) return u.get();
+            up_cv.wait(lk);
+        }
+    }
+    void release_upload(Upload* u) {
+        u->busy.unlock();
+        std::lock_guard<std::mutex> lk(up_mu);
+        up_cv.notify_one();
+    }
     // window tuning: the window of each assignment-driven query is re-chosen once from the digit statistics of
     // the first proof (circom witnesses are mostly 0/1 wires, for which the size-based default is far too wide)
     bool fixed_window = false;
     bool b_same_identities = false;   // b_g1_query and b_g2_query are the identity at the same indices (true for a generated key)
     std::atomic<bool> tuned{false};   // read outside tune_mu by every finished proof
-    std::shared_mutex tune_mu;   // proofs hold it shared; a retune holds it exclusively
+    std::atomic<int> retune_attempts{0};        // finished proofs whose statistics were looked at for the re-tune
+    std::atomic<int> retune_skipped_memory{0};  // queries whose re-tuned table did not fit next to the old one
+    std::shared_mutex tune_mu;   // proofs hold it shared; a retune (and cg_circuit_free) holds it exclusively
+    bool latency = false;
+    // device bytes that stay resident (cg_ctx_get_info): window tables + validity flags | matrices and domain tables | one slot
+    int64_t table_bytes = 0, matrix_bytes = 0, slot_bytes = 0;
     std::mutex pick_mu;
     std::condition_variable pick_cv;
     // blocks until a slot is free; returns it locked
@@ -190,6 +225,19 @@ struct cg_ctx {
         sl->busy.unlock();
         std::lock_guard<std::mutex> lk(pick_mu);
         pick_cv.notify_one();
+    }
+};
+struct UploadGuard {
+    cg_ctx* c = nullptr;
+    Upload* u = nullptr;
+    UploadGuard() = default;
+    UploadGuard(const UploadGuard&) = delete;
+    UploadGuard& operator=(const UploadGuard&) = delete;
+    void take(cg_ctx* ctx) { c = ctx; u = ctx->acquire_upload(); }
+    ~UploadGuard() {
+        if (!u) return;
+        (void)hipStreamSynchronize(u->st);      // a failed call may leave its copy in flight
+        c->release_upload(u);
     }
 };
 struct SlotGuard {
@@ -229,10 +277,12 @@ extern "C" const char* cg_last_error(void) { return last_error().c_str(); }
 extern "C" const char* cg_version(void) { return "crescent_gpu 0.1 (gfx950; BN254 Groth16 prove path: MSM G1/G2 + NTT + witness map)"; }
 
 extern "C" int cg_init(int n_devices, const int* device_ids) {
-    // Proofs in flight run on 5 streams each; the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues
-    // (default 4) and kernels on one queue cannot overlap.  Effective only if HIP has not initialised yet in this
-    // process; a host that initialises HIP earlier should export the variable itself.
-    (void)setenv("GPU_MAX_HW_QUEUES", "32", 0);
+    // The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); kernels of streams that share a
+    // queue cannot overlap, and a process with more than ~24 user queues is time-sliced by the hardware scheduler (a
+    // lone proof then meets 15 ms stalls: profiles/r03_a_streams_and_queues.txt).  16 holds twelve one-stream proofs in
+    // flight plus a five-stream latency context without either effect.  Effective only if HIP has not initialised yet in
+    // this process; a host that initialises HIP earlier should export the variable itself.
+    (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count == 0) return fail(CG_ERR_NO_DEVICE, "no HIP device visible (%s)", hipGetErrorString(e));
@@ -322,11 +372,16 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         if (c->h_strided) c->rh = {0, D / (uint64_t)c->shard_count};     // positions in the shard's own list of points
         c->rl = shard_range(c->folded ? M : M - l, c->shard_rank, c->shard_count);
         c->ra = shard_range(M - 1, c->shard_rank, c->shard_count);
+        // what stays resident is booked per kind as it is allocated (cg_ctx_get_info)
+        std::unique_ptr<AllocScope> booking;
+        auto book = [&](int64_t* counter) { booking.reset(); if (counter) booking.reset(new AllocScope(counter)); };
+        book(&c->matrix_bytes);
         c->A.upload(abc[0], m, M);     // validates the CSR views (monotone row_ptr, column range, canonical coefficients)
         c->B.upload(abc[1], m, M);
         c->C.upload(abc[2], m, M);
         c->dom.build(logD, true, s0);
         CG_HIP(hipStreamSynchronize(s0));
+        book(&c->table_bytes);
         if (c->folded) {
             // every shard transforms the whole queries (the DFT mixes all points) and keeps its own ranges of the results
             DevBuf<G1Affine> th(D), tl(M - l ? M - l : 1);
@@ -356,6 +411,7 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
                 c->b_same_identities = v1 == v2;
             }
         }
+        book(&c->matrix_bytes);
         c->wdom.build(c->dom, s0);
         if (c->h_strided) c->wstr.build(c->dom, ilog2_ceil((uint64_t)c->shard_count), c->shard_rank, s0);
         c->dA.build(c->A, s0); c->dB.build(c->B, s0); c->dC.build(c->C, s0);
@@ -364,10 +420,21 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         // the saturated-form tables were only the source of the packed ones
         c->dom.tw_fwd.release(); c->dom.tw_inv.release(); c->dom.coset_br.release(); c->dom.icoset_br.release();
         c->A.dict.release(); c->B.dict.release(); c->C.dict.release();
+        // a shard of one proof, or a context that proves one proof at a time, is a latency job; several proofs in
+        // flight are a throughput job
+        c->latency = c->shard_count > 1 || n_slots == 1;
+        if (const char* e = getenv("CG_LATENCY_MODE")) c->latency = e[0] == '1';    // profiling aid: force either segment length
         for (int k = 0; k < n_slots; ++k) {
+            book(k == 0 ? &c->slot_bytes : nullptr);      // the slots are identical: the first one is booked
             std::unique_ptr<ProofSlot> sl(new ProofSlot());
-            // CG_SERIAL_STREAMS=1 (profiling aid): one stream per slot, so a kernel trace shows stand-alone durations
-            const bool serial = getenv("CG_SERIAL_STREAMS") && getenv("CG_SERIAL_STREAMS")[0] == '1';
+            // A throughput context runs every proof on ONE stream: with a dozen proofs in flight the overlap comes from the
+            // other proofs, and twelve streams fit the hardware queues one each, where 60 share them (and anything above
+            // ~24 user queues per process is time-sliced by the hardware scheduler in 15 ms quanta): 192 proofs/s on 16
+            // queues against 188 with five streams per proof on 32 (profiles/r03_a_streams_and_queues.txt).  A latency
+            // context (one proof at a time, or a shard of one) spreads its five MSMs and the witness map over five streams.
+            // CG_SERIAL_STREAMS=1 / 0 forces either (profiling: a kernel trace of serial streams shows stand-alone durations).
+            bool serial = !c->latency;
+            if (const char* e = getenv("CG_SERIAL_STREAMS")) serial = e[0] == '1';
             // CG_CHAIN_PRIORITY=1 (experiment): the witness-map -> h-MSM chain, which sets a lone proof's latency, on a
             // high-priority stream
             const bool chain_prio = getenv("CG_CHAIN_PRIORITY") && getenv("CG_CHAIN_PRIORITY")[0] == '1';
@@ -381,16 +448,22 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
             CG_HIP(hipEventCreateWithFlags(&sl->ev_w, hipEventDisableTiming));
             CG_HIP(hipEventCreateWithFlags(&sl->ev_b1, hipEventDisableTiming));
             for (auto& e : sl->ev_t) CG_HIP(hipEventCreate(&e));
-            // a shard of one proof, or a context that proves one proof at a time, is a latency job; several proofs in
-            // flight are a throughput job
-            bool latency = c->shard_count > 1 || n_slots == 1;
-            if (const char* e = getenv("CG_LATENCY_MODE")) latency = e[0] == '1';    // profiling aid: force either segment length
+            const bool latency = c->latency;
             sl->eh.latency_mode = sl->el.latency_mode = sl->ea.latency_mode = sl->eb1.latency_mode = sl->eb2.latency_mode = latency;
             sl->eh.init(&c->bh); sl->el.init(&c->bl); sl->ea.init(&c->ba); sl->eb1.init(&c->bb1); sl->eb2.init(&c->bb2);
-            sl->w_canon.alloc(M); sl->h_canon.alloc(D);
+            sl->h_canon.alloc(D);
             sl->wm.alloc(M, D, std::max(c->A.sell_scratch, std::max(c->B.sell_scratch, c->C.sell_scratch)));
             c->slots.push_back(std::move(sl));
         }
+        for (int k = 0; k < n_slots + 2; ++k) {
+            book(k == 0 ? &c->slot_bytes : nullptr);      // booked with the slot: about one per proof in flight
+            std::unique_ptr<Upload> u(new Upload());
+            u->w.alloc(M);
+            CG_HIP(hipStreamCreateWithFlags(&u->st, hipStreamNonBlocking));
+            for (auto& e : u->ev) CG_HIP(hipEventCreate(&e));
+            c->uploads.push_back(std::move(u));
+        }
+        book(nullptr);
         *out = c.release();
         return CG_OK;
     } catch (...) {
@@ -400,6 +473,11 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
 
 extern "C" void cg_circuit_free(cg_ctx* ctx) {
     if (!ctx) return;
+    {   // proofs hold tune_mu shared from slot acquisition to their last stream synchronisation: taking it exclusively
+        // waits for every cg_prove* still inside this context (a caller must not START a call after this one, as with
+        // any handle)
+        std::unique_lock<std::shared_mutex> drain(ctx->tune_mu);
+    }
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     delete ctx;
@@ -425,24 +503,29 @@ static float ev_ms(hipEvent_t a, hipEvent_t b) {
     return ms;
 }
 
-static int prove_partial_impl(cg_ctx* c, ProofSlot* S, const void* assignment, bool on_device, bool skip_b1, Partials& P, cg_timings* tm,
+// Host -> device copy of one assignment into `u`, on u's copy-only stream; THIS THREAD waits for it.  Every kernel of
+// the proof needs the assignment, so the proof loses nothing, and the other proofs in flight (other threads) keep the GPU
+// busy meanwhile.  Enqueued on the proof's own stream instead, the copy becomes a barrier packet in a hardware queue that
+// several streams share and stalls kernels of OTHER proofs behind it: 171 proofs/s against 184-187 with the wait here
+// (profiles/r03_a_host_witness.txt).  Page-locked source (cg_host_alloc / cg_host_register): one DMA at PCIe speed;
+// pageable source: staged by the runtime through its own pinned buffers, inside the call.  Returns the copy's ms (timed).
+static float upload_assignment(cg_ctx* c, Upload* u, const void* host_assignment, bool timed) {
+    CG_HIP(hipSetDevice(c->device));
+    if (timed) CG_HIP(hipEventRecord(u->ev[0], u->st));
+    CG_HIP(hipMemcpyAsync(u->w.p, host_assignment, c->M * 32, hipMemcpyHostToDevice, u->st));
+    if (timed) CG_HIP(hipEventRecord(u->ev[1], u->st));
+    CG_HIP(hipStreamSynchronize(u->st));
+    return timed ? ev_ms(u->ev[0], u->ev[1]) : 0.f;
+}
+
+// w_dev: the assignment in this context's device memory (the caller's own buffer, or an Upload's)
+static int prove_partial_impl(cg_ctx* c, ProofSlot* S, const Fr* w_dev, bool skip_b1, Partials& P, cg_timings* tm,
                               const std::function<void()>* while_gpu_runs = nullptr) {
     CG_HIP(hipSetDevice(c->device));
     auto t0 = std::chrono::steady_clock::now();
     const uint64_t M = c->M, l = c->l;
+    (void)M;
     hipStream_t s0 = S->st[0];
-    float upload_ms = 0;
-    const Fr* w_dev;
-    if (on_device) {
-        w_dev = (const Fr*)assignment;
-    } else {
-        CG_HIP(hipMemcpyAsync(S->w_canon.p, assignment, M * 32, hipMemcpyHostToDevice, s0));
-        if (tm) {
-            CG_HIP(hipStreamSynchronize(s0));
-            upload_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        }
-        w_dev = S->w_canon.p;
-    }
     CG_HIP(hipEventRecord(S->ev_w, s0));
     for (int i = 1; i < 5; ++i) CG_HIP(hipStreamWaitEvent(S->st[i], S->ev_w, 0));
     // assignment-driven MSMs: operands (prover.rs:70-74, 84-89, 265-266)
@@ -481,7 +564,6 @@ static int prove_partial_impl(cg_ctx* c, ProofSlot* S, const void* assignment, b
     P.b2 = to_affine(S->eb2.value());
     if (tm) {
         memset(tm, 0, sizeof(*tm));
-        tm->upload_ms = upload_ms;
         tm->witness_map_ms = ev_ms(S->ev_t[0], S->ev_t[1]);
         tm->msm_h_ms = S->eh.ms_total();
         tm->msm_l_ms = S->el.ms_total();
@@ -567,45 +649,83 @@ static void partials_to_bytes(const Partials& P, uint8_t out[384]) {
     g2_export_canonical(P.b2, out + 256);
 }
 
-// One-time window re-tuning from the statistics of a finished proof (held in slot S's engines).
+// One-time window re-tuning from the digit statistics of a finished proof.  The statistics are copied out of the
+// proof's slot while the proof still owns it; whether they are worth a re-tune is decided WITHOUT the exclusive lock, so a
+// stream of unrepresentative assignments never drains the pipeline, and after RETUNE_MAX_ATTEMPTS looks the context keeps
+// its size-based windows for good.
+static constexpr int RETUNE_MAX_ATTEMPTS = 8;
+struct TuneStats {
+    bool valid = false;
+    struct Q { uint64_t n_scalars = 0; double nonzero = 0, entries = 0; } l, a, b1, b2;
+};
 template <class F>
-static bool retune_query(cg_ctx* c, MsmBases<F>& bases, MsmEngine<F> ProofSlot::*eng, ProofSlot* S, hipStream_t st) {
-    MsmEngine<F>& e = S->*eng;
-    if (!e.n_scalars || !bases.n) return false;
+static TuneStats::Q tune_stats_of(const MsmEngine<F>& e) {
+    TuneStats::Q q;
+    q.n_scalars = e.n_scalars; q.nonzero = e.n_nonzero(); q.entries = e.n_entries();
+    return q;
+}
+static void snapshot_tune_stats(const cg_ctx* c, const ProofSlot* S, bool skip_b1, TuneStats& ts) {
+    if (c->fixed_window || c->tuned || c->retune_attempts >= RETUNE_MAX_ATTEMPTS) return;
+    ts.l = tune_stats_of(S->el); ts.a = tune_stats_of(S->ea); ts.b2 = tune_stats_of(S->eb2);
+    if (!skip_b1) ts.b1 = tune_stats_of(S->eb1);
+    ts.valid = true;
+}
+// a query's table changed size: every slot's engine for it is re-sized (the first slot's change is booked)
+template <class F>
+static void reinit_engines(cg_ctx* c, MsmEngine<F> ProofSlot::*eng, const MsmBases<F>& bases) {
+    for (size_t k = 0; k < c->slots.size(); ++k) {
+        AllocScope booking(k == 0 ? &c->slot_bytes : nullptr);
+        ((*c->slots[k]).*eng).init(&bases);
+    }
+}
+template <class F>
+static int rebuild_booked(cg_ctx* c, MsmBases<F>& bases, int window, hipStream_t st) {
+    AllocScope booking(&c->table_bytes);
+    return bases.rebuild(window, st);
+}
+template <class F>
+static void retune_query(cg_ctx* c, MsmBases<F>& bases, MsmEngine<F> ProofSlot::*eng, const TuneStats::Q& q, hipStream_t st) {
+    if (!q.n_scalars || !bases.n) return;
     const int W0 = bases.W;
-    double nz = e.n_nonzero(), N = e.n_entries();
+    double nz = q.nonzero, N = q.entries;
     double nz_full = W0 > 1 ? (N - nz) / (double)(W0 - 1) : 0.0;
     if (nz_full < 0) nz_full = 0;
     if (nz_full > nz) nz_full = nz;
-    int best = msm_best_window(bases.n, nz - nz_full, nz_full);
-    if (best == bases.c) return false;
-    bases.rebuild(best, st);
-    for (auto& sl : c->slots) ((*sl).*eng).init(&bases);
-    return true;
+    const int best = msm_best_window(bases.n, nz - nz_full, nz_full);
+    if (best == bases.c) return;
+    const int rc = rebuild_booked(c, bases, best, st);
+    if (rc < 0) { c->retune_skipped_memory++; return; }
+    if (rc > 0) reinit_engines(c, eng, bases);
 }
-static void maybe_retune(cg_ctx* c) {
-    if (c->fixed_window || c->tuned) return;
+static void maybe_retune(cg_ctx* c, const TuneStats& ts) {
+    if (!ts.valid || c->fixed_window || c->tuned) return;
+    if (!ts.l.n_scalars && !ts.a.n_scalars) return;
+    // A degenerate assignment (all zero, or next to it) says nothing about the proofs to come: its statistics would pick
+    // the narrowest window and the widest tables for good.  Keep the size-based windows and wait for a representative
+    // proof - a bounded number of times.
+    if (ts.a.nonzero * 64 < (double)ts.a.n_scalars) { c->retune_attempts++; return; }
     std::unique_lock<std::shared_mutex> lk(c->tune_mu);     // waits for the proofs in flight to drain
     if (c->tuned) return;
-    ProofSlot* S = nullptr;
-    for (auto& sl : c->slots) if (sl->el.n_scalars || sl->ea.n_scalars) { S = sl.get(); break; }
-    if (!S) return;
-    // A degenerate first assignment (all zero, or next to it) says nothing about the proofs to come: its statistics
-    // would pick the narrowest window and the widest tables for good.  Keep the size-based windows and wait for a
-    // representative proof instead.
-    if ((uint64_t)S->ea.n_nonzero() * 64 < S->ea.n_scalars) return;
-    CG_HIP(hipSetDevice(c->device));
-    hipStream_t st = S->st[0];
-    retune_query<Fq>(c, c->bl, &ProofSlot::el, S, st);
-    retune_query<Fq>(c, c->ba, &ProofSlot::ea, S, st);
-    if (S->eb1.n_scalars) retune_query<Fq>(c, c->bb1, &ProofSlot::eb1, S, st);
-    else if (c->bb1.c != c->ba.c) { /* b1 was skipped (r = 0): follow b2's statistics below */ }
-    retune_query<Fq2>(c, c->bb2, &ProofSlot::eb2, S, st);
-    if (!S->eb1.n_scalars && c->bb1.c != c->bb2.c) {         // same scalars and same identity pattern as b2
-        c->bb1.rebuild(c->bb2.c, st);
-        for (auto& sl : c->slots) sl->eb1.init(&c->bb1);
+    c->retune_attempts++;
+    try {
+        CG_HIP(hipSetDevice(c->device));
+        hipStream_t st = c->slots[0]->st[0];
+        retune_query<Fq>(c, c->bl, &ProofSlot::el, ts.l, st);
+        retune_query<Fq>(c, c->ba, &ProofSlot::ea, ts.a, st);
+        if (ts.b1.n_scalars) retune_query<Fq>(c, c->bb1, &ProofSlot::eb1, ts.b1, st);
+        retune_query<Fq2>(c, c->bb2, &ProofSlot::eb2, ts.b2, st);
+        if (!ts.b1.n_scalars && c->bb1.c != c->bb2.c) {         // b1 was skipped (r = 0): same scalars and identity pattern as b2
+            const int rc = rebuild_booked(c, c->bb1, c->bb2.c, st);
+            if (rc < 0) c->retune_skipped_memory++;
+            if (rc > 0) reinit_engines(c, &ProofSlot::eb1, c->bb1);
+        }
+        c->tuned = true;
+    } catch (...) {
+        // the proof this call belongs to is already computed: a failed re-tune (out of memory beside another tenant of the
+        // GPU, say) leaves the size-based windows in force and is retried by a later proof, never reported as that
+        // proof's failure
+        (void)hipGetLastError();
     }
-    c->tuned = true;
 }
 
 static int check_rs(const uint8_t r[32], const uint8_t s[32]) {
@@ -622,15 +742,26 @@ static int prove_common(cg_ctx* ctx, const void* assignment, bool on_device, con
     try {
         Partials P;
         DeltaMultiples pre;
+        TuneStats ts;
         const std::function<void()> overlap = [&]() { pre = delta_multiples(ctx, r, s); };
         int e;
         {
             std::shared_lock<std::shared_mutex> tl(ctx->tune_mu);
+            UploadGuard up;                       // declared before the slot: released after it
+            float upload_ms = 0.f;
+            const Fr* w_dev = (const Fr*)assignment;
+            if (!on_device) {
+                up.take(ctx);
+                upload_ms = upload_assignment(ctx, up.u, assignment, tm != nullptr);
+                w_dev = up.u->w.p;
+            }
             SlotGuard g(ctx);
-            e = prove_partial_impl(ctx, g.s, assignment, on_device, scalar_is_zero(r), P, tm, &overlap);
+            e = prove_partial_impl(ctx, g.s, w_dev, scalar_is_zero(r), P, tm, &overlap);
+            if (!e) snapshot_tune_stats(ctx, g.s, scalar_is_zero(r), ts);
+            if (!e && tm) { tm->upload_ms = upload_ms; tm->total_ms += upload_ms; }
         }
-        if (!e) maybe_retune(ctx);
         if (e) return e;
+        maybe_retune(ctx, ts);
         auto t0 = std::chrono::steady_clock::now();
         assemble_impl(ctx, P, r, s, proof_out, &pre);
         if (tm) {
@@ -658,14 +789,25 @@ extern "C" int cg_prove_partial(cg_ctx* ctx, const void* full_assignment, int as
     if (!scalar_is_canonical(r)) return fail(CG_ERR_INVALID_ARGUMENT, "r not canonical");
     try {
         Partials P;
+        TuneStats ts;
         int e;
         {
             std::shared_lock<std::shared_mutex> tl(ctx->tune_mu);
+            UploadGuard up;
+            float upload_ms = 0.f;
+            const Fr* w_dev = (const Fr*)full_assignment;
+            if (!assignment_on_device) {
+                up.take(ctx);
+                upload_ms = upload_assignment(ctx, up.u, full_assignment, timings != nullptr);
+                w_dev = up.u->w.p;
+            }
             SlotGuard g(ctx);
-            e = prove_partial_impl(ctx, g.s, full_assignment, assignment_on_device != 0, scalar_is_zero(r), P, timings);
+            e = prove_partial_impl(ctx, g.s, w_dev, scalar_is_zero(r), P, timings);
+            if (!e) snapshot_tune_stats(ctx, g.s, scalar_is_zero(r), ts);
+            if (!e && timings) { timings->upload_ms = upload_ms; timings->total_ms += upload_ms; }
         }
-        if (!e) maybe_retune(ctx);
         if (e) return e;
+        maybe_retune(ctx, ts);
         partials_to_bytes(P, out_partials);
         return CG_OK;
     } catch (...) {
@@ -700,14 +842,75 @@ extern "C" int cg_witness_map(cg_ctx* ctx, const uint8_t* full_assignment, uint8
     if (!ctx || !full_assignment || !h_out) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
     try {
         CG_HIP(hipSetDevice(ctx->device));
+        std::shared_lock<std::shared_mutex> tl(ctx->tune_mu);
+        UploadGuard up;
+        up.take(ctx);
+        (void)upload_assignment(ctx, up.u, full_assignment, false);
         SlotGuard g(ctx);
         ProofSlot* S = g.s;
         hipStream_t s0 = S->st[0];
-        CG_HIP(hipMemcpyAsync(S->w_canon.p, full_assignment, ctx->M * 32, hipMemcpyHostToDevice, s0));
-        run_witness_map(ctx, S, S->w_canon.p, s0, false);   // the reference's result: coefficients
+        run_witness_map(ctx, S, up.u->w.p, s0, false);   // the reference's result: coefficients
         CG_HIP(hipMemcpyAsync(h_out, S->h_canon.p, ctx->D * 32, hipMemcpyDeviceToHost, s0));
         CG_HIP(hipStreamSynchronize(s0));
         if (S->wm.h_bad_input.p[0]) return fail(CG_ERR_INVALID_ARGUMENT, "full_assignment holds a value >= the scalar field modulus");
+        return CG_OK;
+    } catch (...) {
+        return translate_exception();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// page-locked host memory for assignments; context description
+// ---------------------------------------------------------------------------------------------
+extern "C" void* cg_host_alloc(uint64_t bytes) {
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)fail(e == hipErrorOutOfMemory ? CG_ERR_OUT_OF_MEMORY : CG_ERR_HIP, "hipHostMalloc(%llu) failed: %s", (unsigned long long)bytes,
+                   hipGetErrorString(e));
+        return nullptr;
+    }
+    return p;
+}
+extern "C" void cg_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+extern "C" int cg_host_register(void* p, uint64_t bytes) {
+    if (!p || !bytes) return fail(CG_ERR_INVALID_ARGUMENT, "null buffer");
+    hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) return fail(CG_ERR_HIP, "hipHostRegister failed: %s", hipGetErrorString(e));
+    return CG_OK;
+}
+extern "C" int cg_host_unregister(void* p) {
+    if (!p) return fail(CG_ERR_INVALID_ARGUMENT, "null buffer");
+    hipError_t e = hipHostUnregister(p);
+    if (e != hipSuccess) return fail(CG_ERR_HIP, "hipHostUnregister failed: %s", hipGetErrorString(e));
+    return CG_OK;
+}
+
+extern "C" int cg_ctx_get_info(cg_ctx* ctx, cg_ctx_info* out) {
+    if (!ctx || !out) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
+    try {
+        memset(out, 0, sizeof(*out));
+        std::shared_lock<std::shared_mutex> tl(ctx->tune_mu);     // not in the middle of a re-tune
+        out->table_bytes = (uint64_t)ctx->table_bytes;
+        out->matrix_bytes = (uint64_t)ctx->matrix_bytes;
+        out->slot_bytes = (uint64_t)ctx->slot_bytes;
+        out->proof_slots = (int32_t)ctx->slots.size();
+        out->total_bytes = out->table_bytes + out->matrix_bytes + out->slot_bytes * (uint64_t)out->proof_slots;
+        CG_HIP(hipSetDevice(ctx->device));
+        size_t free_b = 0, total_b = 0;
+        CG_HIP(hipMemGetInfo(&free_b, &total_b));
+        out->device_free_bytes = free_b;
+        out->device_total_bytes = total_b;
+        out->window_bits[0] = ctx->bh.c; out->window_bits[1] = ctx->bl.c; out->window_bits[2] = ctx->ba.c;
+        out->window_bits[3] = ctx->bb1.c; out->window_bits[4] = ctx->bb2.c;
+        out->tuned = ctx->tuned ? 1 : 0;
+        out->retune_skipped_for_memory = ctx->retune_skipped_memory;
+        out->retune_attempts = ctx->retune_attempts;
+        out->shard_rank = ctx->shard_rank;
+        out->shard_count = ctx->shard_count;
+        out->latency_mode = ctx->latency ? 1 : 0;
         return CG_OK;
     } catch (...) {
         return translate_exception();

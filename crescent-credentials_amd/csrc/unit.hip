@@ -413,3 +413,65 @@ extern "C" int cg_ntt(uint8_t* data, uint32_t log_n, int inverse, int coset) {
     cg_ntt_free(c);
     return e;
 }
+
+// ---------------------------------------------------------------------------------------------
+// shader-clock probe (diagnostic): the clock the chip actually holds while it is doing something else
+// ---------------------------------------------------------------------------------------------
+// One wave reads the shader-cycle counter (s_memtime, clock64) and the constant-rate 100 MHz counter (s_memrealtime,
+// wall_clock64) `window_ticks` of the latter apart, sleeping in between: cycles / ticks x 100 MHz is the clock the
+// shader engines ran at over that window, whatever else was running.  It occupies one wave slot and next to no issue
+// slots.
+__global__ void __launch_bounds__(64) k_clock_probe(uint64_t window_ticks, uint64_t* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    const uint64_t w0 = wall_clock64();
+    const uint64_t c0 = clock64();
+    uint64_t w1 = w0;
+    for (int guard = 0; guard < (1 << 24) && w1 - w0 < window_ticks; ++guard) {   // bounded whatever the counters do
+        __builtin_amdgcn_s_sleep(127);
+        w1 = wall_clock64();
+    }
+    const uint64_t c1 = clock64();
+    w1 = wall_clock64();
+    out[0] = c1 - c0;
+    out[1] = w1 - w0;
+}
+
+namespace {
+// one stream and one result buffer per device for the life of the process: a probe must not allocate or free anything
+// while proofs run (freeing host or device memory synchronises the device)
+struct ClockProbe {
+    std::mutex mu;
+    hipStream_t st = nullptr;
+    cg::PinnedBuf<uint64_t> res;
+    uint64_t* res_dev = nullptr;
+    int wall_khz = 0;
+};
+ClockProbe* const g_probe = new ClockProbe[64];   // never destroyed: the HIP runtime may be gone by static destruction time
+}  // namespace
+
+extern "C" int cg_probe_shader_clock(int32_t device, uint32_t window_us, double* ghz_out) {
+    if (!ghz_out || window_us == 0 || window_us > 1000000u) return fail(CG_ERR_INVALID_ARGUMENT, "window_us must be in [1, 1000000]");
+    try {
+        if (device < 0) CG_HIP(hipGetDevice(&device));
+        if (device >= 64) return fail(CG_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+        CG_HIP(hipSetDevice(device));
+        ClockProbe& P = g_probe[device];
+        std::lock_guard<std::mutex> lk(P.mu);
+        if (!P.st) {
+            CG_HIP(hipDeviceGetAttribute(&P.wall_khz, hipDeviceAttributeWallClockRate, device));
+            if (P.wall_khz <= 0) P.wall_khz = 100000;
+            P.res.alloc(2);
+            P.res_dev = P.res.dev();
+            CG_HIP(hipStreamCreateWithFlags(&P.st, hipStreamNonBlocking));
+        }
+        P.res.p[0] = P.res.p[1] = 0;
+        k_clock_probe<<<1, 64, 0, P.st>>>((uint64_t)window_us * (uint64_t)P.wall_khz / 1000u, P.res_dev);
+        CG_KERNEL_CHECK();
+        CG_HIP(hipStreamSynchronize(P.st));
+        if (!P.res.p[1]) return fail(CG_ERR_HIP, "the constant-rate counter did not advance");
+        *ghz_out = (double)P.res.p[0] / (double)P.res.p[1] * (double)P.wall_khz * 1e-6;
+        return CG_OK;
+    } catch (...) {
+        return translate_current_exception();
+    }
+}

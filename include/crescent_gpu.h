@@ -164,6 +164,42 @@ int cg_prove(cg_ctx* ctx, const uint8_t* full_assignment, const uint8_t r[32], c
 int cg_prove_dev(cg_ctx* ctx, const void* d_full_assignment, const uint8_t r[32], const uint8_t s[32],
                  uint8_t proof_out[256], cg_timings* timings);
 
+/* Page-locked host memory for assignments.
+ * Replaces: the allocation behind `full_assignment: &[E::ScalarField]` (forks/groth16/src/prover.rs:33; built as
+ *           `[instance_assignment, witness_assignment].concat()` at r1cs_to_qap.rs:68-72 from what the WASM witness
+ *           calculator returned, forks/circom-compat/src/circom/builder.rs:71-98).  cg_prove accepts ANY
+ *           host pointer; from pageable memory the 32·num_variables-byte upload is staged by the HIP runtime inside the call,
+ *           from page-locked memory it is one asynchronous DMA that overlaps the other proofs in flight.  A host that
+ *           can choose where the witness calculator writes its output takes the buffer from cg_host_alloc; a host that
+ *           cannot may pin its own buffer once with cg_host_register (and must cg_host_unregister it before freeing it).
+ * cg_host_alloc returns NULL on failure (cg_last_error says why). */
+void* cg_host_alloc(uint64_t bytes);
+void cg_host_free(void* p);
+int cg_host_register(void* p, uint64_t bytes);
+int cg_host_unregister(void* p);
+
+/* What a loaded circuit occupies and how its MSMs are configured.  The reference's prover has no counterpart (its key is
+ * a Vec in host memory, data_structures.rs:101-118); a host sizing `proof_slots`, or running several circuits on one GPU,
+ * needs the numbers, and a host that relies on the one-time window re-tune (see cg_options.window_bits) needs to know
+ * whether it happened. */
+typedef struct cg_ctx_info {
+    uint64_t table_bytes;        /* per-window base tables of the five queries + validity flags (shared by all slots) */
+    uint64_t matrix_bytes;       /* resident constraint matrices + NTT / coset tables */
+    uint64_t slot_bytes;         /* ONE proof slot's working set; the context holds proof_slots of them */
+    uint64_t total_bytes;        /* table_bytes + matrix_bytes + proof_slots x slot_bytes */
+    uint64_t device_free_bytes;  /* hipMemGetInfo at the time of the call */
+    uint64_t device_total_bytes;
+    int32_t proof_slots;
+    int32_t window_bits[5];      /* current window of the h, l, a, b_g1, b_g2 MSMs */
+    int32_t tuned;               /* 1 once the assignment-driven windows were re-chosen from a proof's digit statistics */
+    int32_t retune_skipped_for_memory; /* queries whose re-tuned table did not fit beside the old one: they keep the size-based window */
+    int32_t retune_attempts;     /* proofs inspected for the re-tune so far (it gives up after a few degenerate ones) */
+    int32_t shard_rank, shard_count;
+    int32_t latency_mode;        /* 1: short accumulation segments + tree reductions (one proof at a time); 0: throughput */
+    int32_t reserved[4];
+} cg_ctx_info;
+int cg_ctx_get_info(cg_ctx* ctx, cg_ctx_info* out);
+
 /* Multi-GPU: a context loaded with shard_count > 1 owns a contiguous range of the l, a and b
  * queries and, of the h query, a contiguous range or — for a power-of-two shard_count — the coset points
  * j = shard_rank (mod shard_count), which lets two of its four transforms run at 1/shard_count of the size.  Which
@@ -340,6 +376,12 @@ int cg_client_state_serialize(const cg_client_state_view* v, uint8_t* out, uint6
 int cg_client_state_parse(const uint8_t* data, uint64_t len, cg_client_state** out);
 int cg_client_state_get(const cg_client_state* cs, cg_client_state_view* view);
 void cg_client_state_free(cg_client_state* cs);
+
+/* Diagnostic: the shader clock (GHz) the GPU holds over the next `window_us` microseconds, measured on the device by
+ * one wave that compares the shader-cycle counter with the constant-rate counter - callable from a second thread while
+ * proofs run, which is how bench.py reports the clock its peaks should be scaled by.  device -1 = current.
+ * (No counterpart in the reference: CPU provers do not report their clock either.) */
+int cg_probe_shader_clock(int32_t device, uint32_t window_us, double* ghz_out);
 
 /* Library / device description for logs ("crescent_gpu 0.1 gfx950 ..."). */
 const char* cg_version(void);

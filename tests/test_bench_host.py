@@ -1,0 +1,98 @@
+"""Host-side logic of bench.py that needs no GPU: the self-launch of `--gpus N` (the driver runs `python bench.py
+--gpus N` exactly as it runs `--gpus 1`), the steady-state block timing, and the guard that keeps counter-derived figures
+out of the line when the kernels on disk are not the ones the committed counter pass was taken on."""
+import json
+import os
+import subprocess
+import sys
+import threading
+import time
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_launch_command_is_the_drivers_own():
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "20", "--warmup", "5"], port=29999)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"]
+    # a free port is picked when none is given
+    p = int(bench.launch_command(2, [])[bench.launch_command(2, []).index("--master-port") + 1])
+    assert 1024 < p < 65536
+
+
+def test_gpus_2_without_a_launcher_starts_its_own_ranks_or_says_why():
+    """no GPU in this container: the self-launch path must be the one taken (not the old 'must be launched under
+    torch.distributed.run' exit) and must fail with a message about GPUs, before any rank is started"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.device_count() == 0:
+        assert r.returncode == 2 and "no GPU visible" in r.stderr and "torch.distributed.run" not in r.stderr
+        assert r.stdout.strip() == ""
+
+
+def test_block_count_and_block_times():
+    class A:
+        blocks = 0
+        steps = 20
+    assert bench.n_blocks(A) == 13                      # 13 x 20 >= 240, odd
+    A.steps = 400
+    assert bench.n_blocks(A) == 5
+    A.blocks = 4
+    assert bench.n_blocks(A) == 4
+    # completions one per millisecond from t = 1 ms: every block of 10 lasts 10 ms whatever the warm-up
+    done = [0.001 * (i + 1) for i in range(100)]
+    bt = bench.block_times(done, 7, 10, 5, 0.0)
+    assert all(abs(x - 0.010) < 1e-12 for x in bt) and len(bt) == 5
+    # without warm-up the first block starts at t_start
+    assert abs(bench.block_times(done, 0, 10, 1, 0.0)[0] - 0.010) < 1e-12
+
+
+def test_steady_stream_keeps_n_in_flight_and_surfaces_errors():
+    live, peak, lock = [0], [0], threading.Lock()
+
+    def job(k):
+        with lock:
+            live[0] += 1
+            peak[0] = max(peak[0], live[0])
+        time.sleep(0.002)
+        with lock:
+            live[0] -= 1
+    done = bench.steady_stream(job, 40, 4)
+    assert len(done) == 40 and done == sorted(done) and peak[0] == 4
+
+    def bad(k):
+        if k == 5:
+            raise RuntimeError("boom")
+    with pytest.raises(RuntimeError):
+        bench.steady_stream(bad, 20, 3)
+
+
+def test_counter_pass_is_tied_to_the_kernel_sources():
+    fp = bench.source_fingerprint()
+    assert len(fp) == 16 and fp == bench.source_fingerprint()
+    entry, current = bench.committed_counters("rs256-sd/gates/bits=0.90")
+    if entry is not None:
+        assert current == (entry.get("csrc_sha16") == fp)
+    assert bench.committed_counters("no/such/workload") == (None, False)
+    # the fingerprint moves with any kernel source byte
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("cg_build_t", os.path.join(ROOT, "crescent-credentials_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    old_flags = list(mod.EXTRA_FLAGS)
+    try:
+        mod.EXTRA_FLAGS.append("-DX")
+        assert mod.source_fingerprint() != fp
+    finally:
+        mod.EXTRA_FLAGS[:] = old_flags
+    assert mod.source_fingerprint() == fp

@@ -151,17 +151,37 @@ def test_groth16_prove_call_shape_and_cache(cc, oracle, af, cache_dir):
         with pytest.raises(cc.CrescentGpuError) as ei:
             cc.Groth16.prove(pp.groth16_params, cc.CircomCircuit(r1cs), random.Random(1))
         assert "AssignmentMissing" in str(ei.value)
-        # an id() that comes back for a different object must not hit the cache: identity is checked
-        key = next(iter(cc.Groth16._cache))
-        stale = cc.Groth16._cache[key]
-        other_pk = cc.ProverParams.from_bytes(cache_dir["pp"]).groth16_params
-        cc.Groth16._cache[key] = (other_pk, stale[1], stale[2])
-        p4 = cc.Groth16.prove(pp.groth16_params, circuit, random.Random(5))
-        assert p4.data == p1.data
-        # LRU bound
-        for _ in range(cc.Groth16.MAX_CACHED + 1):
-            cc.Groth16.prove(cc.ProverParams.from_bytes(cache_dir["pp"]).groth16_params, circuit, random.Random(5))
-        assert len(cc.Groth16._cache) <= cc.Groth16.MAX_CACHED
+        # the cache is keyed by CONTENT: a key and a circuit parsed afresh from the same files (what create_client_state
+        # does on every call, creds/src/lib.rs:258,268) reuse the resident circuit ...
+        pp2 = cc.ProverParams.from_bytes(cache_dir["pp"])
+        circuit2 = cc.CircomCircuit(cc.R1CSFile(cache_dir["r1cs"]), cache_dir["w"])
+        p4 = cc.Groth16.prove(pp2.groth16_params, circuit2, random.Random(5))
+        assert p4.data == p1.data and len(cc.Groth16._cache) == 1
+        # ... and a key that differs in one coordinate of one query point does not
+        pp3 = cc.ProverParams.from_bytes(cache_dir["pp"])
+        pp3.groth16_params.a_query = pp3.groth16_params.a_query.copy()
+        pp3.groth16_params.a_query[64 * 7: 64 * 8] = pp3.groth16_params.a_query[64 * 8: 64 * 9]
+        p5 = cc.Groth16.prove(pp3.groth16_params, circuit, random.Random(5))
+        assert len(cc.Groth16._cache) == 2 and p5.b == p1.b
+        # LRU bound, under concurrent callers: MAX_CACHED + 2 different keys proved from 6 threads; an evicted prover is
+        # closed only by the last caller to leave it, so every proof comes back (and equals its own key's proof)
+        from concurrent.futures import ThreadPoolExecutor
+        keys = []
+        for k in range(cc.Groth16.MAX_CACHED + 2):
+            q = cc.ProverParams.from_bytes(cache_dir["pp"]).groth16_params
+            q.l_query = q.l_query.copy()
+            q.l_query[64 * k: 64 * (k + 1)] = q.l_query[64 * (k + 1): 64 * (k + 2)]
+            keys.append(q)
+        old_max = cc.Groth16.MAX_CACHED
+        cc.Groth16.MAX_CACHED = 2
+        try:
+            with ThreadPoolExecutor(max_workers=6) as ex:
+                got = list(ex.map(lambda i: cc.Groth16.prove(keys[i % len(keys)], circuit, random.Random(9)).data, range(18)))
+        finally:
+            cc.Groth16.MAX_CACHED = old_max
+        for i, g in enumerate(got):
+            assert g == got[i % len(keys)] and len(g) == 256
+        assert len(cc.Groth16._cache) <= 2
     finally:
         cc.Groth16.clear_cache()
 

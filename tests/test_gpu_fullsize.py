@@ -66,29 +66,38 @@ def test_full_size_prove_equals_cpu_restatement(cc, oracle, shape, bit_fraction)
             prover.close()
 
 
-def test_full_size_eight_sharded_contexts_assemble_to_the_same_proof(cc, oracle):
-    """config 4's data path at S21 size: eight contexts, each owning 1/8 of every query, produce five
-    partial sums each; their concatenation (the all_gather's result) assembles to the unsharded proof's bytes."""
+@pytest.mark.parametrize("shape,n", [("rs256-sd", 8), ("mdl1", 8), ("rs256-sd", 3)], ids=lambda v: str(v))
+def test_full_size_sharded_contexts_assemble_to_the_same_proof(cc, oracle, shape, n):
+    """config 4's data path at full size: n contexts, each owning 1/n of every query, produce five partial
+    sums each; their concatenation (the all_gather's result) assembles to the unsharded proof's bytes.  S21 and - config
+    4's own size - S22 (mdl1, D = 2^22) over 8 strided shards (Wm29Strided / k_fold29), and S21 over 3 shards (not a power
+    of two: contiguous ranges of the h query's points); a satisfying and an arbitrary assignment each."""
     import cpu_ref
-    (l, m, M), cm, w, pk, rng = _workload(cc, oracle, "rs256-sd", 0.9, 77)
+    (l, m, M), cm, w, pk, rng = _workload(cc, oracle, shape, 0.9, 77 + n)
     r, s = rng.randrange(oracle.R), rng.randrange(oracle.R)
-    exp = cpu_ref.prove(pk, (cm.a, cm.b, cm.c), l, m, M, w, r, s, nthreads=_threads())
-    n = 8
+    nt = _threads()
+    # an assignment that satisfies nothing: the aux wires of the witness in another order (the prover's identities hold
+    # for any assignment; the C restatement computes the reference's (ab - c)/Z quotient for it just the same)
+    w2 = w.reshape(-1, 32).copy()
+    w2[l:] = w2[l:][np.random.default_rng(5).permutation(M - l)]
+    w2 = w2.reshape(-1)
+    exp = cpu_ref.prove(pk, (cm.a, cm.b, cm.c), l, m, M, w, r, s, nthreads=nt)
+    exp2 = cpu_ref.prove(pk, (cm.a, cm.b, cm.c), l, m, M, w2, r, s, nthreads=nt)
     shards = []
     try:
         for k in range(n):
             shards.append(cc.Prover(pk, cm, shard_rank=k, shard_count=n))
-        for rr, ss in ((r, s), (0, 0)):
-            parts = b"".join(p.prove_partial(w, rr) for p in shards)
-            got = shards[3].assemble(parts, n, rr, ss).data
-            if rr:
-                assert got == exp
-            else:
-                whole = cc.Prover(pk, cm)
-                try:
-                    assert got == whole.prove(w, 0, 0).data
-                finally:
-                    whole.close()
+        parts = b"".join(p.prove_partial(w, r) for p in shards)
+        assert shards[n // 2].assemble(parts, n, r, s).data == exp
+        parts = b"".join(p.prove_partial(w2, r) for p in shards)           # second proof of every shard: re-tuned windows
+        assert shards[0].assemble(parts, n, r, s).data == exp2
+        parts = b"".join(p.prove_partial(w, 0) for p in shards)            # r = 0: b1 skipped (prover.rs:102-112)
+        got0 = shards[n - 1].assemble(parts, n, 0, 0).data
     finally:
         for p in shards:
             p.close()
+    whole = cc.Prover(pk, cm)
+    try:
+        assert got0 == whole.prove(w, 0, 0).data
+    finally:
+        whole.close()

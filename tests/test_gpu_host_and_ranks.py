@@ -1,0 +1,221 @@
+"""Round-3 GPU tests of the boundary around the hot path:
+  * the witness arriving in HOST memory (the reference's reality, creds/src/lib.rs:274-283): pageable, page-locked from
+    cg_host_alloc, and a caller's own buffer pinned with cg_host_register - the same 256 bytes in every case;
+  * cg_ctx_get_info: resident bytes, windows, the one-time re-tune and its give-up rule;
+  * the real N-rank path: two `gloo` ranks on the one GPU, each with a REAL Prover(shard_rank=k, shard_count=2) under
+    ShardedProver (forks/groth16/src/prover.rs:66,74,266 sharded by range, one all_gather per proof), bytes against
+    oracle/cpu_ref.c;
+  * plain `python bench.py --gpus 2` starting its own ranks, as the driver invokes it."""
+import json
+import os
+import random
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0xC5E5CE47
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init(cc):
+    rc = cc.lib().cg_init(0, None)
+    assert rc == 0, cc.lib().cg_last_error()
+
+
+@pytest.fixture(scope="module")
+def medium(cc, oracle):
+    from crescent_credentials_amd import workloads as wl
+    l, m, M = wl.SHAPES["medium"]
+    cm, w = wl.synthetic_circuit(SEED + 5, l, m, M, 0.9, 3, profile="gates")
+    rng = random.Random(SEED + 5)
+    pk = cc.generate_parameters_with_qap(cm, *[rng.randrange(1, oracle.R) for _ in range(4)])
+    return (l, m, M), cm, w, pk
+
+
+def test_host_witness_pageable_pinned_registered_give_the_same_bytes(cc, oracle, medium):
+    import cpu_ref
+    (l, m, M), cm, w, pk = medium
+    r, s = 0x1234567, 0x7654321
+    want = cpu_ref.prove(pk, (cm.a, cm.b, cm.c), l, m, M, w, r, s, nthreads=8)
+    prover = cc.Prover(pk, cm, proof_slots=3)
+    try:
+        assert prover.prove(w, r, s).data == want                                  # pageable numpy memory
+        hb = cc.HostBuffer(w.size)
+        hb.array[:] = w
+        p, tm = prover.prove_host_ptr(hb.ptr, r, s, timings=True)                  # cg_host_alloc
+        assert p.data == want and tm["upload_ms"] > 0.0
+        own = w.copy()
+        cc.host_register(own)                                                      # the caller's own buffer, pinned in place
+        try:
+            assert prover.prove_host_ptr(own.ctypes.data, r, s).data == want
+        finally:
+            cc.host_unregister(own)
+        # several uploads in flight at once, from both kinds of memory
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=6) as ex:
+            got = list(ex.map(lambda i: prover.prove_host_ptr(hb.ptr if i & 1 else w.ctypes.data, r, s).data, range(12)))
+        assert all(g == want for g in got)
+        # a non-canonical element is still refused when it arrives from the host
+        hb.array[32 * 9:32 * 10] = np.frombuffer(oracle.R.to_bytes(32, "little"), np.uint8)
+        with pytest.raises(cc.CrescentGpuError):
+            prover.prove_host_ptr(hb.ptr, r, s)
+        hb.close()
+        assert cc.lib().cg_host_register(None, 10) == -1 and cc.lib().cg_host_unregister(None) == -1
+    finally:
+        prover.close()
+
+
+def test_ctx_info_reports_memory_windows_and_the_retune(cc, oracle, medium):
+    (l, m, M), cm, w, pk = medium
+    prover = cc.Prover(pk, cm, proof_slots=2)
+    try:
+        i0 = prover.info()
+        assert i0["proof_slots"] == 2 and i0["tuned"] == 0 and i0["retune_attempts"] == 0 and i0["latency_mode"] == 0
+        assert i0["table_bytes"] > 0 and i0["slot_bytes"] > 0 and i0["matrix_bytes"] > 0
+        assert i0["total_bytes"] == i0["table_bytes"] + i0["matrix_bytes"] + 2 * i0["slot_bytes"]
+        assert i0["device_total_bytes"] > i0["device_free_bytes"] > 0
+        # tables: at least the h query's rows (64 B per point and window)
+        D = prover.domain_size
+        wb = i0["window_bits"]
+        assert i0["table_bytes"] >= 64 * D * ((255 + wb["h"] - 1) // wb["h"])
+        # a degenerate assignment (only wire 0 set) is looked at, not taken as the sample, and does not drain the pipeline
+        z = np.zeros_like(w)
+        z[0] = 1
+        prover.prove(z, 1, 2)
+        i1 = prover.info()
+        assert i1["tuned"] == 0 and i1["retune_attempts"] == 1 and i1["window_bits"] == wb
+        # a representative one re-tunes the assignment-driven windows once
+        prover.prove(w, 1, 2)
+        i2 = prover.info()
+        assert i2["tuned"] == 1 and i2["retune_skipped_for_memory"] == 0 and i2["window_bits"]["h"] == wb["h"]
+        assert i2["window_bits"]["a"] <= wb["a"]
+        assert i2["total_bytes"] == i2["table_bytes"] + i2["matrix_bytes"] + 2 * i2["slot_bytes"]
+        prover.prove(w, 1, 2)
+        assert prover.info()["retune_attempts"] == i2["retune_attempts"]
+    finally:
+        prover.close()
+    # the give-up rule: a context that only ever sees degenerate assignments stops looking
+    p2 = cc.Prover(pk, cm)
+    try:
+        z = np.zeros_like(w)
+        z[0] = 1
+        for _ in range(12):
+            p2.prove(z, 3, 4)
+        i = p2.info()
+        assert i["tuned"] == 0 and i["retune_attempts"] == 8 and i["latency_mode"] == 1
+    finally:
+        p2.close()
+    # a fixed window is never re-tuned
+    p3 = cc.Prover(pk, cm, window_bits=12)
+    try:
+        p3.prove(w, 1, 2)
+        i = p3.info()
+        assert i["tuned"] == 0 and i["retune_attempts"] == 0 and set(i["window_bits"].values()) == {12}
+    finally:
+        p3.close()
+    sh = cc.Prover(pk, cm, shard_rank=1, shard_count=4)
+    try:
+        i = sh.info()
+        assert (i["shard_rank"], i["shard_count"], i["latency_mode"]) == (1, 4, 1)
+    finally:
+        sh.close()
+
+
+def test_shader_clock_probe(cc):
+    g = [cc.probe_shader_clock(-1, 5000) for _ in range(3)]
+    assert all(0.1 < x < 3.5 for x in g), g
+    with pytest.raises(cc.CrescentGpuError):
+        cc.probe_shader_clock(-1, 0)
+
+
+# ---- two real ranks --------------------------------------------------------------------------------------------------
+_RANK_SCRIPT = r'''
+import json, os, random, sys
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # two ranks share the GPU: do not oversubscribe its hardware queues
+root = sys.argv[1]; shape = sys.argv[2]; out_path = sys.argv[3]
+for p in (root, os.path.join(root, "oracle")):
+    sys.path.insert(0, p)
+import numpy as np, torch, torch.distributed as dist
+import crescent_credentials_amd as cc
+from crescent_credentials_amd import workloads as wl
+from crescent_credentials_amd.distributed import ShardedProver, barrier_sync
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+assert cc.lib().cg_init(0, None) == 0
+R = cc.api.FR_MODULUS
+SEED = 0xC5E5CE47
+l, m, M = wl.SHAPES[shape]
+cm, w = wl.synthetic_circuit(SEED + 11, l, m, M, 0.9, 3, profile="gates")
+rng = random.Random(SEED + 11)
+pk = cc.generate_parameters_with_qap(cm, *[rng.randrange(1, R) for _ in range(4)])
+ctx = cc.Prover(pk, cm, shard_rank=rank, shard_count=world)
+sp = ShardedProver(ctx, torch.device("cuda", 0))
+wd = torch.from_numpy(w).cuda()
+cases = [(rng.randrange(R), rng.randrange(R)), (0, 0), (rng.randrange(R), rng.randrange(R))]
+proofs = []
+for i, (r, s) in enumerate(cases):
+    proofs.append((sp.prove(w, r, s) if i == 1 else sp.prove_dev(wd.data_ptr(), r, s)).data.hex())
+res = {"rank": rank, "proofs": proofs, "all_gathers": sp.all_gathers, "n": len(cases), "breakdown_ms": sp.breakdown_ms(),
+       "info": ctx.info()["shard_count"]}
+if rank == 0:
+    import cpu_ref
+    res["want"] = [cpu_ref.prove(pk, (cm.a, cm.b, cm.c), l, m, M, w, r, s, nthreads=16).hex() for r, s in cases]
+barrier_sync(world)
+ctx.close()
+json.dump(res, open(out_path + ".%d" % rank, "w"))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("shape", ["medium", "rs256-sd"])
+def test_two_gloo_ranks_with_real_hip_shards_under_sharded_prover(shape, tmp_path):
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "res.json")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script), ROOT, shape, out]
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert run.returncode == 0, run.stderr[-3000:]
+    res = [json.load(open(out + ".%d" % k)) for k in range(2)]
+    want = res[0]["want"]
+    for r in res:
+        assert r["proofs"] == want, "rank %d assembled other bytes than the CPU restatement" % r["rank"]
+        assert r["all_gathers"] == r["n"] == 3              # exactly one collective per proof
+        assert r["info"] == 2
+    assert len(set(want)) == 3
+
+
+def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
+    """the driver's command, verbatim: no launcher around it.  One GPU here, so the ranks share it (gloo plumbing run);
+    the line must carry n_gpus = 2 and a `sharded` record whose proofs equal the unsharded ones."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "12", "--warmup", "2",
+           "--inflight", "4", "--blocks", "3", "--shape", "medium", "--no-host-witness", "--sharded-steps", "6"]
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [x for x in run.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1, run.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 12 and d["value"] > 0 and d["timing"]["blocks"] == 3
+    sh = d["sharded"]
+    assert sh["ranks"] == 2 and sh["backend"] == "gloo" and sh["bytes_identical_to_unsharded"] is True
+    assert sh["all_gathers"] == sh["proofs"] == 6 and set(sh["ms_breakdown_rank0"]) == {"partial", "gather", "assemble"}
+    # and with RCCL two ranks cannot share the one GPU: refused up front with a message, not a hang
+    if __import__("torch").cuda.device_count() == 1:
+        run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=env,
+                             capture_output=True, text=True, timeout=300)
+        assert run.returncode == 2 and "one GPU per rank" in run.stderr

@@ -24,8 +24,13 @@ fa = [x[2] for x in f if is_acc(x[0])]
 wa = [x[2] for x in w if is_acc(x[0])]
 fetch_kb = sum(fa) / len(fa)
 write_kb = sum(wa) / len(wa)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "crescent-credentials_amd"))
+import build as cg_build   # noqa: E402  (the package directory has a hyphen: imported by path)
 entry = {
     "command": cmd,
+    # the kernel sources + compiler flags these counts were taken on; bench.py nulls what it derives from them when the
+    # tree it runs on differs
+    "csrc_sha16": cg_build.source_fingerprint(),
     "steady_state_proofs": {"fetch": nf, "write": nw, "valu": nv},
     "accum_affine_g1_launches_measured": len(fa),
     "accum_affine_g1_fetch_kb_per_launch": round(fetch_kb, 1),

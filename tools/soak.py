@@ -3,7 +3,7 @@
 byte for byte with the proof a single-slot (latency) context made for the same (assignment, r, s).  Catches rare
 order-dependence in the grouping / accumulation under load.   usage: python tools/soak.py [N=4000] [T=12]"""
 import os, random, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from concurrent.futures import ThreadPoolExecutor
 import numpy as np, torch
