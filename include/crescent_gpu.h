@@ -194,7 +194,8 @@ typedef struct cg_ctx_info {
     int32_t tuned;               /* 1 once the assignment-driven windows were re-chosen from a proof's digit statistics */
     int32_t retune_skipped_for_memory; /* queries whose re-tuned table did not fit beside the old one: they keep the size-based window */
     int32_t retune_attempts;     /* proofs inspected for the re-tune so far (it gives up after a few degenerate ones) */
-    int32_t shard_rank, shard_count;
+    int32_t shard_rank;
+    int32_t shard_count;
     int32_t latency_mode;        /* 1: short accumulation segments + tree reductions (one proof at a time); 0: throughput */
     int32_t reserved[4];
 } cg_ctx_info;

@@ -85,6 +85,31 @@ fn map_err(rc: i32) -> SynthesisError {
     }
 }
 
+/// Page-locked host bytes from `cg_host_alloc`, freed with `cg_host_free`.
+struct PinnedBytes {
+    ptr: *mut u8,
+    len: usize,
+}
+impl PinnedBytes {
+    fn new(len: usize) -> Result<Self, SynthesisError> {
+        let p = unsafe { sys::cg_host_alloc(len as u64) } as *mut u8;
+        if p.is_null() {
+            eprintln!("crescent-gpu: {}", last_error());
+            return Err(SynthesisError::AssignmentMissing);
+        }
+        Ok(PinnedBytes { ptr: p, len })
+    }
+    #[allow(clippy::mut_from_ref)]
+    fn slice_mut(&self) -> &mut [u8] {
+        unsafe { std::slice::from_raw_parts_mut(self.ptr, self.len) }
+    }
+}
+impl Drop for PinnedBytes {
+    fn drop(&mut self) {
+        unsafe { sys::cg_host_free(self.ptr as *mut std::os::raw::c_void) }
+    }
+}
+
 pub struct GpuCircuit {
     ctx: *mut sys::cg_ctx,
     num_variables: usize,
@@ -144,18 +169,32 @@ impl GpuCircuit {
         if full_assignment.len() != self.num_variables {
             return Err(SynthesisError::AssignmentMissing);
         }
-        let mut w = Vec::with_capacity(full_assignment.len() * 32);
-        for x in full_assignment {
-            w.extend_from_slice(&x.into_bigint().to_bytes_le()); // prover.rs:64,71,86 take the same form
+        // the canonical bytes are written straight into page-locked memory (cg_host_alloc): cg_prove's upload is then
+        // one asynchronous DMA at PCIe speed that overlaps the other proofs in flight
+        let w = PinnedBytes::new(full_assignment.len() * 32)?;
+        for (i, x) in full_assignment.iter().enumerate() {
+            w.slice_mut()[i * 32..i * 32 + 32].copy_from_slice(&x.into_bigint().to_bytes_le()); // prover.rs:64,71,86 take the same form
         }
         let (rb, sb) = (r.into_bigint().to_bytes_le(), s.into_bigint().to_bytes_le());
         let mut out = [0u8; 256];
-        let rc = unsafe { sys::cg_prove(self.ctx, w.as_ptr(), rb.as_ptr(), sb.as_ptr(), out.as_mut_ptr(), std::ptr::null_mut()) };
+        let rc = unsafe { sys::cg_prove(self.ctx, w.ptr as *const u8, rb.as_ptr(), sb.as_ptr(), out.as_mut_ptr(), std::ptr::null_mut()) };
         if rc != 0 {
             return Err(map_err(rc));
         }
         // a ‖ b ‖ c, ark-serialize uncompressed (data_structures.rs:7-14)
         Proof::deserialize_uncompressed_unchecked(&out[..]).map_err(|_| SynthesisError::MalformedVerifyingKey)
+    }
+}
+
+impl GpuCircuit {
+    /// What the circuit occupies on the GPU and how its MSMs are configured (`cg_ctx_get_info`).
+    pub fn info(&self) -> Result<sys::cg_ctx_info, SynthesisError> {
+        let mut i = sys::cg_ctx_info::default();
+        let rc = unsafe { sys::cg_ctx_get_info(self.ctx, &mut i) };
+        if rc != 0 {
+            return Err(map_err(rc));
+        }
+        Ok(i)
     }
 }
 
@@ -181,33 +220,52 @@ impl Drop for QapHandle {
 }
 
 /// Matrices are constants of a credential type but arrive by reference on every call (r1cs_to_qap.rs:150-155), so the
-/// resident copy is looked up by a fingerprint of their content: shape, non-zero counts and every 1024th term.
+/// resident copy is looked up by a digest of their WHOLE content: the shape, the non-zero counts and two independent
+/// 64-bit FNV-1a passes over every term (all four limbs of every coefficient, every column index, every row boundary).
+/// One pass over the 17 M terms of a full-size circuit costs a few tens of milliseconds - the reference's own call spends
+/// seconds in the transforms it replaces.  (Round 2 sampled every 1024th term: two circuits of the same shape that
+/// differed in an unsampled coefficient would have shared a resident copy and produced a wrong h without an error.)
 fn fingerprint<F: PrimeField>(m: &ConstraintMatrices<F>) -> [u64; 8] {
-    let mut f = [
-        m.num_instance_variables as u64, m.num_witness_variables as u64, m.num_constraints as u64,
-        m.a_num_non_zero as u64, m.b_num_non_zero as u64, m.c_num_non_zero as u64, 0, 0,
-    ];
-    let mut t = 0u64;
+    const P: u64 = 0x0000_0100_0000_01b3; // FNV-1a 64 prime
+    let (mut h1, mut h2) = (0xcbf2_9ce4_8422_2325u64, 0x8422_2325_cbf2_9ce4u64);
+    let mut eat = |v: u64| {
+        h1 = (h1 ^ v).wrapping_mul(P);
+        h2 = (h2 ^ v.rotate_left(29) ^ 0x9e37_79b9_7f4a_7c15).wrapping_mul(P).rotate_left(5);
+    };
     for mat in [&m.a, &m.b, &m.c] {
         for row in mat.iter() {
+            eat(0xffff_ffff_0000_0000 | row.len() as u64); // row boundary
             for (c, j) in row {
-                if t % 1024 == 0 {
-                    let limb = c.into_bigint().as_ref()[0];
-                    f[6] = f[6].rotate_left(7) ^ limb;
-                    f[7] = f[7].wrapping_mul(0x9e3779b97f4a7c15).wrapping_add(*j as u64);
+                for limb in c.into_bigint().as_ref() {
+                    eat(*limb);
                 }
-                t += 1;
+                eat(*j as u64);
             }
         }
+        eat(0x5a5a_5a5a_5a5a_5a5a); // matrix boundary
     }
-    f
+    [
+        m.num_instance_variables as u64, m.num_witness_variables as u64, m.num_constraints as u64,
+        m.a_num_non_zero as u64, m.b_num_non_zero as u64, m.c_num_non_zero as u64, h1, h2,
+    ]
+}
+
+/// At most this many circuits keep a device copy of their matrices; the least recently used one is dropped first.  A
+/// dropped entry's `cg_qap_free` runs when its last `Arc` holder (a call still in flight) lets go - never under a caller.
+const QAP_CACHE_MAX: usize = 4;
+struct QapCache {
+    tick: u64,
+    entries: HashMap<[u64; 8], (u64, Arc<QapHandle>)>, // key -> (last use, handle)
 }
 fn qap_for<F: PrimeField>(m: &ConstraintMatrices<F>) -> Result<Arc<QapHandle>, SynthesisError> {
-    static CACHE: OnceLock<Mutex<HashMap<[u64; 8], Arc<QapHandle>>>> = OnceLock::new();
+    static CACHE: OnceLock<Mutex<QapCache>> = OnceLock::new();
     let key = fingerprint(m);
-    let mut cache = CACHE.get_or_init(|| Mutex::new(HashMap::new())).lock().unwrap();
-    if let Some(h) = cache.get(&key) {
-        return Ok(h.clone());
+    let mut cache = CACHE.get_or_init(|| Mutex::new(QapCache { tick: 0, entries: HashMap::new() })).lock().unwrap();
+    cache.tick += 1;
+    let now = cache.tick;
+    if let Some(e) = cache.entries.get_mut(&key) {
+        e.0 = now;
+        return Ok(e.1.clone());
     }
     let rc = unsafe { sys::cg_init(0, std::ptr::null()) };
     if rc != 0 {
@@ -224,7 +282,11 @@ fn qap_for<F: PrimeField>(m: &ConstraintMatrices<F>) -> Result<Arc<QapHandle>, S
         return Err(map_err(rc));
     }
     let h = Arc::new(QapHandle(ctx));
-    cache.insert(key, h.clone());
+    cache.entries.insert(key, (now, h.clone()));
+    while cache.entries.len() > QAP_CACHE_MAX {
+        let oldest = *cache.entries.iter().min_by_key(|(_, v)| v.0).map(|(k, _)| k).unwrap();
+        cache.entries.remove(&oldest); // the Arc drops here, or with the last call still using it
+    }
     Ok(h)
 }
 
@@ -323,4 +385,27 @@ pub fn msm_g1(bases: &[G1Affine], scalars: &[Fr]) -> Result<G1Affine, SynthesisE
     let x = Fq::from_le_bytes_mod_order(&out[..32]);
     let y = Fq::from_le_bytes_mod_order(&out[32..]);
     Ok(G1Affine::new_unchecked(x, y))
+}
+
+/// `<G2 as VariableBaseMSM>::msm_bigint` for the show-step sized sums over G2 (forks/ark-poly-commit/src/kzg10/mod.rs:196-290
+/// commits in G1; the verifier-side G2 sums of creds/src/utils.rs:124-138 callers are this shape): one-shot.
+pub fn msm_g2(bases: &[G2Affine], scalars: &[Fr]) -> Result<G2Affine, SynthesisError> {
+    let b = pack_g2(bases);
+    let mut sc = Vec::with_capacity(scalars.len() * 32);
+    for x in scalars {
+        sc.extend_from_slice(&x.into_bigint().to_bytes_le());
+    }
+    let mut out = [0u8; 128];
+    let rc = unsafe {
+        sys::cg_msm_g2(b.as_ptr(), sys::CG_FORM_MONTGOMERY, bases.len() as u64, sc.as_ptr(), scalars.len() as u64, 0, out.as_mut_ptr())
+    };
+    if rc != 0 {
+        return Err(map_err(rc));
+    }
+    if out.iter().all(|v| *v == 0) {
+        return Ok(G2Affine::identity());
+    }
+    let x = Fq2::new(Fq::from_le_bytes_mod_order(&out[..32]), Fq::from_le_bytes_mod_order(&out[32..64]));
+    let y = Fq2::new(Fq::from_le_bytes_mod_order(&out[64..96]), Fq::from_le_bytes_mod_order(&out[96..]));
+    Ok(G2Affine::new_unchecked(x, y))
 }

@@ -72,6 +72,26 @@ pub struct cg_timings {
     pub accum_g2_launches: u32,
 }
 
+#[repr(C)]
+#[derive(Default, Clone, Copy, Debug)]
+pub struct cg_ctx_info {
+    pub table_bytes: u64,
+    pub matrix_bytes: u64,
+    pub slot_bytes: u64,
+    pub total_bytes: u64,
+    pub device_free_bytes: u64,
+    pub device_total_bytes: u64,
+    pub proof_slots: i32,
+    pub window_bits: [i32; 5],
+    pub tuned: i32,
+    pub retune_skipped_for_memory: i32,
+    pub retune_attempts: i32,
+    pub shard_rank: i32,
+    pub shard_count: i32,
+    pub latency_mode: i32,
+    pub reserved: [i32; 4],
+}
+
 pub enum cg_ctx {}
 pub enum cg_msm_ctx {}
 pub enum cg_qap_ctx {}
@@ -97,6 +117,9 @@ extern "C" {
         proof_out: *mut u8,
         timings: *mut cg_timings,
     ) -> c_int;
+    pub fn cg_host_alloc(bytes: u64) -> *mut c_void;
+    pub fn cg_host_free(p: *mut c_void);
+    pub fn cg_ctx_get_info(ctx: *mut cg_ctx, out: *mut cg_ctx_info) -> c_int;
     pub fn cg_witness_map(ctx: *mut cg_ctx, full_assignment: *const u8, h_out: *mut u8) -> c_int;
     pub fn cg_domain_size(ctx: *const cg_ctx) -> u64;
     pub fn cg_qap_load(
@@ -117,6 +140,15 @@ extern "C" {
     pub fn cg_qap_domain_size(ctx: *const cg_qap_ctx) -> u64;
     pub fn cg_qap_free(ctx: *mut cg_qap_ctx);
     pub fn cg_msm_g1(
+        bases: *const u8,
+        coord_form: u32,
+        n_bases: u64,
+        scalars: *const u8,
+        n_scalars: u64,
+        window_bits: i32,
+        out: *mut u8,
+    ) -> c_int;
+    pub fn cg_msm_g2(
         bases: *const u8,
         coord_form: u32,
         n_bases: u64,

@@ -241,7 +241,7 @@ def test_rust_shim_bindings_match_header():
     rs = open(os.path.join(ROOT, "integration", "rust", "crescent-gpu", "src", "sys.rs")).read()
     fns = re.findall(r"pub fn (cg_[a-z0-9_]+)\s*\(", rs)
     assert len(fns) >= 8 and set(fns) <= set(_declared_symbols())
-    for name in ("cg_proving_key", "cg_csr", "cg_options", "cg_timings"):
+    for name in ("cg_proving_key", "cg_csr", "cg_options", "cg_timings", "cg_ctx_info"):
         body = re.search(r"pub struct %s \{(.*?)\n\}" % name, rs, flags=re.S).group(1)
         fields = re.findall(r"pub (\w+):", body)
         assert fields == _c_struct_fields(name), name
@@ -250,6 +250,10 @@ def test_rust_shim_bindings_match_header():
     assert [f for f, _ in api._CgOptions._fields_] == _c_struct_fields("cg_options")
     assert [f for f, _ in api.CgTimings._fields_] == _c_struct_fields("cg_timings")
     assert [f for f, _ in api._CgProvingKey._fields_] == _c_struct_fields("cg_proving_key")
+    assert [f for f, _ in api.CgCtxInfo._fields_] == _c_struct_fields("cg_ctx_info")
+    # the resident-matrices cache of the shim is keyed by a digest of EVERY term (round 2 sampled every 1024th) and bounded
+    lib_rs = open(os.path.join(ROOT, "integration", "rust", "crescent-gpu", "src", "lib.rs")).read()
+    assert "% 1024" not in lib_rs and "QAP_CACHE_MAX" in lib_rs and "cg_host_alloc" in lib_rs
 
 
 def test_parsers_survive_mutated_input(cc, oracle):
