@@ -78,6 +78,9 @@ def parse():
                     help="proofs in flight per GPU: host threads x context proof_slots (4: 169, 8: 173, 12: 174, 16: 176 proofs/s "
                          "on one box, profiles/r02_j_inflight_and_tuning.txt)")
     ap.add_argument("--assignments", type=int, default=4, help="device-resident assignments the timed proofs rotate over")
+    ap.add_argument("--no-clock-probe", action="store_true",
+                    help="do not sample the shader clock during the timed proofs (profiling runs: under rocprofv3 --pmc kernels "
+                         "are serialised and the probe's sleeping wave would hold the others up)")
     ap.add_argument("--blocks", type=int, default=0, help="timed blocks of --steps proofs (0 = enough for 240 proofs, at least 5, odd)")
     return ap.parse_args()
 
@@ -345,7 +348,7 @@ def main():
 
     blocks = n_blocks(a)
     prime(prove_dev_k)
-    clock = ClockSampler(cc, local_rank) if rank == 0 else None
+    clock = ClockSampler(cc, local_rank) if rank == 0 and not a.no_clock_probe else None
     dt, timing = measure(prove_dev_k, a.steps, a.warmup, blocks, True, clock)
     value = a.steps * world / dt
     dt_br = bracketed(prove_dev_k, a.steps, True)
@@ -549,30 +552,46 @@ def main():
             wall = time.perf_counter() - t_c
             same = cpu_proof == gpu_proof
             g1_s = sum(ctm.get(k, 0.0) for k in ("msm_h_s", "msm_l_s", "msm_a_s", "msm_b1_s"))
-            # one thread: the a-query G1 MSM of the same proof (M - 1 pairs) - a bounded sample; a whole proof on one
-            # thread would take about a minute
+            # one thread: the a-query G1 MSM of the same proof (M - 1 pairs) - a bounded sample; a whole proof of this size on
+            # one thread would take about a minute, so the whole-proof one-thread figure is taken at an eighth of the size
             t1 = time.perf_counter()
             cpu_ref.msm_g1(pk.a_query[64:], w_np[32:], nthreads=1)
             one_thread_s = time.perf_counter() - t1
+            l8, m8, M8 = wl.SHAPES["rs256-sd-eighth"]
+            cm8, w8 = wl.synthetic_circuit(0xC5E5CE47 + 88, l8, m8, M8, a.bits, 3, profile=a.profile)
+            pk8 = cc.generate_parameters_with_qap(cm8, *trap)
+            r8, s8 = fresh_rs()
+            p8 = cc.Prover(pk8, cm8, device=local_rank)
+            gpu8 = p8.prove(w8, r8, s8).data
+            p8.close()
+            cpu8, ctm8 = cpu_ref.prove(pk8, (cm8.a, cm8.b, cm8.c), l8, m8, M8, w8, r8, s8, nthreads=1, timings=True)
+            same8 = cpu8 == gpu8
             out["cpu_baseline"] = {
                 "value": round(1.0 / ctm["total_s"], 5), "unit": "proofs/s", "cores": threads, "host_threads_available": cores,
                 "kind": "port",
                 "sample": "1 full proof of the SAME workload (same key, assignment, r, s) by oracle/cpu_ref.c, the "
-                          "arkworks-equivalent C restatement, on %d threads of this %d-thread host "
-                          "(Pippenger c = ln(n) + 2 with one task per window as arkworks has it, so <= 16 threads work during "
-                          "an MSM; blocked radix-2 NTT and row-parallel sparse products on all threads): %.2fs prove "
-                          "(+ %.2fs key decode, not counted)" % (threads, cores, ctm["total_s"], ctm["load_s"]),
+                          "arkworks-equivalent C restatement, on %d threads - every CPU this process may use: %d hardware threads "
+                          "visible, cgroup quota %s - (Pippenger c = ln(n) + 2 with one task per window as arkworks has it, so <= 16 "
+                          "threads work during an MSM; four-step radix-2 NTT and row-parallel sparse products on all threads): "
+                          "%.2fs prove (+ %.2fs key decode, not counted)" %
+                          (threads, cores, cpu_ref.cpu_quota(), ctm["total_s"], ctm["load_s"]),
                 "proof_bytes_identical_to_gpu": bool(same),
                 "phase_s": {k: round(v, 3) for k, v in ctm.items()}, "wall_s": round(wall, 2),
                 "g1_msm_scalar_adds_per_s": round(g1_pairs / g1_s, 1) if g1_s > 0 else None,
                 "one_thread": {"sample": "the a-query G1 MSM of the same proof (%d pairs) on 1 thread" % (M - 1),
-                               "seconds": round(one_thread_s, 3), "g1_msm_scalar_adds_per_s": round((M - 1) / one_thread_s, 1)},
+                               "seconds": round(one_thread_s, 3), "g1_msm_scalar_adds_per_s": round((M - 1) / one_thread_s, 1),
+                               "whole_proof": {"sample": "1 full proof of the same gate mix at an eighth of the size (D = 2^18, m = %d, "
+                                                         "M = %d, l = %d) on 1 thread" % (m8, M8, l8),
+                                               "seconds": round(ctm8["total_s"], 3), "proofs_per_s": round(1.0 / ctm8["total_s"], 5),
+                                               "phase_s": {k: round(v, 3) for k, v in ctm8.items()},
+                                               "proof_bytes_identical_to_gpu": bool(same8)}},
+                "cpu_quota": cpu_ref.cpu_quota() if cpu_ref.cpu_quota() != float("inf") else None,
                 "gpu_over_cpu": round(value / (1.0 / ctm["total_s"]), 1)}
             # no published number exists for this metric (none in the tree); the only baseline there is is
             # this same-run CPU restatement, and the ratio to it is what the field carries - named for what it is
             out["vs_baseline"] = out["cpu_baseline"]["gpu_over_cpu"]
             out["vs_baseline_kind"] = "value / cpu_baseline.value of this run (BASELINE.json publishes no number for this metric)"
-            assert same, "CPU restatement and HIP path disagree on the proof bytes"
+            assert same and same8, "CPU restatement and HIP path disagree on the proof bytes"
         except Exception as e:  # the baseline is a reported number, never the thing measured
             out["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
             if isinstance(e, AssertionError):

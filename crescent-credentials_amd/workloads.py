@@ -19,6 +19,7 @@ SHAPES = {
     "rs256-sd-large": (26, 3_000_000 - 26 - 20_000, 3_000_000),  # S22 stress variant
     "rs256-db": (28, 1_480_000, 1_500_000),
     "mdl1": (21, 2_980_000, 3_000_000),        # S22, D = 2^22
+    "rs256-sd-eighth": (26, 185_000, 187_500),   # D = 2^18: the rs256-sd proportions at an eighth of the size (one-thread CPU sample)
     "tiny": (4, 200, 240),
     "small": (6, 3_000, 3_100),                # D = 2^12
     "medium": (20, 60_000, 61_000),            # D = 2^16

@@ -95,38 +95,34 @@ static inline void fe_neg(const field_t* F, fe* r, const fe* a) {
     fe_sub(F, r, &z, a);
 }
 static inline void fe_dbl(const field_t* F, fe* r, const fe* a) { fe_add(F, r, a, a); }
-/* Montgomery multiplication, coarsely integrated operand scanning; always inlined so that the field constants
- * fold in and the loops unroll (the shape of ark-ff's generated code for a 4-limb modulus) */
+/* Montgomery multiplication: coarsely integrated operand scanning in the "no-carry" form ark-ff generates for a modulus
+ * whose top bit is clear (both BN254 moduli are below 2^254): the running value never needs a fifth limb, so every
+ * step is one 64x64 -> 128 product plus two additions that cannot overflow 128 bits.  Always inlined: the field
+ * constants fold in and the sixteen + sixteen products unroll into mulx / adc chains (-mbmi2 -madx; arkworks' `asm`
+ * feature, creds/Cargo.toml:12-15, selects the same instructions). */
+#define CG_MM_STEP(I)                                                                     \
+    do {                                                                                  \
+        u128 p = (u128)a->l[0] * b->l[I] + t0;                                            \
+        uint64_t lo = (uint64_t)p, A = (uint64_t)(p >> 64);                               \
+        const uint64_t m = lo * F->ninv;                                                  \
+        p = (u128)m * F->n[0] + lo;                                                       \
+        uint64_t C = (uint64_t)(p >> 64);                                                 \
+        p = (u128)a->l[1] * b->l[I] + t1 + A; lo = (uint64_t)p; A = (uint64_t)(p >> 64);  \
+        p = (u128)m * F->n[1] + lo + C; t0 = (uint64_t)p; C = (uint64_t)(p >> 64);        \
+        p = (u128)a->l[2] * b->l[I] + t2 + A; lo = (uint64_t)p; A = (uint64_t)(p >> 64);  \
+        p = (u128)m * F->n[2] + lo + C; t1 = (uint64_t)p; C = (uint64_t)(p >> 64);        \
+        p = (u128)a->l[3] * b->l[I] + t3 + A; lo = (uint64_t)p; A = (uint64_t)(p >> 64);  \
+        p = (u128)m * F->n[3] + lo + C; t2 = (uint64_t)p; C = (uint64_t)(p >> 64);        \
+        t3 = C + A;                                                                       \
+    } while (0)
 static inline __attribute__((always_inline)) void fe_mul(const field_t* F, fe* r, const fe* a, const fe* b) {
-    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
-_Pragma("GCC unroll 4")
-    for (int i = 0; i < 4; ++i) {
-        u128 c = 0;
-_Pragma("GCC unroll 4")
-        for (int j = 0; j < 4; ++j) {
-            c += (u128)a->l[j] * b->l[i] + t[j];
-            t[j] = (uint64_t)c;
-            c >>= 64;
-        }
-        c += t[4];
-        t[4] = (uint64_t)c;
-        t[5] = (uint64_t)(c >> 64);
-        uint64_t m = t[0] * F->ninv;
-        c = (u128)m * F->n[0] + t[0];
-        c >>= 64;
-_Pragma("GCC unroll 4")
-        for (int j = 1; j < 4; ++j) {
-            c += (u128)m * F->n[j] + t[j];
-            t[j - 1] = (uint64_t)c;
-            c >>= 64;
-        }
-        c += t[4];
-        t[3] = (uint64_t)c;
-        t[4] = t[5] + (uint64_t)(c >> 64);
-    }
-    if (t[4] || ge_mod(t, F->n)) sub_mod_raw(t, F->n);
+    uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    CG_MM_STEP(0); CG_MM_STEP(1); CG_MM_STEP(2); CG_MM_STEP(3);
+    uint64_t t[4] = {t0, t1, t2, t3};
+    if (ge_mod(t, F->n)) sub_mod_raw(t, F->n);
     memcpy(r->l, t, 32);
 }
+#undef CG_MM_STEP
 static inline void fe_sqr(const field_t* F, fe* r, const fe* a) { fe_mul(F, r, a, a); }
 static void fe_pow(const field_t* F, fe* r, const fe* a, const uint64_t e[4]) {
     fe acc = F->one;
@@ -356,65 +352,93 @@ static uint64_t bitrev(uint64_t x, int bits) {
     for (int i = 0; i < bits; ++i) { r = (r << 1) | (x & 1); x >>= 1; }
     return r;
 }
+/* in place, natural order in and out: x[k] <- Σ_j x[j] root^{jk} over m = 2^logm points that fit the cache: the textbook
+ * loop (bit reversal, then log m decimation-in-time stages); tw[i] = root^i for i < m/2.  One thread. */
+static void ntt_small(fe* x, int logm, const fe* tw) {
+    const uint64_t m = 1ull << logm;
+    for (uint64_t i = 0; i < m; ++i) {
+        uint64_t j = bitrev(i, logm);
+        if (i < j) { fe t = x[i]; x[i] = x[j]; x[j] = t; }
+    }
+    for (int s = 1; s <= logm; ++s) {
+        const uint64_t len = 1ull << s, half = len >> 1, step = m / len;
+        for (uint64_t i0 = 0; i0 < m; i0 += len)
+            for (uint64_t k = 0; k < half; ++k) {
+                fe v, u = x[i0 + k];
+                fe_mul(&FR, &v, &x[i0 + k + half], &tw[k * step]);
+                fe_add(&FR, &x[i0 + k], &u, &v);
+                fe_sub(&FR, &x[i0 + k + half], &u, &v);
+            }
+    }
+}
+static void powers_table(fe* tw, uint64_t count, const fe* root) {
+    fe p = FR.one;
+    for (uint64_t i = 0; i < count; ++i) { tw[i] = p; fe_mul(&FR, &p, &p, root); }
+}
+/* dst (cols x rows) = transpose of src (rows x cols), tile by tile */
+static void transpose(fe* dst, const fe* src, uint64_t rows, uint64_t cols, int nthreads) {
+    const uint64_t B = 16;
+    _Pragma("omp parallel for collapse(2) schedule(static) num_threads(nthreads)")
+    for (uint64_t r0 = 0; r0 < rows; r0 += B)
+        for (uint64_t c0 = 0; c0 < cols; c0 += B) {
+            const uint64_t r1 = r0 + B < rows ? r0 + B : rows, c1 = c0 + B < cols ? c0 + B : cols;
+            for (uint64_t r = r0; r < r1; ++r)
+                for (uint64_t c = c0; c < c1; ++c) dst[c * rows + r] = src[r * cols + c];
+        }
+}
 /* in place, natural order in and out: a[k] <- Σ_j a[j] w^{jk}.
- * Same butterflies as the textbook loop (bit reversal, then log n decimation-in-time stages), arranged the way a
- * multi-core radix-2 library runs them (ark-poly's parallel FFT splits the same way): the powers of w come from
- * per-thread geometric runs, the first NTT_BLOCK_LOG stages run block by block inside the cache, and each later
- * stage is one parallel sweep with unit-stride inner loops. */
-#define NTT_BLOCK_LOG 12
+ * The same transform as ark-poly's radix-2 domain computes, arranged so that every thread works on its own data between
+ * a handful of joins (the four-step form: n = n1·n2, j = j1·n2 + j2, k = k1 + n1·k2):
+ *     A[k1 + n1·k2] = Σ_{j2} w^{j2·k1} · ( Σ_{j1} a[j1·n2 + j2] · (w^{n2})^{j1·k1} ) · (w^{n1})^{j2·k2}
+ *   1. transpose to n2 x n1;  2. n2 independent in-cache transforms of size n1, each element then times w^{j2·k1};
+ *   3. transpose back to n1 x n2;  4. n1 independent in-cache transforms of size n2;  5. transpose into natural order.
+ * Every row transform is a statically assigned, independent task: the butterfly stages themselves need no barrier (round
+ * 2's stage-by-stage sweeps joined all threads log n - 12 times per transform).  The arithmetic is exact, so the values
+ * are those of any other radix-2 evaluation order. */
 static void ntt_inplace(fe* a, int logn, const fe* w, int nthreads) {
     const uint64_t n = 1ull << logn;
     if (n == 1) return;
-    _Pragma("omp parallel for schedule(static) num_threads(nthreads)")
-    for (uint64_t i = 0; i < n; ++i) {
-        uint64_t j = bitrev(i, logn);
-        if (i < j) { fe t = a[i]; a[i] = a[j]; a[j] = t; }
+    if (logn < 6) {                                    /* too small to split */
+        fe* tw = (fe*)malloc(sizeof(fe) * (n / 2));
+        powers_table(tw, n / 2, w);
+        ntt_small(a, logn, tw);
+        free(tw);
+        return;
     }
-    const uint64_t nh = n / 2;
-    fe* tw = (fe*)malloc(sizeof(fe) * nh);
+    const int log1 = logn / 2, log2 = logn - log1;
+    const uint64_t n1 = 1ull << log1, n2 = 1ull << log2;
+    fe w1 = *w, w2 = *w;                               /* w1 = w^{n2} (order n1), w2 = w^{n1} (order n2) */
+    for (int i = 0; i < log2; ++i) fe_sqr(&FR, &w1, &w1);
+    for (int i = 0; i < log1; ++i) fe_sqr(&FR, &w2, &w2);
+    fe* tw1 = (fe*)malloc(sizeof(fe) * (n1 / 2));
+    fe* tw2 = (fe*)malloc(sizeof(fe) * (n2 / 2));
+    powers_table(tw1, n1 / 2, &w1);
+    powers_table(tw2, n2 / 2, &w2);
+    fe* t = (fe*)malloc(sizeof(fe) * n);
+    transpose(t, a, n1, n2, nthreads);                 /* t[j2][j1] */
     _Pragma("omp parallel num_threads(nthreads)")
     {
-        int t = omp_get_thread_num(), T = omp_get_num_threads();
-        uint64_t lo = nh * t / T, hi = nh * (t + 1) / T;
+        const int id = omp_get_thread_num(), T = omp_get_num_threads();
+        const uint64_t lo = n2 * id / T, hi = n2 * (id + 1) / T;
         if (lo < hi) {
             uint64_t e[4] = {lo, 0, 0, 0};
-            fe p; fe_pow(&FR, &p, w, e);
-            for (uint64_t i = lo; i < hi; ++i) { tw[i] = p; fe_mul(&FR, &p, &p, w); }
-        }
-    }
-    const int blk_log = logn < NTT_BLOCK_LOG ? logn : NTT_BLOCK_LOG;
-    const uint64_t blk = 1ull << blk_log;
-    _Pragma("omp parallel for schedule(static) num_threads(nthreads)")
-    for (uint64_t b0 = 0; b0 < n; b0 += blk) {
-        fe* x = a + b0;
-        for (int s = 1; s <= blk_log; ++s) {
-            const uint64_t len = 1ull << s, half = len >> 1, step = n / len;
-            for (uint64_t i0 = 0; i0 < blk; i0 += len)
-                for (uint64_t k = 0; k < half; ++k) {
-                    fe v, u = x[i0 + k];
-                    fe_mul(&FR, &v, &x[i0 + k + half], &tw[k * step]);
-                    fe_add(&FR, &x[i0 + k], &u, &v);
-                    fe_sub(&FR, &x[i0 + k + half], &u, &v);
-                }
-        }
-    }
-    for (int s = blk_log + 1; s <= logn; ++s) {
-        const uint64_t len = 1ull << s, half = len >> 1, step = n / len;
-        const uint64_t chunk = 1024;                       /* butterflies per task; half >= 4096 here */
-        _Pragma("omp parallel for schedule(static) num_threads(nthreads)")
-        for (uint64_t c0 = 0; c0 < nh; c0 += chunk) {
-            const uint64_t blkidx = c0 / half, k0 = c0 % half;
-            fe* x0 = a + blkidx * len + k0;
-            fe* x1 = x0 + half;
-            for (uint64_t k = 0; k < chunk; ++k) {
-                fe v, u = x0[k];
-                fe_mul(&FR, &v, &x1[k], &tw[(k0 + k) * step]);
-                fe_add(&FR, &x0[k], &u, &v);
-                fe_sub(&FR, &x1[k], &u, &v);
+            fe rho; fe_pow(&FR, &rho, w, e);           /* w^{j2} for the first row of this thread */
+            for (uint64_t j2 = lo; j2 < hi; ++j2) {
+                fe* x = t + j2 * n1;
+                ntt_small(x, log1, tw1);
+                fe p = rho;                            /* x[k1] *= w^{j2·k1} */
+                for (uint64_t k1 = 1; k1 < n1; ++k1) { fe_mul(&FR, &x[k1], &x[k1], &p); fe_mul(&FR, &p, &p, &rho); }
+                fe_mul(&FR, &rho, &rho, w);
             }
         }
     }
-    free(tw);
+    transpose(a, t, n2, n1, nthreads);                 /* a[k1][j2] */
+    _Pragma("omp parallel for schedule(static) num_threads(nthreads)")
+    for (uint64_t k1 = 0; k1 < n1; ++k1) ntt_small(a + k1 * n2, log2, tw2);
+    transpose(t, a, n1, n2, nthreads);                 /* t[k2][k1] = A[k1 + n1·k2] */
+    _Pragma("omp parallel for schedule(static) num_threads(nthreads)")
+    for (uint64_t i = 0; i < n; i += 4096) memcpy(a + i, t + i, sizeof(fe) * (n - i < 4096 ? n - i : 4096));
+    free(t); free(tw1); free(tw2);
 }
 typedef struct { int logn; uint64_t n; fe w, winv, ninv, g, ginv; } domain_t;
 static void domain_init(domain_t* d, int logn) {

@@ -51,6 +51,35 @@ def num_procs() -> int:
     return lib().ref_num_procs()
 
 
+def cpu_quota() -> float:
+    """CPUs this process may actually use at once: the cgroup's quota / period (cgroup v2 cpu.max, v1 cpu.cfs_*), or
+    +inf without one.  The GPU boxes of this pool show 256 hardware threads and a quota of 16 CPUs: more runnable threads
+    than that are throttled by the kernel, which is what the 13 s witness map on 256 threads was
+    (profiles/r02_cpu_thread_scaling.txt), not a property of the code."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return float(q) / float(p)
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and p > 0:
+            return q / p
+    except Exception:
+        pass
+    return float("inf")
+
+
+def best_threads(visible=None) -> int:
+    """threads for the timed baseline: every CPU the process is allowed to use (visible threads capped by the cgroup quota)"""
+    import math
+    visible = visible or num_procs()
+    q = cpu_quota()
+    return max(1, min(visible, int(math.ceil(q)) if q != float("inf") else visible))
+
+
 def _u8(a):
     if isinstance(a, (bytes, bytearray)):
         a = np.frombuffer(bytes(a), dtype=np.uint8)

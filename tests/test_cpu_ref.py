@@ -80,6 +80,22 @@ def test_ntt_golden(ref, oracle):
             assert hashlib.sha256(val.tobytes()).hexdigest() == c["outputs_sha256"][k], (c["log_n"], k)
 
 
+@pytest.mark.parametrize("logn", [1, 5, 6, 7, 9, 12])
+def test_ntt_four_step_sizes_vs_oracle(ref, oracle, logn):
+    """the C restatement's transform is the four-step arrangement (n = n1·n2, independent row transforms between
+    transposes) from 2^6 up: odd exponents (n1 != n2), every thread count that does not divide the rows, all four
+    variants, against the plain big-int transform (ark-poly semantics, r1cs_to_qap.rs:179-185,198-199,210)"""
+    r = random.Random(77 + logn)
+    v = [r.randrange(oracle.R) for _ in range(1 << logn)]
+    d = _scalars(v)
+    want = dict(fft=oracle.fft(v), ifft=oracle.ifft(v), coset_fft=oracle.coset_fft(v), coset_ifft=oracle.coset_ifft(v))
+    for nt in (1, 3, 7):
+        got = dict(fft=ref.ntt(d, nthreads=nt), ifft=ref.ntt(d, inverse=True, nthreads=nt), coset_fft=ref.ntt(d, coset=True, nthreads=nt),
+                   coset_ifft=ref.ntt(d, inverse=True, coset=True, nthreads=nt))
+        for k in want:
+            assert got[k].tobytes() == _scalars(want[k]).tobytes(), (logn, nt, k)
+
+
 @pytest.mark.parametrize("idx", [0, 1, 2, 3])
 def test_msm_golden(ref, oracle, idx):
     c = load_golden("msm.json")["cases"][idx]

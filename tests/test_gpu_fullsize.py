@@ -29,7 +29,7 @@ def _init(cc):
 
 def _threads():
     import cpu_ref
-    return max(1, min(cpu_ref.num_procs(), 64))
+    return cpu_ref.best_threads()          # every CPU the cgroup allows (16 on the pool's boxes, whatever nproc says)
 
 
 def _workload(cc, oracle, shape, bit_fraction, seed_off):
