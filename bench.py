@@ -74,9 +74,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for plumbing tests)")
     ap.add_argument("--allow-shared-gpu", action="store_true",
                     help="N > visible GPUs: let several ranks share a GPU (implied by --backend gloo; RCCL needs a GPU per rank)")
-    ap.add_argument("--inflight", type=int, default=12,
-                    help="proofs in flight per GPU: host threads x context proof_slots (4: 169, 8: 173, 12: 174, 16: 176 proofs/s "
-                         "on one box, profiles/r02_j_inflight_and_tuning.txt)")
+    ap.add_argument("--inflight", type=int, default=16,
+                    help="proofs in flight per GPU: host threads x context proof_slots, one stream each (8: 185, 12: 194, 16: 197, "
+                         "20: 195 proofs/s on one box, profiles/r03_b_inflight_and_segments.txt)")
     ap.add_argument("--assignments", type=int, default=4, help="device-resident assignments the timed proofs rotate over")
     ap.add_argument("--no-clock-probe", action="store_true",
                     help="do not sample the shader clock during the timed proofs (profiling runs: under rocprofv3 --pmc kernels "

@@ -19,6 +19,7 @@
 //              folded on the host.
 // All curve arithmetic here runs on the lazy 29-bit-limb representation (field29.hpp / curve29.hpp).
 #include "msm.hpp"
+#include "g2pair.hpp"
 
 #include <cstring>
 
@@ -422,6 +423,16 @@ __global__ void __launch_bounds__(1024) k_part_plan(int bits1, int two_level, co
     if (threadIdx.x == 0) { chunk0[B1] = chunks; plan[PLAN_CHUNKS] = chunks; }
 }
 
+// a plan taken over with another engine's entries: the segment geometry is re-cut for THIS engine's accumulation kernel
+// (the entry list itself does not care where it is cut)
+__global__ void k_replan(uint32_t* __restrict__ plan, uint32_t target_segments, uint32_t min_L) {
+    const uint32_t N = plan[PLAN_N];
+    uint32_t L = (uint32_t)(((uint64_t)N + target_segments - 1) / target_segments);
+    if (L < min_L) L = min_L;
+    plan[PLAN_L] = L;
+    plan[PLAN_T] = N ? (N + L - 1) / L : 0;
+}
+
 template <int C>
 __global__ void __launch_bounds__(PART_THREADS) k_part_place(PartShape sh, const Fr* __restrict__ scalars, const uint8_t* __restrict__ valid,
                                                     const uint32_t* __restrict__ blk_hist, const uint32_t* __restrict__ start1,
@@ -760,13 +771,81 @@ k_accum_affine_g2(const uint64_t* __restrict__ entries, const uint32_t* __restri
     }
 }
 
+// ---- the same over Fq2 with every value split over a lane pair (g2pair.hpp): accumulator in registers, no LDS -----------
+// Lanes 2p and 2p + 1 take segment p together; they share every branch (same entries, same keys), so the DPP exchanges
+// inside pr_madd always find their partner active.
+#if defined(CG_G2PAIR_WAVES)     // A/B aid: force the occupancy target
+#define CG_G2PAIR_ATTR __attribute__((amdgpu_waves_per_eu(CG_G2PAIR_WAVES, CG_G2PAIR_WAVES)))
+#else
+#define CG_G2PAIR_ATTR
+#endif
+__global__ void __launch_bounds__(256) CG_G2PAIR_ATTR
+k_accum_affine_g2_pair(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ plan, const uint32_t* __restrict__ table,
+                       uint32_t* __restrict__ bucket_sums, uint32_t* __restrict__ part_keys, uint32_t* __restrict__ part_pts) {
+    constexpr int ACC = Words29<Fq2_29>::ACC;
+    const uint32_t N = plan[PLAN_N], L = plan[PLAN_L], T = plan[PLAN_T];
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = gt >> 1, half = gt & 1u, odd = 0u - half;
+    if (t >= T) return;
+    const bool final_level = (T == 1);
+    const uint32_t beg = t * L;
+    const uint32_t end = beg + L < N ? beg + L : N;
+    PairAcc acc;
+    bool inf = true;
+    uint64_t next_ent = entries[beg];                  // fetched an iteration ahead, as in k_accum_affine
+    uint32_t cur = (uint32_t)(next_ent >> 32);
+    bool first = true;
+    for (uint32_t k = beg; k < end; ++k) {
+        const uint64_t ent = next_ent;
+        if (k + 1 < end) next_ent = entries[k + 1];
+        const uint32_t key = (uint32_t)(ent >> 32), v = (uint32_t)ent;
+        if (key != cur) {
+            if (first && !final_level) {
+                part_keys[2 * t] = cur;
+                pr_store_acc(part_pts + (size_t)(2 * t) * ACC, acc, inf, half);
+            } else {
+                pr_store_acc(bucket_sums + (size_t)cur * ACC, acc, inf, half);
+            }
+            first = false;
+            inf = true;
+            cur = key;
+        }
+        pr_madd(acc, inf, table, v & 0x7fffffffu, half, (v >> 31) != 0, odd);
+    }
+    if (final_level) {
+        pr_store_acc(bucket_sums + (size_t)cur * ACC, acc, inf, half);
+    } else if (first) {  // the whole segment is one run
+        part_keys[2 * t] = cur;
+        pr_store_acc(part_pts + (size_t)(2 * t) * ACC, acc, inf, half);
+        part_keys[2 * t + 1] = cur;
+        pr_store_acc(part_pts + (size_t)(2 * t + 1) * ACC, acc, true, half);
+    } else {
+        part_keys[2 * t + 1] = cur;
+        pr_store_acc(part_pts + (size_t)(2 * t + 1) * ACC, acc, inf, half);
+    }
+}
+
+// Which G2 accumulation kernel an engine runs.  The lane-pair kernel (g2pair.hpp) is the faster one when it has the GPU to
+// itself - 3.15 against 3.35 ms on a full 2^20 G2 MSM, 0.55 against 0.66 ms on the 1.8 M entries of a circom-like
+// witness, i.e. 80 % against 68 % of its instruction floor at full occupancy - but it executes ~10 % more instructions
+// per addition (the lane exchanges and operand selects), and with a dozen proofs in flight every issue slot the one-lane
+// kernel leaves idle is taken by another proof's kernel: all-uniform witnesses prove at 77.2 proofs/s with the pair kernel
+// against 79.3 with the one-lane kernel, circom-like ones the same either way (profiles/r03_c_g2_lane_pair.txt).  So:
+// pair kernel for latency contexts (a lone proof, a shard), one-lane kernel for throughput contexts.  CG_G2_PAIR=1 / 0
+// forces either.
+static bool g2_pair_kernel(bool latency_mode) {
+    static const char* e = getenv("CG_G2_PAIR");
+    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+    return latency_mode;
+}
 // T_max: the largest segment count the plan can hold for this engine (lanes beyond the plan's T return at once)
 template <class F29T>
 static void launch_accum_affine(const uint64_t* entries, const uint32_t* plan, uint32_t T_max, const uint32_t* table, uint32_t* bucket_sums,
-                                uint32_t* part_keys, uint32_t* part_pts, hipStream_t st) {
-    if constexpr (Words29<F29T>::NF == 2)
-        k_accum_affine_g2<<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
-    else
+                                uint32_t* part_keys, uint32_t* part_pts, bool latency_mode, hipStream_t st) {
+    if constexpr (Words29<F29T>::NF == 2) {
+        if (!g2_pair_kernel(latency_mode)) k_accum_affine_g2<<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
+        else k_accum_affine_g2_pair<<<ceil_div(2ull * T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
+    } else
         k_accum_affine<F29T><<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
 }
 
@@ -1077,6 +1156,18 @@ __global__ void __launch_bounds__(256) k_bit_sums(const uint32_t* __restrict__ r
 // engine
 // ---------------------------------------------------------------------------------------------
 static constexpr uint32_t ACC_TARGET_THREADS = 256u * 4u * 4u * 64u;  // CUs x SIMDs x waves x lanes: one fully resident round
+// the G2 accumulation runs a lane PAIR per segment at CG_G2PAIR_WAVES waves per SIMD (g2pair.hpp): one resident round
+#if !defined(CG_G2PAIR_WAVES)
+#define CG_G2PAIR_RESIDENT_WAVES 2u
+#else
+#define CG_G2PAIR_RESIDENT_WAVES ((uint32_t)(CG_G2PAIR_WAVES))
+#endif
+static constexpr uint32_t ACC_TARGET_PAIRS = 256u * 4u * CG_G2PAIR_RESIDENT_WAVES * 64u / 2u;
+// segments of one fully resident round of the engine's accumulation kernel
+template <class F29T> static uint32_t acc_target_segments(bool latency_mode) {
+    if (Words29<F29T>::NF != 2) return ACC_TARGET_THREADS;
+    return g2_pair_kernel(latency_mode) ? ACC_TARGET_PAIRS : ACC_TARGET_THREADS;
+}
 // shortest segment.  Throughput: 64 - fewer, longer lanes for the small MSMs, whose pieces cost a wave-wide addition
 // each to combine (they run beside the h MSM, which fills the chip).  Latency (a shard of one proof): 16.
 static constexpr uint32_t ACC_MIN_L = 64, ACC_MIN_L_LATENCY = 16;
@@ -1124,7 +1215,7 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
         if (v >= 1 && v <= 4096) min_L = (uint32_t)v;
     }
     uint64_t t1 = (cap_entries + min_L - 1) / min_L;
-    if (t1 > ACC_TARGET_THREADS) t1 = ACC_TARGET_THREADS;
+    if (t1 > acc_target_segments<F29T>(latency_mode)) t1 = acc_target_segments<F29T>(latency_mode);
     max_segments = (uint32_t)t1;
     const uint64_t pa = 2 * t1, pb = 2 * ceil_div(t1, 64);   // two pieces per segment, then two per wave of 64 segments
     part_keys_a.alloc(pa); part_pts_a.alloc(pa * ACC);
@@ -1193,7 +1284,7 @@ void MsmEngine<F>::digits(const Fr* scalars_dev, uint64_t n, hipStream_t st) {
     fill_zero(counters.p, (counters.bytes() + 15) & ~(size_t)15, st);
     launch_part_level1(true, sh, tiles, (size_t)B1 * 4, st, scalars_dev, bases->valid.p, blk_hist.p, hist1, plan, nullptr, nullptr, nullptr);
     CG_KERNEL_CHECK();
-    k_part_plan<<<1, 1024, (size_t)B1 * 4, st>>>(bits1, bits2 ? 1 : 0, hist1, start1, chunk0, plan, ACC_TARGET_THREADS, min_L);
+    k_part_plan<<<1, 1024, (size_t)B1 * 4, st>>>(bits1, bits2 ? 1 : 0, hist1, start1, chunk0, plan, acc_target_segments<F29T>(latency_mode), min_L);
     CG_KERNEL_CHECK();
     launch_part_level1(false, sh, tiles, (size_t)B1 * 4, st, scalars_dev, bases->valid.p, blk_hist.p, nullptr, nullptr, start1, cur1, ent_a.p);
     CG_KERNEL_CHECK();
@@ -1217,6 +1308,8 @@ void MsmEngine<F>::adopt(const uint64_t* grouped_entries, const uint32_t* plan_d
     // the plan (entry count, segment geometry, statistics) travels with the entries; everything downstream reads it from
     // this engine's own counters as usual
     CG_HIP(hipMemcpyAsync(counters.p, plan_dev, PLAN_WORDS * 4, hipMemcpyDeviceToDevice, st));
+    k_replan<<<1, 1, 0, st>>>(counters.p, acc_target_segments<F29T>(latency_mode), min_L);
+    CG_KERNEL_CHECK();
     CG_HIP(hipEventRecord(ev_t[2], st));
     adopted = n ? grouped_entries : nullptr;
 }
@@ -1230,7 +1323,7 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
         const uint32_t* plan = counters.p;
         const uint64_t* grouped = adopted ? adopted : (bits2 ? ent_b.p : ent_a.p);
         CG_HIP(hipEventRecord(ev_t[3], st));
-        launch_accum_affine<F29T>(grouped, plan, max_segments, bases->table.p, bucket_sums.p, part_keys_a.p, part_pts_a.p, st);
+        launch_accum_affine<F29T>(grouped, plan, max_segments, bases->table.p, bucket_sums.p, part_keys_a.p, part_pts_a.p, latency_mode, st);
         CG_KERNEL_CHECK();
         CG_HIP(hipEventRecord(ev_t[4], st));
         // combine the segments' pieces wave by wave until one wave covers them all (k_combine_wave); the grids cover the

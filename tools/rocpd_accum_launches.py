@@ -29,7 +29,7 @@ def per_proof(rows, firsts, val):
         lo, hi = bounds[p], bounds[p + 1]
         acc = [r for r in rows if lo <= r[1] < hi and "k_accum_affine" in r[0]]
         for i, r in enumerate(acc):
-            kind = "G2" if ("Fq2" in r[0] or "_g2" in r[0]) else "G1"
+            kind = "G2" if ("Fq2_29" in r[0] or "_g2" in r[0]) else "G1"
             out.setdefault((i, kind), []).append(val(r))
     return out
 
