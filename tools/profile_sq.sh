@@ -20,7 +20,7 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" "SQ_WAIT_ANY SQ_W
   i=$((i+1))
   rocprofv3 --pmc $SET -d "$OUT/s$i" -o p -- python3 "$ROOT/bench.py" $FLAGS > "$OUT/s$i.line.json" 2> "$OUT/s$i.log"
   DB=$(find "$OUT/s$i" -name '*.db' | head -1)
-  if [ -n "$DB" ]; then echo >> "$OUT/sq_counters.md"; python3 "$ROOT/tools/rocpd_counters.py" "$DB" | head -14 >> "$OUT/sq_counters.md"; else echo "set $i ($SET): no database" >> "$OUT/sq_counters.md"; tail -3 "$OUT/s$i.log" >> "$OUT/sq_counters.md"; fi
+  if [ -n "$DB" ]; then echo >> "$OUT/sq_counters.md"; python3 "$ROOT/tools/rocpd_counters.py" "$DB" | head -14 >> "$OUT/sq_counters.md"; echo >> "$OUT/sq_counters.md"; python3 "$ROOT/tools/rocpd_counters_big_launch.py" "$DB" >> "$OUT/sq_counters.md"; else echo "set $i ($SET): no database" >> "$OUT/sq_counters.md"; tail -3 "$OUT/s$i.log" >> "$OUT/sq_counters.md"; fi
   rm -rf "$OUT/s$i"
 done
 cat "$OUT/sq_counters.md"
