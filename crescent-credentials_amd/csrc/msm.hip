@@ -465,14 +465,91 @@ __global__ void __launch_bounds__(PART_THREADS) k_part_place(PartShape sh, const
     }
 }
 
+// Level-1 placement staged through LDS, for the wide windows (C >= 18: at most 15 digits per scalar).  k_part_place hands every
+// entry to its bin with one 8-byte global store per lane - 64 stores to 64 different bins per wave instruction, 27 M
+// separate write transactions for the h MSM - which makes it the slowest kernel of the grouping (0.28 ms stand-alone
+// against 0.05 ms for the counting pass that does the same walk).  Here a block takes its tile in sub-tiles of 1024
+// scalars: the entries of a sub-tile stay in registers while they are counted by bin in LDS, are then placed bin by bin
+// into an LDS staging area, and leave it in RUNS: consecutive lanes write consecutive slots of the same bin (13 entries
+// = 104 contiguous bytes per bin and sub-tile at c = 20).  The block's range of every bin is reserved once, as before.
+static constexpr uint32_t STAGE_SUB = 1024;        // scalars per sub-tile = threads per block
+static constexpr int STAGE_MIN_C = 18;
+template <int C>
+__global__ void __launch_bounds__(PART_THREADS) k_part_place_staged(PartShape sh, const Fr* __restrict__ scalars, const uint8_t* __restrict__ valid,
+                                                           const uint32_t* __restrict__ blk_hist, const uint32_t* __restrict__ start1,
+                                                           uint32_t* __restrict__ cur1, uint64_t* __restrict__ out) {
+    constexpr int W = (SCALAR_BITS + C - 1) / C;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t B1 = 1u << sh.bits1;
+    uint32_t* gbase = lds;                 // [B1] next global slot of the bin for this block
+    uint32_t* cnt = lds + B1;              // [B1] entries of the sub-tile per bin, then the fill cursor
+    uint32_t* off = lds + 2 * B1;          // [B1] first staging slot of the bin
+    uint64_t* stage = reinterpret_cast<uint64_t*>(lds + 3 * B1 + (B1 & 1u));      // [STAGE_SUB * W]
+    const uint32_t* row = blk_hist + (size_t)blockIdx.x * B1;
+    for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) {
+        const uint32_t c = row[k];
+        gbase[k] = c ? start1[k] + atomicAdd(&cur1[(size_t)k * PART_PAD], c) : 0u;
+    }
+    const uint32_t base = blockIdx.x * PART_TILE;
+    for (uint32_t sub = 0; sub < PART_TILE / STAGE_SUB; ++sub) {
+        const uint32_t i = base + sub * STAGE_SUB + threadIdx.x;
+        for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) cnt[k] = 0;
+        __syncthreads();
+        uint64_t e[W];                     // entry of window j, or all ones: indexed by the unrolled walk's constant j
+#pragma unroll
+        for (int u = 0; u < W; ++u) e[u] = ~0ull;
+        if (i < sh.n && valid[i] != 0) {
+            const Fr sc = scalars[i];
+            for_each_digit_c<C>(sc.l, [&](int j, int32_t d) {
+                if (d == 0) return;
+                const uint32_t key = (uint32_t)(d < 0 ? -d : d) - 1u;
+                const uint32_t val = ((uint32_t)j * sh.row_stride + i) | (d < 0 ? 0x80000000u : 0u);
+                e[j] = ((uint64_t)key << 32) | val;
+                atomicAdd(&cnt[key >> sh.bits2], 1u);
+            });
+        }
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) off[k] = cnt[k];
+        __syncthreads();
+        const uint32_t total = block_exclusive_scan(off, B1);
+        for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) cnt[k] = off[k];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < W; ++u)
+            if (e[u] != ~0ull) stage[atomicAdd(&cnt[(uint32_t)(e[u] >> 32) >> sh.bits2], 1u)] = e[u];
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < total; k += blockDim.x) {
+            const uint64_t v = stage[k];
+            const uint32_t b = (uint32_t)(v >> 32) >> sh.bits2;
+            out[gbase[b] + (k - off[b])] = v;
+        }
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) gbase[k] += cnt[k] - off[k];
+        // the next sub-tile's zeroing of cnt is behind the barrier at the top of the loop; gbase is only read after the
+        // barriers that follow
+        __syncthreads();
+    }
+}
+
 // the two level-1 kernels, instantiated for the window sizes the prover meets (size-based defaults and re-tuned windows of
 // 10 .. 22 bits); any other window takes the run-time walk
 template <int C>
 static void launch_part_level1_c(bool count, const PartShape& sh, uint32_t tiles, size_t lds, hipStream_t st, const Fr* scalars,
                                  const uint8_t* valid, uint32_t* blk_hist, uint32_t* hist1, uint32_t* plan, const uint32_t* start1,
                                  uint32_t* cur1, uint64_t* out) {
-    if (count) k_part_count<C><<<tiles, PART_THREADS, lds, st>>>(sh, scalars, valid, blk_hist, hist1, plan);
-    else k_part_place<C><<<tiles, PART_THREADS, lds, st>>>(sh, scalars, valid, blk_hist, start1, cur1, out);
+    if (count) { k_part_count<C><<<tiles, PART_THREADS, lds, st>>>(sh, scalars, valid, blk_hist, hist1, plan); return; }
+    if constexpr (C >= STAGE_MIN_C) {
+        static const bool direct = getenv("CG_PLACE_DIRECT") != nullptr;      // A/B aid: the one-store-per-lane placement
+        if (!direct && sh.precomputed) {
+            constexpr int W = (SCALAR_BITS + C - 1) / C;
+            const uint32_t B1 = 1u << sh.bits1;
+            const size_t bytes = (size_t)(3 * B1 + (B1 & 1u)) * 4 + (size_t)STAGE_SUB * W * 8;
+            // (dynamic LDS above 64 KB needs no opt-in on this platform: k_part_place2 has always taken 80 KB)
+            k_part_place_staged<C><<<tiles, PART_THREADS, bytes, st>>>(sh, scalars, valid, blk_hist, start1, cur1, out);
+            return;
+        }
+    }
+    k_part_place<C><<<tiles, PART_THREADS, lds, st>>>(sh, scalars, valid, blk_hist, start1, cur1, out);
 }
 static void launch_part_level1(bool count, const PartShape& sh, uint32_t tiles, size_t lds, hipStream_t st, const Fr* scalars,
                                const uint8_t* valid, uint32_t* blk_hist, uint32_t* hist1, uint32_t* plan, const uint32_t* start1,
