@@ -295,16 +295,19 @@ def main():
         if sync_ranks:
             barrier_sync(world)
         t_start = time.perf_counter()
+        cpu0 = time.process_time()
         if clock is not None:
             with clock:
                 done = steady_stream(prove_k, total, threads)
         else:
             done = steady_stream(prove_k, total, threads)
+        cpu_busy = (time.process_time() - cpu0) / max(1e-9, time.perf_counter() - t_start)
         torch.cuda.synchronize()
         bt = sorted(block_times(done, warmup, steps, blocks, t_start))
         med = bt[len(bt) // 2]
         rec = {"blocks": blocks, "spread_pct": round((bt[-1] - bt[0]) / med * 100.0, 2),
-               "block_ms_min_median_max": [round(bt[0] * 1e3, 2), round(med * 1e3, 2), round(bt[-1] * 1e3, 2)]}
+               "block_ms_min_median_max": [round(bt[0] * 1e3, 2), round(med * 1e3, 2), round(bt[-1] * 1e3, 2)],
+               "host_cpus_busy": round(cpu_busy, 2)}     # process CPU seconds per second of the stream: what the callers cost the host
         if sync_ranks:
             barrier_sync(world)
             med = max_over_ranks(med, world, dev)

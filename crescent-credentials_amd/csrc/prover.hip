@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <exception>
 #include <functional>
+#include <thread>
 
 #include "msm.hpp"
 #include "ntt.hpp"
@@ -133,12 +134,15 @@ struct ProofSlot {
     hipStream_t st[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // 0: witness map + h, 1: l, 2: a, 3: b1, 4: b2
     hipEvent_t ev_w = nullptr;
     hipEvent_t ev_b1 = nullptr;        // b1's entries are grouped (the G2 MSM adopts them)
+    hipEvent_t ev_done = nullptr;      // one-stream slots: the proof's last kernel is done (a BLOCKING event, see wait_for_proof)
+    bool one_stream = false;
     hipEvent_t ev_t[2] = {nullptr, nullptr};
     ~ProofSlot() {
         for (int i = 0; i < 5; ++i)
             if (st[i] && (i == 0 || st[i] != st[0])) (void)hipStreamDestroy(st[i]);
         if (ev_w) (void)hipEventDestroy(ev_w);
         if (ev_b1) (void)hipEventDestroy(ev_b1);
+        if (ev_done) (void)hipEventDestroy(ev_done);
         for (auto& e : ev_t) if (e) (void)hipEventDestroy(e);
     }
 };
@@ -151,9 +155,11 @@ struct Upload {
     DevBuf<Fr> w;
     hipStream_t st = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
+    hipEvent_t ev_done = nullptr;      // blocking: the calling thread sleeps until its copy has landed
     ~Upload() {
         if (st) (void)hipStreamDestroy(st);
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        if (ev_done) (void)hipEventDestroy(ev_done);
     }
 };
 
@@ -447,6 +453,8 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
             }
             CG_HIP(hipEventCreateWithFlags(&sl->ev_w, hipEventDisableTiming));
             CG_HIP(hipEventCreateWithFlags(&sl->ev_b1, hipEventDisableTiming));
+            CG_HIP(hipEventCreateWithFlags(&sl->ev_done, hipEventDisableTiming | hipEventBlockingSync));
+            sl->one_stream = serial;
             for (auto& e : sl->ev_t) CG_HIP(hipEventCreate(&e));
             const bool latency = c->latency;
             sl->eh.latency_mode = sl->el.latency_mode = sl->ea.latency_mode = sl->eb1.latency_mode = sl->eb2.latency_mode = latency;
@@ -461,6 +469,7 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
             u->w.alloc(M);
             CG_HIP(hipStreamCreateWithFlags(&u->st, hipStreamNonBlocking));
             for (auto& e : u->ev) CG_HIP(hipEventCreate(&e));
+            CG_HIP(hipEventCreateWithFlags(&u->ev_done, hipEventDisableTiming | hipEventBlockingSync));
             c->uploads.push_back(std::move(u));
         }
         book(nullptr);
@@ -503,6 +512,27 @@ static float ev_ms(hipEvent_t a, hipEvent_t b) {
     return ms;
 }
 
+// How a calling thread waits for the GPU.  A throughput context has a dozen or more proofs in flight, one calling thread
+// each, and every one of them waits ~80 ms for its proof: spinning in hipStreamSynchronize they would hold as many CPUs
+// as there are proofs in flight (and a multi-rank host multiplies that by its ranks, against whatever CPU quota it has).
+// Measured: 16.0 CPUs busy for 16 proofs in flight - the whole cgroup quota of the pool's hosts - and no different with
+// hipEventBlockingSync events, which this runtime also waits for actively.  So the waiters POLL the event and sleep in
+// between (hipEventQuery is a read of the completion signal): a 250 us nap costs a proof 0.3 % of its time in flight and
+// nothing of the GPU's, which the other proofs keep busy.  A latency context (one proof at a time: the wait IS the
+// latency) keeps the spinning synchronise.  CG_SPIN_WAIT=1 forces spinning everywhere (A/B).
+static bool spin_wait() {
+    static const bool v = getenv("CG_SPIN_WAIT") != nullptr && getenv("CG_SPIN_WAIT")[0] == '1';
+    return v;
+}
+static void wait_sleeping(hipEvent_t ev, unsigned nap_us) {
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return;
+        if (e != hipErrorNotReady) CG_HIP(e);
+        std::this_thread::sleep_for(std::chrono::microseconds(nap_us));
+    }
+}
+
 // Host -> device copy of one assignment into `u`, on u's copy-only stream; THIS THREAD waits for it.  Every kernel of
 // the proof needs the assignment, so the proof loses nothing, and the other proofs in flight (other threads) keep the GPU
 // busy meanwhile.  Enqueued on the proof's own stream instead, the copy becomes a barrier packet in a hardware queue that
@@ -514,7 +544,12 @@ static float upload_assignment(cg_ctx* c, Upload* u, const void* host_assignment
     if (timed) CG_HIP(hipEventRecord(u->ev[0], u->st));
     CG_HIP(hipMemcpyAsync(u->w.p, host_assignment, c->M * 32, hipMemcpyHostToDevice, u->st));
     if (timed) CG_HIP(hipEventRecord(u->ev[1], u->st));
-    CG_HIP(hipStreamSynchronize(u->st));
+    if (spin_wait() || c->latency) {
+        CG_HIP(hipStreamSynchronize(u->st));
+    } else {
+        CG_HIP(hipEventRecord(u->ev_done, u->st));
+        wait_sleeping(u->ev_done, 50);             // a 48 MB copy takes ~1 ms
+    }
     return timed ? ev_ms(u->ev[0], u->ev[1]) : 0.f;
 }
 
@@ -555,7 +590,12 @@ static int prove_partial_impl(cg_ctx* c, ProofSlot* S, const Fr* w_dev, bool ski
     S->eb2.accumulate(S->st[4]);
     S->eh.accumulate(s0);
     if (while_gpu_runs) (*while_gpu_runs)();      // host work that needs no MSM value
-    for (int i = 0; i < 5; ++i) CG_HIP(hipStreamSynchronize(S->st[i]));
+    if (S->one_stream && !spin_wait()) {
+        CG_HIP(hipEventRecord(S->ev_done, s0));
+        wait_sleeping(S->ev_done, 250);            // a proof with fifteen others in flight takes ~80 ms
+    } else {
+        for (int i = 0; i < 5; ++i) CG_HIP(hipStreamSynchronize(S->st[i]));
+    }
     if (S->wm.h_bad_input.p[0]) return fail(CG_ERR_INVALID_ARGUMENT, "full_assignment holds a value >= the scalar field modulus");
     P.h = to_affine(S->eh.value());
     P.l = to_affine(S->el.value());

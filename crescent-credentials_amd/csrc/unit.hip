@@ -8,6 +8,7 @@
 #include <chrono>
 #include <memory>
 #include <mutex>
+#include <thread>
 
 #include "msm.hpp"
 #include "wmap29.hpp"
@@ -467,7 +468,12 @@ extern "C" int cg_probe_shader_clock(int32_t device, uint32_t window_us, double*
         P.res.p[0] = P.res.p[1] = 0;
         k_clock_probe<<<1, 64, 0, P.st>>>((uint64_t)window_us * (uint64_t)P.wall_khz / 1000u, P.res_dev);
         CG_KERNEL_CHECK();
-        CG_HIP(hipStreamSynchronize(P.st));
+        for (;;) {                                  // the probe sleeps on the device: so does its caller (no spinning synchronise)
+            const hipError_t e = hipStreamQuery(P.st);
+            if (e == hipSuccess) break;
+            if (e != hipErrorNotReady) CG_HIP(e);
+            std::this_thread::sleep_for(std::chrono::microseconds(window_us < 2000 ? 50 : 500));
+        }
         if (!P.res.p[1]) return fail(CG_ERR_HIP, "the constant-rate counter did not advance");
         *ghz_out = (double)P.res.p[0] / (double)P.res.p[1] * (double)P.wall_khz * 1e-6;
         return CG_OK;
