@@ -12,8 +12,30 @@
 
 namespace cg {
 
-static constexpr int TS29 = 10;            // log2 of the LDS tile (1024 elements x 9 limbs = 36 KiB + padding)
-static constexpr int STRIDED_MAX_S29 = 6;
+// log2 of the LDS tile.  10: 1024 elements x 9 limbs = 36 KiB + padding per block of 256 threads, four blocks per CU, a
+// 2^21 transform in THREE passes (10 + 6 + 5 stages).  11: 2048 elements = 73 KiB per block of 512 threads, two blocks per
+// CU - the same four waves per SIMD - and a 2^21 transform in TWO passes (11 + 10 stages): a third of the pass ends (unpack,
+// reduce, pack) and one global round trip fewer, at the price of 64-byte instead of 512-byte runs in the strided pass.
+// Measured (profiles/r03_h_ntt_tiles.txt): stand-alone the two are equal at 2^21 (0.301 against 0.304 ms - the passes are
+// bound by instruction issue, not by their ends) and the big tile is ~5 % ahead at 2^20 and 2^24, behind at 2^22 (no pass
+// saved) and below 2^20 (too few tiles to fill the chip); in the proof pipeline it is worth +0.8 %.  So the big tile is
+// taken where it saves a pass on a transform of at least 2^20 elements.
+static constexpr int TS29_SMALL = 10, TS29_BIG = 11;
+// most stages a strided pass takes (its tile holds 2^(tile - S) columns of 2^S rows)
+static int strided_max_stages(int tile_log) { return tile_log == TS29_BIG ? 10 : 6; }
+static int ntt_passes(int logn, int tile_log) {
+    if (logn <= tile_log) return 1;
+    const int smax = strided_max_stages(tile_log);
+    return 1 + (logn - tile_log + smax - 1) / smax;
+}
+static int ntt_tile_log(int logn) {
+    static const int forced = [] {
+        const char* e = getenv("CG_NTT_TILE");          // A/B aid
+        return (e && (atoi(e) == TS29_SMALL || atoi(e) == TS29_BIG)) ? atoi(e) : 0;
+    }();
+    if (forced) return (forced == TS29_BIG && logn > TS29_SMALL) ? TS29_BIG : TS29_SMALL;
+    return (logn >= 20 && ntt_passes(logn, TS29_BIG) < ntt_passes(logn, TS29_SMALL)) ? TS29_BIG : TS29_SMALL;
+}
 
 // ---- packed (8 x u32) global accesses ---------------------------------------------------------------------
 __device__ __forceinline__ Fr29 load_packed29(const uint32_t* __restrict__ base, uint64_t idx) {
@@ -259,15 +281,16 @@ __device__ __forceinline__ void bfly(Fr29& u, Fr29& v, const Fr29& w) {
 // Lazy-value bounds: a pass starts below 6N (packed inputs are < 2^256 = 5.3N), every stage adds at most 3N — the
 // product-free first group of a transform ends below 22.6N instead — so after ten stages values stay under 47N
 // (representable: 2^261 = 169N) and limbs, renormalised every second stage, under 2^32.
-template <int LOAD, int STORE>
-__global__ void __launch_bounds__(256) k_ntt29_pass(const uint32_t* __restrict__ in_a, const uint32_t* __restrict__ in_b,
+template <int LOAD, int STORE, int TSL>
+__global__ void __launch_bounds__(256 << (TSL - 10)) k_ntt29_pass(const uint32_t* __restrict__ in_a, const uint32_t* __restrict__ in_b,
                                                     const uint32_t* __restrict__ in_c, uint32_t* __restrict__ out,
                                                     const uint32_t* __restrict__ tw, const uint32_t* __restrict__ scale,
                                                     Packed8 vinv_p, Pass29 pp, int store_bitrev) {
-    __shared__ uint32_t sm[(1 << TS29) * 9 + (1 << TS29) / 16];
+    __shared__ uint32_t sm[(1 << TSL) * 9 + (1 << TSL) / 16];
+    constexpr uint32_t NT = 256u << (TSL - 10);
     const uint32_t tile = blockIdx.x;
     const uint32_t tsize = 1u << pp.ts;
-    for (uint32_t e = threadIdx.x; e < tsize; e += 256) {
+    for (uint32_t e = threadIdx.x; e < tsize; e += NT) {
         uint32_t gi = l2g29(e, tile, pp);
         Fr29 x = load_packed29(in_a, gi);
         if (LOAD == 1) {
@@ -284,7 +307,7 @@ __global__ void __launch_bounds__(256) k_ntt29_pass(const uint32_t* __restrict__
         const int lb = pp.cbits + (q - pp.gbit_lo);
         const uint32_t lmask = (1u << lb) - 1u;
         const int sh1 = pp.logn - 1 - q, sh2 = pp.logn - 2 - q;
-        for (uint32_t b = threadIdx.x; b < (tsize >> 2); b += 256) {
+        for (uint32_t b = threadIdx.x; b < (tsize >> 2); b += NT) {
             const uint32_t e00 = ((b & ~lmask) << 2) | (b & lmask);
             const uint32_t e01 = e00 | (1u << lb), e10 = e00 | (2u << lb), e11 = e00 | (3u << lb);
             const uint32_t gi = l2g29(e00, tile, pp);
@@ -325,7 +348,7 @@ __global__ void __launch_bounds__(256) k_ntt29_pass(const uint32_t* __restrict__
         const int lb = pp.cbits + (q - pp.gbit_lo);
         const uint32_t lmask = (1u << lb) - 1u;
         const int tw_shift = pp.logn - 1 - q;
-        for (uint32_t b = threadIdx.x; b < (tsize >> 1); b += 256) {
+        for (uint32_t b = threadIdx.x; b < (tsize >> 1); b += NT) {
             uint32_t e0 = ((b & ~lmask) << 1) | (b & lmask);
             uint32_t e1 = e0 | (1u << lb);
             uint32_t gi = l2g29(e0, tile, pp);
@@ -338,7 +361,7 @@ __global__ void __launch_bounds__(256) k_ntt29_pass(const uint32_t* __restrict__
         __syncthreads();
     }
     const uint32_t smask = (1u << pp.S) - 1u;
-    for (uint32_t f = threadIdx.x; f < tsize; f += 256) {
+    for (uint32_t f = threadIdx.x; f < tsize; f += NT) {
         uint32_t e = f;
         if (store_bitrev) {   // walk the tile so that consecutive lanes hit consecutive bit-reversed destinations
             uint32_t gprime = f & smask, colp = f >> pp.S;
@@ -357,8 +380,9 @@ __global__ void __launch_bounds__(256) k_ntt29_pass(const uint32_t* __restrict__
 
 template <int LOAD, int STORE>
 static void launch_pass(uint32_t tiles, const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t* out, const uint32_t* tw,
-                        const uint32_t* scale, const Packed8& vinv, const Pass29& pp, int store_bitrev, hipStream_t st) {
-    k_ntt29_pass<LOAD, STORE><<<tiles, 256, 0, st>>>(a, b, c, out, tw, scale, vinv, pp, store_bitrev);
+                        const uint32_t* scale, const Packed8& vinv, const Pass29& pp, int store_bitrev, int tile_log, hipStream_t st) {
+    if (tile_log == TS29_BIG) k_ntt29_pass<LOAD, STORE, TS29_BIG><<<tiles, 512, 0, st>>>(a, b, c, out, tw, scale, vinv, pp, store_bitrev);
+    else k_ntt29_pass<LOAD, STORE, TS29_SMALL><<<tiles, 256, 0, st>>>(a, b, c, out, tw, scale, vinv, pp, store_bitrev);
     CG_KERNEL_CHECK();
 }
 
@@ -372,10 +396,12 @@ static void dit29(const Wm29Domain& d, const uint32_t* tw, const uint32_t* in_a,
     Packed8 vinv;
     memcpy(vinv.w, const_scale ? const_scale : d.vinv, 32);
     std::vector<Pass29> plan;
-    const int ts = logn < TS29 ? logn : TS29;
+    const int tile_log = ntt_tile_log(logn);
+    const int ts = logn < tile_log ? logn : tile_log;
     plan.push_back(Pass29{logn, ts, ts, 0, 0, 0});
     const int rest = logn - ts;
-    const int npass = rest ? (rest + STRIDED_MAX_S29 - 1) / STRIDED_MAX_S29 : 0;
+    const int smax = strided_max_stages(tile_log);
+    const int npass = rest ? (rest + smax - 1) / smax : 0;
     int done = 0;
     for (int p = 0; p < npass; ++p) {
         int S = (rest - done + (npass - p) - 1) / (npass - p);
@@ -390,12 +416,12 @@ static void dit29(const Wm29Domain& d, const uint32_t* tw, const uint32_t* in_a,
         const bool pw = first && pointwise;
         const bool sc = last && scale != nullptr;
         const int sb = last && store_bitrev ? 1 : 0;
-        if (last && quot_a) launch_pass<0, 3>(tiles, a, quot_a, nullptr, o, tw, nullptr, vinv, plan[i], sb, st);
-        else if (last && const_scale) launch_pass<0, 2>(tiles, a, nullptr, nullptr, o, tw, nullptr, vinv, plan[i], sb, st);
-        else if (pw && sc) launch_pass<1, 1>(tiles, a, in_b, in_c, o, tw, scale, vinv, plan[i], sb, st);
-        else if (pw) launch_pass<1, 0>(tiles, a, in_b, in_c, o, tw, scale, vinv, plan[i], sb, st);
-        else if (sc) launch_pass<0, 1>(tiles, a, nullptr, nullptr, o, tw, scale, vinv, plan[i], sb, st);
-        else launch_pass<0, 0>(tiles, a, nullptr, nullptr, o, tw, scale, vinv, plan[i], sb, st);
+        if (last && quot_a) launch_pass<0, 3>(tiles, a, quot_a, nullptr, o, tw, nullptr, vinv, plan[i], sb, tile_log, st);
+        else if (last && const_scale) launch_pass<0, 2>(tiles, a, nullptr, nullptr, o, tw, nullptr, vinv, plan[i], sb, tile_log, st);
+        else if (pw && sc) launch_pass<1, 1>(tiles, a, in_b, in_c, o, tw, scale, vinv, plan[i], sb, tile_log, st);
+        else if (pw) launch_pass<1, 0>(tiles, a, in_b, in_c, o, tw, scale, vinv, plan[i], sb, tile_log, st);
+        else if (sc) launch_pass<0, 1>(tiles, a, nullptr, nullptr, o, tw, scale, vinv, plan[i], sb, tile_log, st);
+        else launch_pass<0, 0>(tiles, a, nullptr, nullptr, o, tw, scale, vinv, plan[i], sb, tile_log, st);
     }
 }
 
