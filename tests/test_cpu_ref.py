@@ -96,6 +96,26 @@ def test_ntt_four_step_sizes_vs_oracle(ref, oracle, logn):
             assert got[k].tobytes() == _scalars(want[k]).tobytes(), (logn, nt, k)
 
 
+def test_external_vectors_through_the_c_restatement(ref, oracle):
+    """the external known answers of tests/test_oracle_kats.py (3·G1, 2·G2, the published 2^28-th root of unity) through
+    oracle/cpu_ref.c, the timed CPU baseline: the third implementation that must agree with them"""
+    from test_oracle_kats import G1_TIMES_3, G2_TIMES_2, FR_ROOT_OF_UNITY_2_28
+    g = oracle.g1_packed(oracle.G1_GEN)
+    g2 = oracle.g1_packed(oracle.G1.to_affine(oracle.G1.mul_affine(oracle.G1_GEN, 2)))
+    want3 = G1_TIMES_3[0].to_bytes(32, "little") + G1_TIMES_3[1].to_bytes(32, "little")
+    assert ref.msm_g1(g + g2, _scalars([1, 1])) == want3 and ref.msm_g1(g, _scalars([3])) == want3
+    (x0, x1), (y0, y1) = G2_TIMES_2
+    want2 = b"".join(v.to_bytes(32, "little") for v in (x0, x1, y0, y1))
+    h = oracle.g2_packed(oracle.G2_GEN)
+    assert ref.msm_g2(h * 2, _scalars([1, 1])) == want2 and ref.msm_g2(h, _scalars([2])) == want2
+    for logn in (2, 9, 12):
+        n = 1 << logn
+        out = ref.ntt(_scalars([0, 1] + [0] * (n - 2)), nthreads=3).tobytes()
+        w = pow(FR_ROOT_OF_UNITY_2_28, 1 << (28 - logn), oracle.R)
+        for k in (0, 1, 2, n // 2 + 1, n - 1):
+            assert int.from_bytes(out[32 * k:32 * k + 32], "little") == pow(w, k, oracle.R)
+
+
 @pytest.mark.parametrize("idx", [0, 1, 2, 3])
 def test_msm_golden(ref, oracle, idx):
     c = load_golden("msm.json")["cases"][idx]

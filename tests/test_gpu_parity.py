@@ -147,6 +147,38 @@ def test_alt_bn128_doubling_vector_on_the_gpu(cc, oracle):
         ctx.close()
 
 
+def test_external_vectors_on_the_gpu(cc, oracle):
+    """the other external known answers of tests/test_oracle_kats.py through the HIP library: 3·G1 = G1 + 2·G1 (a mixed
+    addition of distinct points, via the MSM and the fixed-base path), 2·G2 (the Fq2 arithmetic of the G2 kernels), and the
+    2^28-th root of unity that gnark-crypto publishes and ark-ff derives from generator 5 - seen through the transform of
+    a unit impulse, whose k-th output is ω^k"""
+    from test_oracle_kats import G1_TIMES_3, G2_TIMES_2, FR_ROOT_OF_UNITY_2_28
+    want3 = G1_TIMES_3[0].to_bytes(32, "little") + G1_TIMES_3[1].to_bytes(32, "little")
+    g = oracle.g1_packed(oracle.G1_GEN)
+    g2 = bytes(cc.fixed_base_g1(_scalars([2])))
+    assert bytes(cc.fixed_base_g1(_scalars([3]))) == want3
+    assert cc.msm_bigint_g1(g + g2, _scalars([1, 1])) == want3
+    assert cc.msm_bigint_g1(g, _scalars([3])) == want3
+    (x0, x1), (y0, y1) = G2_TIMES_2
+    want2 = b"".join(v.to_bytes(32, "little") for v in (x0, x1, y0, y1))
+    h = oracle.g2_packed(oracle.G2_GEN)
+    assert bytes(cc.fixed_base_g2(_scalars([2]))) == want2
+    assert cc.msm_bigint_g2(h * 2, _scalars([1, 1])) == want2
+    assert cc.msm_bigint_g2(h, _scalars([2])) == want2
+    for logn in (2, 11, 21):
+        n = 1 << logn
+        delta = np.zeros(n * 32, np.uint8)
+        delta[32] = 1                                    # the polynomial x
+        out = bytes(cc.fft_in_place(delta))
+        w = pow(FR_ROOT_OF_UNITY_2_28, 1 << (28 - logn), oracle.R)
+        for k in (0, 1, 2, 3, n // 2 + 1, n - 1):
+            assert int.from_bytes(out[32 * k:32 * k + 32], "little") == pow(w, k, oracle.R), (logn, k)
+        # and on the coset: x evaluated at 5·ω^k
+        outc = bytes(cc.fft_in_place(delta, coset=True))
+        for k in (0, 1, n - 1):
+            assert int.from_bytes(outc[32 * k:32 * k + 32], "little") == 5 * pow(w, k, oracle.R) % oracle.R, (logn, k)
+
+
 def test_msm_empty_and_all_zero(cc, oracle):
     assert cc.msm_bigint_g1(b"", b"") == bytes(64)
     g = oracle.g1_packed(oracle.G1_GEN)

@@ -89,6 +89,48 @@ def test_alt_bn128_doubling_vector(oracle):
     assert oracle.G1.to_affine(oracle.G1.msm([oracle.G1_GEN, oracle.G1_GEN], [1, 1])) == (x2, y2)
 
 
+# Further EXTERNAL known answers, from the published test data and constants of other BN254 / alt_bn128 implementations
+# (none of them in the reference tree, which pins no arithmetic): py_ecc's bn128 curve tests and the EIP-196 / EIP-197
+# precompile suites carry 3·G1 and 2·G2; gnark-crypto (ecc/bn254/fr/fft, `rootOfUnity`, multiplicative generator 5) and
+# ark-ff's derivation from `GENERATOR = 5` give the 2^28-th root of unity of Fr that ark-poly's radix-2 domains are built on.
+G1_TIMES_3 = (3353031288059533942658390886683067124040920775575537747144343083137631628272,
+              19321533766552368860946552437480515441416830039777911637913418824951667761761)
+G2_TIMES_2 = ((18029695676650738226693292988307914797657423701064905010927197838374790804409,
+               14583779054894525174450323658765874724019480979794335525732096752006891875705),
+              (2140229616977736810657479771656733941598412651537078903776637920509952744750,
+               11474861747383700316476719153975578001603231366361248090558603872215261634898))
+FR_ROOT_OF_UNITY_2_28 = 19103219067921713944291392827692070036145651957329286315305642004821462161904
+
+
+def test_external_group_vectors(oracle):
+    """3·G1 = G1 + 2·G1 (a mixed addition of DISTINCT points, which the doubling vector does not exercise) and 2·G2 (the
+    Fq2 arithmetic: u^2 = -1, component order c0 then c1, twist coefficient 3/(9+u))"""
+    g, g2 = oracle.G1_GEN, oracle.G1.to_affine(oracle.G1.mul_affine(oracle.G1_GEN, 2))
+    assert oracle.G1.to_affine(oracle.G1.mul_affine(g, 3)) == G1_TIMES_3
+    assert oracle.G1.to_affine(oracle.G1.add_affine(oracle.G1.to_jac(g2), g)) == G1_TIMES_3
+    assert oracle.G1.to_affine(oracle.G1.msm([g, g2], [1, 1])) == G1_TIMES_3
+    assert oracle.G2.to_affine(oracle.G2.mul_affine(oracle.G2_GEN, 2)) == G2_TIMES_2
+    assert oracle.G2.to_affine(oracle.G2.msm([oracle.G2_GEN, oracle.G2_GEN], [1, 1])) == G2_TIMES_2
+    (x0, x1), (y0, y1) = G2_TIMES_2                     # on the twist y^2 = x^3 + 3/(9+u)
+    q = oracle.Q
+    f2mul = lambda a, b: ((a[0] * b[0] - a[1] * b[1]) % q, (a[0] * b[1] + a[1] * b[0]) % q)
+    x3 = f2mul(f2mul((x0, x1), (x0, x1)), (x0, x1))
+    inv9u = (9 * pow(82, -1, q) % q, -pow(82, -1, q) % q)          # 1/(9+u) = (9-u)/82
+    b = f2mul((3, 0), inv9u)
+    y2 = f2mul((y0, y1), (y0, y1))
+    assert y2 == ((x3[0] + b[0]) % q, (x3[1] + b[1]) % q)
+
+
+def test_external_root_of_unity(oracle):
+    """the [ark-mem] constants of SURVEY Appendix A, pinned from outside: Fr's multiplicative generator 5 and its 2^28-th
+    root of unity - the point set of every evaluation domain (r1cs_to_qap.rs:156,179-185), hence of h"""
+    w28 = pow(5, (oracle.R - 1) >> 28, oracle.R)
+    assert w28 == FR_ROOT_OF_UNITY_2_28
+    assert oracle.FR_GENERATOR == 5
+    for logn in (1, 3, 10, 21, 28):
+        assert oracle.root_of_unity(1 << logn) == pow(FR_ROOT_OF_UNITY_2_28, 1 << (28 - logn), oracle.R)
+
+
 def test_pairing_bilinear(oracle):
     from bn254_oracle import _f12_one, _f12_pow
     e1 = oracle.pairing(oracle.G1_GEN, oracle.G2_GEN)
