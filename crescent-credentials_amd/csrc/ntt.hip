@@ -6,6 +6,8 @@
 
 #include "ntt.hpp"
 
+#include <algorithm>
+
 namespace cg {
 
 // ---------------------------------------------------------------------------------------------
@@ -200,6 +202,22 @@ void DevCsr::build_sell(const std::vector<uint32_t>& rp, const uint32_t* col_h, 
     items.reserve(rows);
     for (uint64_t i = 0; i < rows; ++i)
         if (rp[i + 1] > rp[i]) items.push_back({(uint32_t)i, rp[i], rp[i + 1] - rp[i]});
+    // Inside a row the terms with a coefficient other than one come first (a sum does not care), so a piece is "k
+    // products, then plain additions", and the pieces are sorted by k before they are sliced: the 64 lanes of a slice
+    // then agree on which of their steps multiply.  Circom rows are mostly unit coefficients with the powers of two
+    // concentrated in the adder rows (gate mix: 82 % of A's rows carry no other coefficient at all), and a wave pays the
+    // 207-instruction product at every step at which ANY of its lanes needs it.
+    static const bool plain = getenv("CG_SELL_PLAIN") != nullptr;       // A/B aid: round 2's layout (terms as given, pieces by length)
+    for (const Item& it : items) {
+        if (plain) break;
+        uint32_t w = it.first;
+        for (uint32_t t = it.first; t < it.first + it.len; ++t)
+            if (cur_idx[t] != 0) {
+                std::swap(cur_idx[t], cur_idx[w]);
+                std::swap(cur_col[t], cur_col[w]);
+                ++w;
+            }
+    }
     n_sell = 0;
     sell_scratch = 0;
     while (!items.empty()) {
@@ -224,15 +242,27 @@ void DevCsr::build_sell(const std::vector<uint32_t>& rp, const uint32_t* col_h, 
                 next_col.push_back(partials++);
             }
         }
-        // longest pieces first, so that a slice holds pieces of (nearly) one length
-        std::vector<uint32_t> start(SELL_PIECE + 2, 0);
-        for (const Piece& p : pieces) start[SELL_PIECE - p.len + 1]++;
-        for (uint32_t k = 0; k <= SELL_PIECE; ++k) start[k + 1] += start[k];
+        // most products first, then longest first: a slice holds pieces of (nearly) one shape
+        auto products_of = [&](const Piece& p) {
+            uint32_t k = 0;
+            if (plain) return k;
+            for (uint32_t t = 0; t < p.len; ++t) k += cur_idx[p.first + t] != 0;
+            return k;
+        };
+        constexpr uint32_t NK = (SELL_PIECE + 1) * (SELL_PIECE + 1);
+        auto key_of = [&](const Piece& p) { return (SELL_PIECE - products_of(p)) * (SELL_PIECE + 1) + (SELL_PIECE - p.len); };
+        std::vector<uint32_t> start(NK + 1, 0);
+        for (const Piece& p : pieces) start[key_of(p) + 1]++;
+        for (uint32_t k = 0; k < NK; ++k) start[k + 1] += start[k];
         std::vector<Piece> sorted(pieces.size());
-        for (const Piece& p : pieces) sorted[start[SELL_PIECE - p.len]++] = p;
+        for (const Piece& p : pieces) sorted[start[key_of(p)]++] = p;
         const uint32_t np = (uint32_t)sorted.size(), ns = (np + 63) / 64;
         std::vector<uint32_t> sp(ns + 1, 0), dst(np);
-        for (uint32_t s = 0; s < ns; ++s) sp[s + 1] = sp[s] + 64 * sorted[(size_t)s * 64].len;   // the slice's first piece is its longest
+        for (uint32_t s = 0; s < ns; ++s) {
+            uint32_t longest = 0;
+            for (uint32_t p = s * 64; p < np && p < (s + 1) * 64; ++p) longest = std::max(longest, sorted[p].len);
+            sp[s + 1] = sp[s] + 64 * longest;
+        }
         std::vector<uint32_t> lc(sp[ns] ? sp[ns] : 1, 0), li(sp[ns] ? sp[ns] : 1, SELL_PAD);
         for (uint32_t p = 0; p < np; ++p) {
             const Piece& pc = sorted[p];
