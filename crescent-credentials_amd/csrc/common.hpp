@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+#include <shared_mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -86,10 +88,13 @@ struct PinnedBuf {
     explicit PinnedBuf(size_t count) { alloc(count); }
     PinnedBuf(const PinnedBuf&) = delete;
     PinnedBuf& operator=(const PinnedBuf&) = delete;
-    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
-    void alloc(size_t count) {
+    ~PinnedBuf() { free_now(); }
+    void free_now() {
         if (p) (void)hipHostFree(p);
         p = nullptr;
+    }
+    void alloc(size_t count) {
+        free_now();
         if (count) CG_HIP(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault));
         n = count;
     }

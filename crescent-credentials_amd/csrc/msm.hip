@@ -1265,7 +1265,6 @@ static void part_bits(int c, int W, bool precomputed, int& bits1, int& bits2) {
 
 template <class F>
 void MsmEngine<F>::init(const MsmBases<F>* b) {
-    if (red_graph) { (void)hipGraphExecDestroy(red_graph); red_graph = nullptr; }   // shapes and buffers change below
     bases = b;
     const uint64_t n = b->n;
     const int W = b->W;
@@ -1328,7 +1327,6 @@ template <class F> float MsmEngine<F>::ms_accum() const { return n_scalars ? ela
 
 template <class F>
 MsmEngine<F>::~MsmEngine() {
-    if (red_graph) (void)hipGraphExecDestroy(red_graph);
     for (auto& e : ev_t) if (e) (void)hipEventDestroy(e);
 }
 
@@ -1421,22 +1419,13 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
     }
     // bucket reduction (see the comment above block_tree_sum): two launches, the second writing the per-bit sums to host memory, of a fixed
     // shape for a given window size - captured once into a HIP graph and replayed as one submission.
-    if (!red_graph) {
-        hipGraph_t g = nullptr;
-        CG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        try {
-            enqueue_reduction(st);
-        } catch (...) {
-            (void)hipStreamEndCapture(st, &g);
-            if (g) (void)hipGraphDestroy(g);
-            throw;
-        }
-        CG_HIP(hipStreamEndCapture(st, &g));
-        hipError_t e = hipGraphInstantiate(&red_graph, g, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(g);
-        CG_HIP(e);
-    }
-    CG_HIP(hipGraphLaunch(red_graph, st));
+    // The reduction's two or three launches go out directly.  Rounds 1-2 replayed them as a captured HIP graph, which is
+    // worth ~0.03 ms on a lone proof and nothing on the rate (and costs the host twice the CPU: 1.4 against 0.7 CPUs busy
+    // with sixteen proofs in flight) - and a capture is invalidated by anything that synchronises the device from ANOTHER
+    // thread while it is open (a context being freed or loaded next to a context's first proof: "operation failed due
+    // to a previous error during capture", met by tests/test_gpu_e2e_files.py under concurrent callers).  No capture, no
+    // such window (profiles/r03_j_reduction_graph.txt).
+    enqueue_reduction(st);
     CG_HIP(hipEventRecord(ev_t[5], st));
 }
 

@@ -73,7 +73,6 @@ struct MsmEngine {
     // valid once the stream has been synchronised
     uint32_t n_entries() const { return h_plan.p ? h_plan.p[0] : 0; }
     uint32_t n_nonzero() const { return h_plan.p ? h_plan.p[3] : 0; }
-    hipGraphExec_t red_graph = nullptr;   // the bucket reduction's launches, captured on first use (reset by init)
     void enqueue_reduction(hipStream_t st);
     // timing events (recorded on the MSM's own stream): digits start, sort begin/end, level-1
     // accumulation kernel begin/end, result ready

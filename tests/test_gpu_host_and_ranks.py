@@ -128,6 +128,48 @@ def test_ctx_info_reports_memory_windows_and_the_retune(cc, oracle, medium):
         sh.close()
 
 
+def test_contexts_come_and_go_while_others_prove(cc, oracle, medium):
+    """circuits loaded, proved on once and freed from three threads while a fourth proves continuously on a resident
+    context: a context's first proof captures its reduction launches into a graph (latency contexts), and loading or
+    freeing another context synchronises the device - the two must not meet (a freed context once invalidated another
+    thread's capture: 'operation failed due to a previous error during capture')"""
+    import cpu_ref
+    from concurrent.futures import ThreadPoolExecutor
+    (l, m, M), cm, w, pk = medium
+    r, s = 11, 13
+    want = cpu_ref.prove(pk, (cm.a, cm.b, cm.c), l, m, M, w, r, s, nthreads=8)
+    resident = cc.Prover(pk, cm, proof_slots=3)
+    stop = []
+
+    def keep_proving():
+        n = 0
+        while not stop:
+            assert resident.prove(w, r, s).data == want
+            n += 1
+        return n
+
+    def come_and_go(k):
+        for i in range(4):
+            p = cc.Prover(pk, cm, shard_rank=(k + i) % 2, shard_count=2) if (k + i) % 3 == 0 else cc.Prover(pk, cm)
+            try:
+                if p.info()["shard_count"] == 2:
+                    assert len(p.prove_partial(w, r)) == 384
+                else:
+                    assert p.prove(w, r, s).data == want
+            finally:
+                p.close()
+        return True
+    try:
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            bg = ex.submit(keep_proving)
+            assert all(ex.map(come_and_go, range(3)))
+            stop.append(1)
+            assert bg.result() > 0
+    finally:
+        stop.append(1)
+        resident.close()
+
+
 def test_shader_clock_probe(cc):
     g = [cc.probe_shader_clock(-1, 5000) for _ in range(3)]
     assert all(0.1 < x < 3.5 for x in g), g
