@@ -50,6 +50,23 @@ static uint8_t* read_file(const char* path, uint64_t* len) {
     return buf;
 }
 
+/* the witness goes straight into page-locked memory (cg_host_alloc): where a host lets its witness calculator write,
+ * so that cg_prove's upload is one asynchronous DMA */
+static uint8_t* read_file_pinned(const char* path, uint64_t* len) {
+    FILE* f = fopen(path, "rb");
+    if (!f) { perror(path); return NULL; }
+    if (fseek(f, 0, SEEK_END) != 0) { fclose(f); return NULL; }
+    long n = ftell(f);
+    if (n < 0) { fclose(f); return NULL; }
+    rewind(f);
+    uint8_t* buf = (uint8_t*)cg_host_alloc((uint64_t)n);
+    if (!buf) { fprintf(stderr, "cg_host_alloc: %s\n", cg_last_error()); fclose(f); return NULL; }
+    if (fread(buf, 1, (size_t)n, f) != (size_t)n) { perror(path); cg_host_free(buf); fclose(f); return NULL; }
+    fclose(f);
+    *len = (uint64_t)n;
+    return buf;
+}
+
 static int below_modulus(const uint8_t x[32]) {
     for (int i = 31; i >= 0; --i) {
         if (x[i] < FR_MODULUS_LE[i]) return 1;
@@ -115,11 +132,12 @@ int main(int argc, char** argv) {
     uint64_t r1cs_len = 0, pp_len = 0, w_len = 0;
     uint8_t* r1cs_bytes = read_file(argv[1], &r1cs_len);
     uint8_t* pp_bytes = read_file(argv[2], &pp_len);
-    uint8_t* witness = read_file(argv[3], &w_len);
-    if (!r1cs_bytes || !pp_bytes || !witness) return 1;
+    if (!r1cs_bytes || !pp_bytes) return 1;
 
     if (cg_init(0, NULL) != CG_OK) return die("cg_init");
     fprintf(stderr, "%s\n", cg_version());
+    uint8_t* witness = read_file_pinned(argv[3], &w_len);
+    if (!witness) return 1;
 
     /* the circuit: R1CSFile::new + R1CS::from */
     cg_r1cs* r1cs = NULL;
@@ -153,6 +171,12 @@ int main(int argc, char** argv) {
     cg_timings tm;
     if (cg_prove(ctx, witness, r, s, proof, &tm) != CG_OK) return die("cg_prove");
     double t2 = now_ms();
+    cg_ctx_info info;
+    if (cg_ctx_get_info(ctx, &info) != CG_OK) return die("cg_ctx_get_info");
+    fprintf(stderr, "resident: %.2f GB (tables %.2f, matrices %.2f, per proof slot %.2f x %d); windows h/l/a/b1/b2 = %d/%d/%d/%d/%d%s; upload %.2f ms\n",
+            (double)info.total_bytes / 1e9, (double)info.table_bytes / 1e9, (double)info.matrix_bytes / 1e9, (double)info.slot_bytes / 1e9,
+            (int)info.proof_slots, (int)info.window_bits[0], (int)info.window_bits[1], (int)info.window_bits[2], (int)info.window_bits[3],
+            (int)info.window_bits[4], info.tuned ? " (re-tuned from this proof)" : "", tm.upload_ms);
     fprintf(stderr, "circuit: %llu constraints, %llu wires, %llu public; load %.0f ms; prove %.2f ms (witness map %.2f, h %.2f, l %.2f, a %.2f, b1 %.2f, b2 %.2f)\n",
             (unsigned long long)hdr.n_constraints, (unsigned long long)hdr.num_variables, (unsigned long long)hdr.num_inputs, t1 - t0,
             t2 - t1, tm.witness_map_ms, tm.msm_h_ms, tm.msm_l_ms, tm.msm_a_ms, tm.msm_b1_ms, tm.msm_b2_ms);
@@ -180,6 +204,6 @@ int main(int argc, char** argv) {
     cg_circuit_free(ctx);
     cg_prover_params_free(pp);
     cg_r1cs_free(r1cs);
-    free(witness); free(pp_bytes); free(r1cs_bytes);
+    cg_host_free(witness); free(pp_bytes); free(r1cs_bytes);
     return 0;
 }
