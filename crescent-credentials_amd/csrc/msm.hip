@@ -307,6 +307,7 @@ struct PartShape {
     int precomputed;       // 1: key = |d| - 1, value = j * row_stride + i;  0: key = j * nb + |d| - 1, value = i
     uint32_t row_stride;
     int bits1, bits2;      // key bits taken by level 1 (high) and level 2 (low; 0 = single level)
+    int staged;            // host side only: level-1 placement through the LDS staging area (latency contexts)
 };
 
 // C = the window size when the kernel was instantiated for it, 0 = taken from the shape at run time
@@ -539,8 +540,11 @@ static void launch_part_level1_c(bool count, const PartShape& sh, uint32_t tiles
                                  uint32_t* cur1, uint64_t* out) {
     if (count) { k_part_count<C><<<tiles, PART_THREADS, lds, st>>>(sh, scalars, valid, blk_hist, hist1, plan); return; }
     if constexpr (C >= STAGE_MIN_C) {
-        static const bool direct = getenv("CG_PLACE_DIRECT") != nullptr;      // A/B aid: the one-store-per-lane placement
-        if (!direct && sh.precomputed) {
+        // latency contexts only: the staging costs 15 M wave-instructions per proof more than it saves in stores (23.9 M against
+        // 9.1 M for the h MSM), which is 0.1 ms off a lone proof and 0.7 % ON a proof in the pipeline.  CG_PLACE_STAGED=1 / 0 forces either.
+        static const char* force = getenv("CG_PLACE_STAGED");
+        const bool staged = (force && (force[0] == '0' || force[0] == '1')) ? force[0] == '1' : sh.staged != 0;
+        if (staged && sh.precomputed) {
             constexpr int W = (SCALAR_BITS + C - 1) / C;
             const uint32_t B1 = 1u << sh.bits1;
             const size_t bytes = (size_t)(3 * B1 + (B1 & 1u)) * 4 + (size_t)STAGE_SUB * W * 8;
@@ -1354,6 +1358,7 @@ void MsmEngine<F>::digits(const Fr* scalars_dev, uint64_t n, hipStream_t st) {
     sh.n = (uint32_t)n; sh.c = bases->c; sh.W = bases->W; sh.precomputed = bases->precomputed ? 1 : 0;
     sh.row_stride = (uint32_t)bases->n;          // table row j starts at j * bases->n
     sh.bits1 = bits1; sh.bits2 = bits2;
+    sh.staged = latency_mode ? 1 : 0;
     const uint32_t tiles = ceil_div(n, PART_TILE);
     CG_HIP(hipEventRecord(ev_t[1], st));
     fill_zero(counters.p, (counters.bytes() + 15) & ~(size_t)15, st);
