@@ -263,6 +263,7 @@ def main():
     from crescent_credentials_amd.distributed import ShardedProver, barrier_sync, max_over_ranks
 
     assert cc.lib().cg_init(0, None) == 0, cc.lib().cg_last_error()
+    cc.set_device(local_rank)          # the key generation below has no device argument (the library's runtime is not torch's)
     R = cc.api.FR_MODULUS
     l, m, M = wl.SHAPES[a.shape]
     log = (lambda *x: print("[bench]", *x, file=sys.stderr, flush=True)) if rank == 0 else (lambda *x: None)

@@ -11,6 +11,7 @@ from .api import (  # noqa: F401
     host_register,
     host_unregister,
     probe_shader_clock,
+    set_device,
     CircomCircuit,
     ClientState,
     IOLocations,

@@ -100,6 +100,7 @@ class _CgR1csHeader(C.Structure):
 # every symbol include/crescent_gpu.h declares, with its signature
 _SIGNATURES = {
     "cg_init": (C.c_int, [C.c_int, C.c_void_p]),
+    "cg_set_device": (C.c_int, [C.c_int32]),
     "cg_last_error": (C.c_char_p, []),
     "cg_version": (C.c_char_p, []),
     "cg_circuit_load": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(_CgProvingKey), C.POINTER(_CgCsr), C.c_uint64,
@@ -471,6 +472,13 @@ class HostBuffer:
             self.close()
         except Exception:
             pass
+
+
+def set_device(device: int) -> None:
+    """cg_set_device: the GPU that the entry points without a device of their own (the setup, the one-shot MSM / NTT) use
+    from this thread on.  Needed next to torch: the library links its own HIP runtime, which does not see
+    torch.cuda.set_device."""
+    _check(lib().cg_set_device(device))
 
 
 def probe_shader_clock(device: int = -1, window_us: int = 20000) -> float:

@@ -298,6 +298,16 @@ extern "C" int cg_init(int n_devices, const int* device_ids) {
     return CG_OK;
 }
 
+extern "C" int cg_set_device(int32_t device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) return fail(CG_ERR_NO_DEVICE, "no HIP device visible (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(CG_ERR_INVALID_ARGUMENT, "device id out of range (have %d devices)", count);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(CG_ERR_HIP, "hipSetDevice(%d) failed: %s", (int)device, hipGetErrorString(e));
+    return CG_OK;
+}
+
 extern "C" uint64_t cg_domain_size(const cg_ctx* ctx) { return ctx ? ctx->D : 0; }
 
 template <class F>

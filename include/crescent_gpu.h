@@ -133,6 +133,12 @@ typedef struct cg_timings {
  * n_devices/device_ids may be 0/NULL (use whatever is visible). */
 int cg_init(int n_devices, const int* device_ids);
 
+/* The GPU that entry points WITHOUT a device of their own run on when called from this thread afterwards: cg_setup,
+ * cg_msm_g1/g2, cg_ntt, cg_fixed_base_*, and the loaders given device -1.  (Contexts carry their device and switch to
+ * it on every call.)  A host with one process per GPU calls this once with its local rank; the reference has no
+ * counterpart (it has no devices). */
+int cg_set_device(int32_t device);
+
 /* Thread-local description of the last error on this thread ("" if none). */
 const char* cg_last_error(void);
 

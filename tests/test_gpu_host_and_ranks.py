@@ -170,6 +170,18 @@ def test_contexts_come_and_go_while_others_prove(cc, oracle, medium):
         resident.close()
 
 
+def test_set_device(cc, oracle):
+    """cg_set_device: range-checked, and the device-less entry points still answer afterwards"""
+    cc.set_device(0)
+    with pytest.raises(cc.CrescentGpuError) as ei:
+        cc.set_device(99)
+    assert ei.value.code == -1 and "out of range" in str(ei.value)
+    with pytest.raises(cc.CrescentGpuError):
+        cc.set_device(-1)
+    two = (2).to_bytes(32, "little")
+    assert bytes(cc.fixed_base_g1(np.frombuffer(two, np.uint8))) == oracle.g1_packed(oracle.G1.to_affine(oracle.G1.mul_affine(oracle.G1_GEN, 2)))
+
+
 def test_shader_clock_probe(cc):
     g = [cc.probe_shader_clock(-1, 5000) for _ in range(3)]
     assert all(0.1 < x < 3.5 for x in g), g
