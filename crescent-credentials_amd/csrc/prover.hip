@@ -528,18 +528,27 @@ static float ev_ms(hipEvent_t a, hipEvent_t b) {
 // Measured: 16.0 CPUs busy for 16 proofs in flight - the whole cgroup quota of the pool's hosts - and no different with
 // hipEventBlockingSync events, which this runtime also waits for actively.  So the waiters POLL the event and sleep in
 // between (hipEventQuery is a read of the completion signal): a 250 us nap costs a proof 0.3 % of its time in flight and
-// nothing of the GPU's, which the other proofs keep busy.  A latency context (one proof at a time: the wait IS the
+// nothing of the GPU's, which the other proofs keep busy (wait_sleeping: shorter naps early on, for small circuits).  A latency context (one proof at a time: the wait IS the
 // latency) keeps the spinning synchronise.  CG_SPIN_WAIT=1 forces spinning everywhere (A/B).
 static bool spin_wait() {
     static const bool v = getenv("CG_SPIN_WAIT") != nullptr && getenv("CG_SPIN_WAIT")[0] == '1';
     return v;
 }
-static void wait_sleeping(hipEvent_t ev, unsigned nap_us) {
+// Polls `ev` until it is done: spinning for the first 200 us (a small circuit's proof is over by then), after that napping
+// an eighth of the time already waited, at most `max_nap_us` - the overshoot stays below an eighth of the wait whatever
+// the circuit's size, and a long wait costs next to no CPU.
+static void wait_sleeping(hipEvent_t ev, unsigned max_nap_us) {
+    const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         const hipError_t e = hipEventQuery(ev);
         if (e == hipSuccess) return;
         if (e != hipErrorNotReady) CG_HIP(e);
-        std::this_thread::sleep_for(std::chrono::microseconds(nap_us));
+        const long long waited = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (waited < 200) { std::this_thread::yield(); continue; }
+        long long nap = waited / 8;
+        if (nap < 20) nap = 20;
+        if (nap > (long long)max_nap_us) nap = max_nap_us;
+        std::this_thread::sleep_for(std::chrono::microseconds(nap));
     }
 }
 
