@@ -417,6 +417,9 @@ def main():
                                "window_bits": info["window_bits"], "tuned": bool(info["tuned"]),
                                "retune_skipped_for_memory": info["retune_skipped_for_memory"]}},
         "roofline": roof, "roofline_valu": roof_valu, "phase_ms": phases,
+        "phase_ms_note": "one proof ALONE on this throughput context, whose proofs run their kernels back to back on one stream each (the "
+                         "overlap comes from the other proofs in flight); a latency context (proof_slots = 1) spreads a proof over five "
+                         "streams: 6.3 ms (profiles/r03_l_shard_latency.txt)",
         "msm_g1_pairs_per_proof": g1_pairs, "msm_g2_pairs_per_proof": g2_pairs,
         "entries_g1": tm["entries_g1"], "entries_g2": tm["entries_g2"],
         "g1_msm_scalar_adds_per_s": round(g1_pairs * value, 1),      # pairs consumed per second of whole-job time
