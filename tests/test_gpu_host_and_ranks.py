@@ -192,8 +192,9 @@ def test_shader_clock_probe(cc):
 # ---- two real ranks --------------------------------------------------------------------------------------------------
 _RANK_SCRIPT = r'''
 import json, os, random, sys
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # two ranks share the GPU: do not oversubscribe its hardware queues
-root = sys.argv[1]; shape = sys.argv[2]; out_path = sys.argv[3]
+root = sys.argv[1]; shape = sys.argv[2]; out_path = sys.argv[3]; backend = sys.argv[4] if len(sys.argv) > 4 else "gloo"
+if backend == "gloo":
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # two ranks share the GPU: do not oversubscribe its hardware queues
 for p in (root, os.path.join(root, "oracle")):
     sys.path.insert(0, p)
 import numpy as np, torch, torch.distributed as dist
@@ -201,17 +202,23 @@ import crescent_credentials_amd as cc
 from crescent_credentials_amd import workloads as wl
 from crescent_credentials_amd.distributed import ShardedProver, barrier_sync
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-torch.cuda.set_device(0)
-dist.init_process_group("gloo")
+gpu = rank if backend == "nccl" else 0                  # RCCL: one GPU per rank; gloo: both ranks on GPU 0
+torch.cuda.set_device(gpu)
+if backend == "nccl":
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", device_id=torch.device("cuda", gpu))
+else:
+    dist.init_process_group("gloo")
 assert cc.lib().cg_init(0, None) == 0
+cc.set_device(gpu)
 R = cc.api.FR_MODULUS
 SEED = 0xC5E5CE47
 l, m, M = wl.SHAPES[shape]
 cm, w = wl.synthetic_circuit(SEED + 11, l, m, M, 0.9, 3, profile="gates")
 rng = random.Random(SEED + 11)
 pk = cc.generate_parameters_with_qap(cm, *[rng.randrange(1, R) for _ in range(4)])
-ctx = cc.Prover(pk, cm, shard_rank=rank, shard_count=world)
-sp = ShardedProver(ctx, torch.device("cuda", 0))
+ctx = cc.Prover(pk, cm, device=gpu, shard_rank=rank, shard_count=world)
+sp = ShardedProver(ctx, torch.device("cuda", gpu))
 wd = torch.from_numpy(w).cuda()
 cases = [(rng.randrange(R), rng.randrange(R)), (0, 0), (rng.randrange(R), rng.randrange(R))]
 proofs = []
@@ -251,6 +258,50 @@ def test_two_gloo_ranks_with_real_hip_shards_under_sharded_prover(shape, tmp_pat
         assert r["all_gathers"] == r["n"] == 3              # exactly one collective per proof
         assert r["info"] == 2
     assert len(set(want)) == 3
+
+
+def _gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs (the RCCL leg: one rank per GPU over xGMI)")
+def test_two_rccl_ranks_with_real_hip_shards_under_sharded_prover(tmp_path):
+    """the same protocol as above over RCCL ("nccl"), each rank on its own GPU: runs wherever two GPUs are visible"""
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "res.json")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script), ROOT, "medium", out, "nccl"]
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert run.returncode == 0, run.stderr[-3000:]
+    res = [json.load(open(out + ".%d" % k)) for k in range(2)]
+    for r in res:
+        assert r["proofs"] == res[0]["want"] and r["all_gathers"] == r["n"] == 3
+
+
+@pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs")
+def test_two_devices_in_one_process(cc, oracle, medium):
+    """one process, a context on each of two GPUs (cg_options.device), proving concurrently: the same bytes from both"""
+    import cpu_ref
+    from concurrent.futures import ThreadPoolExecutor
+    (l, m, M), cm, w, pk = medium
+    want = cpu_ref.prove(pk, (cm.a, cm.b, cm.c), l, m, M, w, 21, 22, nthreads=8)
+    provers = [cc.Prover(pk, cm, device=d, proof_slots=2) for d in (0, 1)]
+    try:
+        assert [p.info()["proof_slots"] for p in provers] == [2, 2]
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            got = list(ex.map(lambda i: provers[i & 1].prove(w, 21, 22).data, range(12)))
+        assert all(g == want for g in got)
+    finally:
+        for p in provers:
+            p.close()
 
 
 def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
