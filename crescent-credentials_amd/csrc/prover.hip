@@ -134,7 +134,7 @@ struct ProofSlot {
     hipStream_t st[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // 0: witness map + h, 1: l, 2: a, 3: b1, 4: b2
     hipEvent_t ev_w = nullptr;
     hipEvent_t ev_b1 = nullptr;        // b1's entries are grouped (the G2 MSM adopts them)
-    hipEvent_t ev_done = nullptr;      // one-stream slots: the proof's last kernel is done (a BLOCKING event, see wait_for_proof)
+    hipEvent_t ev_done = nullptr;      // one-stream slots: recorded behind the proof's last kernel and polled (wait_sleeping)
     bool one_stream = false;
     hipEvent_t ev_t[2] = {nullptr, nullptr};
     ~ProofSlot() {
@@ -155,7 +155,7 @@ struct Upload {
     DevBuf<Fr> w;
     hipStream_t st = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
-    hipEvent_t ev_done = nullptr;      // blocking: the calling thread sleeps until its copy has landed
+    hipEvent_t ev_done = nullptr;      // recorded behind the copy and polled (wait_sleeping)
     ~Upload() {
         if (st) (void)hipStreamDestroy(st);
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -463,7 +463,7 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
             }
             CG_HIP(hipEventCreateWithFlags(&sl->ev_w, hipEventDisableTiming));
             CG_HIP(hipEventCreateWithFlags(&sl->ev_b1, hipEventDisableTiming));
-            CG_HIP(hipEventCreateWithFlags(&sl->ev_done, hipEventDisableTiming | hipEventBlockingSync));
+            CG_HIP(hipEventCreateWithFlags(&sl->ev_done, hipEventDisableTiming));
             sl->one_stream = serial;
             for (auto& e : sl->ev_t) CG_HIP(hipEventCreate(&e));
             const bool latency = c->latency;
@@ -479,7 +479,7 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
             u->w.alloc(M);
             CG_HIP(hipStreamCreateWithFlags(&u->st, hipStreamNonBlocking));
             for (auto& e : u->ev) CG_HIP(hipEventCreate(&e));
-            CG_HIP(hipEventCreateWithFlags(&u->ev_done, hipEventDisableTiming | hipEventBlockingSync));
+            CG_HIP(hipEventCreateWithFlags(&u->ev_done, hipEventDisableTiming));
             c->uploads.push_back(std::move(u));
         }
         book(nullptr);
@@ -528,8 +528,9 @@ static float ev_ms(hipEvent_t a, hipEvent_t b) {
 // Measured: 16.0 CPUs busy for 16 proofs in flight - the whole cgroup quota of the pool's hosts - and no different with
 // hipEventBlockingSync events, which this runtime also waits for actively.  So the waiters POLL the event and sleep in
 // between (hipEventQuery is a read of the completion signal): a 250 us nap costs a proof 0.3 % of its time in flight and
-// nothing of the GPU's, which the other proofs keep busy (wait_sleeping: shorter naps early on, for small circuits).  A latency context (one proof at a time: the wait IS the
-// latency) keeps the spinning synchronise.  CG_SPIN_WAIT=1 forces spinning everywhere (A/B).
+// nothing of the GPU's, which the other proofs keep busy (wait_sleeping: shorter naps early on, for small circuits).  A
+// latency context (one proof at a time: the wait IS the latency) keeps the spinning synchronise.  CG_SPIN_WAIT=1 forces
+// spinning everywhere (A/B).
 static bool spin_wait() {
     static const bool v = getenv("CG_SPIN_WAIT") != nullptr && getenv("CG_SPIN_WAIT")[0] == '1';
     return v;
