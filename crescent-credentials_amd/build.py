@@ -20,6 +20,9 @@ SYNTH_LIB = os.path.join(HERE, "libcg_synth.so")
 # and that the ABI links without Python or torch
 CALLER_SRC = os.path.join(HERE, "..", "integration", "c", "crescent_prove.c")
 CALLER_BIN = os.path.join(HERE, "..", "integration", "c", "crescent_prove")
+# a multi-threaded C host proving in a loop (steady-state proofs/s with no Python in the process)
+THROUGHPUT_SRC = os.path.join(HERE, "..", "integration", "c", "crescent_throughput.c")
+THROUGHPUT_BIN = os.path.join(HERE, "..", "integration", "c", "crescent_throughput")
 
 HIP_SOURCES = ["ntt.hip", "wmap29.hip", "msm.hip", "ecntt.hip", "prover.hip", "unit.hip", "setup.hip", "r1cs.hip", "serialize.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
@@ -108,6 +111,16 @@ def build(verbose: bool = False, jobs: int = int(os.environ.get("CG_BUILD_JOBS",
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("integration/c/crescent_prove build failed:\n" + r.stderr[-4000:])
+    if os.path.exists(THROUGHPUT_SRC) and (todo or not os.path.exists(THROUGHPUT_BIN) or
+                                           os.path.getmtime(THROUGHPUT_BIN) < max(os.path.getmtime(THROUGHPUT_SRC), hdr_t,
+                                                                                  os.path.getmtime(SYNTH_LIB))):
+        rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(_hipcc()))), "lib")
+        cmd = ["gcc", "-std=c11", "-O2", "-Wall", "-Wextra", "-Werror", "-pedantic", "-pthread",
+               "-I", os.path.join(HERE, "..", "include"), THROUGHPUT_SRC, "-o", THROUGHPUT_BIN, "-L", HERE, "-lcrescent_gpu", "-lcg_synth",
+               "-Wl,-rpath,$ORIGIN/../../crescent-credentials_amd", "-Wl,-rpath-link," + rocm_lib, "-Wl,-rpath," + rocm_lib]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("integration/c/crescent_throughput build failed:\n" + r.stderr[-4000:])
     return LIB
 
 

@@ -260,6 +260,24 @@ def test_two_gloo_ranks_with_real_hip_shards_under_sharded_prover(shape, tmp_pat
     assert len(set(want)) == 3
 
 
+def test_c_host_with_threads_proves_in_a_loop():
+    """integration/c/crescent_throughput: a plain C host (pthreads; no Python, no torch in the process) that sets up a key,
+    loads the circuit and proves in a loop from T + 2 threads with the witness in page-locked host memory, then the same
+    from pageable memory - the reference's server-side call pattern (sample/client_helper/src/main.rs:177-216) over the C
+    ABI alone"""
+    exe = os.path.join(ROOT, "integration", "c", "crescent_throughput")
+    assert os.path.exists(exe), "build() did not produce integration/c/crescent_throughput"
+    for extra in ([], ["--pageable"]):
+        run = subprocess.run([exe, "--shape", "20", "60000", "61000", "--slots", "4", "--proofs", "60", "--warmup", "8"] + extra,
+                             capture_output=True, text=True, timeout=600)
+        assert run.returncode == 0, run.stderr[-2000:]
+        d = json.loads(run.stdout.strip().splitlines()[-1])
+        assert d["proofs"] == 60 and d["proof_slots"] == 4 and d["caller_threads"] == 6 and d["proofs_per_s"] > 10
+        assert d["tuned"] == 1 and ("pageable" in d["witness"]) == bool(extra)
+    bad = subprocess.run([exe, "--slots", "99"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 2
+
+
 def _gpus():
     import torch
     return torch.cuda.device_count()
