@@ -19,7 +19,7 @@ Timed region.  Several proofs are in flight per GPU (that is how the latency-bou
 kernels of another), so a region of K proofs that starts and ends with an empty GPU contains a ramp-up and a drain that
 weigh more the smaller K is (K = 20 with 12 in flight is 1.7 pipeline fills).  The headline is therefore measured in
 steady state: after W warm-up proofs the stream of proofs keeps running and B consecutive blocks of EXACTLY K
-completions each are timed (B chosen so that B·K >= 240, odd); `ms_per_step` is the MEDIAN block's time / K, `blocks`
+completions each are timed (B chosen so that B·K >= 640, odd); `ms_per_step` is the MEDIAN block's time / K, `blocks`
 and `spread_pct` say how many and how far apart they were.  The classical bracket (barrier + synchronise, K proofs,
 synchronise + barrier; max over ranks) is measured in the same run and reported as `bracketed`.
 
@@ -81,7 +81,7 @@ def parse():
     ap.add_argument("--no-clock-probe", action="store_true",
                     help="do not sample the shader clock during the timed proofs (profiling runs: under rocprofv3 --pmc kernels "
                          "are serialised and the probe's sleeping wave would hold the others up)")
-    ap.add_argument("--blocks", type=int, default=0, help="timed blocks of --steps proofs (0 = enough for 240 proofs, at least 5, odd)")
+    ap.add_argument("--blocks", type=int, default=0, help="timed blocks of --steps proofs (0 = enough for 640 proofs, at least 5, odd)")
     return ap.parse_args()
 
 
@@ -219,7 +219,7 @@ def block_times(done, warmup, steps, blocks, t_start):
 def n_blocks(a):
     if a.blocks > 0:
         return a.blocks
-    b = max(5, math.ceil(240 / max(1, a.steps)))
+    b = max(5, math.ceil(640 / max(1, a.steps)))      # with 16 proofs in flight completions come in bursts: short blocks need many
     return b | 1
 
 

@@ -44,7 +44,7 @@ def test_block_count_and_block_times():
     class A:
         blocks = 0
         steps = 20
-    assert bench.n_blocks(A) == 13                      # 13 x 20 >= 240, odd
+    assert bench.n_blocks(A) == 33                      # 33 x 20 >= 640, odd
     A.steps = 400
     assert bench.n_blocks(A) == 5
     A.blocks = 4
