@@ -919,6 +919,9 @@ static bool g2_pair_kernel(bool latency_mode) {
     if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
     return latency_mode;
 }
+}  // namespace cg
+#include "batchaff.hpp"
+namespace cg {
 // T_max: the largest segment count the plan can hold for this engine (lanes beyond the plan's T return at once)
 template <class F29T>
 static void launch_accum_affine(const uint64_t* entries, const uint32_t* plan, uint32_t T_max, const uint32_t* table, uint32_t* bucket_sums,
@@ -1313,6 +1316,34 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
             colp_buf.alloc((size_t)ceil_div(R, RED_CHUNK) * C * wins * ACC);
         }
     }
+    ba_rounds = 0;
+    if constexpr (Words29<F29T>::NF == 1) {
+        if (const char* e = getenv("CG_BA_ROUNDS"); e && ba_allowed) ba_rounds = atoi(e) < 0 ? 0 : (atoi(e) > 6 ? 6 : atoi(e));
+        if (const char* e = getenv("CG_BA_SLOTS")) { const int v = atoi(e); if (v >= 1 && v <= 1024) ba_B = (uint32_t)v; }
+    }
+    if (ba_rounds) {
+        uint64_t ncap = cap_entries, out1 = 0, out2 = 0;
+        for (int r = 0; r < ba_rounds; ++r) {
+            const uint64_t scap = (ncap + 1) / 2;
+            ba_tcap[r] = (uint32_t)((ceil_div(scap, (uint64_t)ba_B) + 63) & ~(uint64_t)63);
+            uint64_t ocap = scap + nbuckets_total;
+            if (ocap > ncap) ocap = ncap;
+            if (r == 0) out1 = ocap;
+            if (r == 1) out2 = ocap;
+            ncap = ocap;
+        }
+        const size_t lanes = ba_tcap[0], slots = (size_t)lanes * ba_B;
+        ba_prefix.alloc(slots * 9);
+        ba_split.alloc(slots / 64 + 1);
+        ba_exc.alloc(slots / 64 + 1);
+        ba_wpre.alloc(slots / 64 + 1);
+        ba_totals.alloc(lanes * 9);
+        ba_inv.alloc(lanes * 9);
+        ba_chain.alloc((lanes + BA_GROUP) * 9);
+        ba_rec_a.alloc((out1 + 1) * BA_REC);
+        ba_rec_b.alloc((out2 + 1) * BA_REC);
+        ba_plan.alloc((size_t)(ba_rounds + 1) * BAP_WORDS + PLAN_WORDS);
+    }
     h_plan.alloc(PLAN_WORDS);
     for (int k = 0; k < PLAN_WORDS; ++k) h_plan.p[k] = 0;
     h_result.alloc((size_t)wins * (red_rbits + red_cbits1) * ACC);   // per window: the per-bit sums of rows, then of columns
@@ -1403,7 +1434,39 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
         const uint32_t* plan = counters.p;
         const uint64_t* grouped = adopted ? adopted : (bits2 ? ent_b.p : ent_a.p);
         CG_HIP(hipEventRecord(ev_t[3], st));
-        launch_accum_affine<F29T>(grouped, plan, max_segments, bases->table.p, bucket_sums.p, part_keys_a.p, part_pts_a.p, latency_mode, st);
+        bool ba_done = false;
+        if constexpr (Words29<F29T>::NF == 1) {
+            if (ba_rounds) {
+                // R pair rounds (batchaff.hpp), then the XYZZ accumulation over what is left under its own plan
+                uint32_t* plan2 = ba_plan.p + (size_t)(ba_rounds + 1) * BAP_WORDS;
+                k_ba_begin<<<1, 1, 0, st>>>(plan, ba_plan.p, ba_B);
+                CG_KERNEL_CHECK();
+                const uint32_t* recs_in = nullptr;
+                for (int r = 0; r < ba_rounds; ++r) {
+                    const uint32_t* bp = ba_plan.p + (size_t)r * BAP_WORDS;
+                    const bool last = r + 1 == ba_rounds;
+                    uint32_t* out = (r & 1) ? ba_rec_b.p : ba_rec_a.p;
+                    const uint32_t grid = ceil_div(ba_tcap[r], 256u);
+                    if (r == 0) k_ba_forward<0><<<grid, 256, 0, st>>>(grouped, bases->table.p, nullptr, bp, ba_B, ba_prefix.p, ba_totals.p, ba_split.p, ba_exc.p);
+                    else k_ba_forward<1><<<grid, 256, 0, st>>>(nullptr, nullptr, recs_in, bp, ba_B, ba_prefix.p, ba_totals.p, ba_split.p, ba_exc.p);
+                    CG_KERNEL_CHECK();
+                    k_ba_scan<<<1, 1024, 0, st>>>(ba_split.p, ba_wpre.p, bp, last ? nullptr : ba_plan.p + (size_t)(r + 1) * BAP_WORDS, ba_B,
+                                                  last ? plan2 : nullptr, acc_target_segments<F29T>(latency_mode), min_L);
+                    CG_KERNEL_CHECK();
+                    k_ba_invert<<<ceil_div(ceil_div(ba_tcap[r], BA_GROUP), 64u), 64, 0, st>>>(ba_totals.p, bp, ba_chain.p, ba_inv.p);
+                    CG_KERNEL_CHECK();
+                    if (r == 0) k_ba_backward<0><<<grid, 256, 0, st>>>(grouped, bases->table.p, nullptr, bp, ba_B, ba_prefix.p, ba_inv.p, ba_split.p, ba_exc.p, ba_wpre.p, out);
+                    else k_ba_backward<1><<<grid, 256, 0, st>>>(nullptr, nullptr, recs_in, bp, ba_B, ba_prefix.p, ba_inv.p, ba_split.p, ba_exc.p, ba_wpre.p, out);
+                    CG_KERNEL_CHECK();
+                    recs_in = out;
+                }
+                k_accum_records<<<ceil_div(max_segments, 256u), 256, 0, st>>>(recs_in, plan2, bucket_sums.p, part_keys_a.p, part_pts_a.p);
+                CG_KERNEL_CHECK();
+                plan = plan2;
+                ba_done = true;
+            }
+        }
+        if (!ba_done) launch_accum_affine<F29T>(grouped, plan, max_segments, bases->table.p, bucket_sums.p, part_keys_a.p, part_pts_a.p, latency_mode, st);
         CG_KERNEL_CHECK();
         CG_HIP(hipEventRecord(ev_t[4], st));
         // combine the segments' pieces wave by wave until one wave covers them all (k_combine_wave); the grids cover the

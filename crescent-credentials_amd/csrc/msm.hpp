@@ -70,6 +70,13 @@ struct MsmEngine {
     PinnedBuf<uint32_t> h_result;     // per window: red_rbits + red_cbits1 per-bit sums of the rows / the columns
     uint64_t n_scalars = 0;
     bool latency_mode = false;        // set before init(): short segments (one proof at a time matters more than proofs per second)
+    // batch-affine pair rounds in front of the accumulation (batchaff.hpp; G1 only; 0 = off)
+    bool ba_allowed = true;           // set before init()
+    int ba_rounds = 0;
+    uint32_t ba_B = 32;               // slots chained per lane
+    uint32_t ba_tcap[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // launch bound (lanes) of every round
+    DevBuf<uint32_t> ba_prefix, ba_totals, ba_inv, ba_chain, ba_wpre, ba_rec_a, ba_rec_b, ba_plan;
+    DevBuf<uint64_t> ba_split, ba_exc;
     // valid once the stream has been synchronised
     uint32_t n_entries() const { return h_plan.p ? h_plan.p[0] : 0; }
     uint32_t n_nonzero() const { return h_plan.p ? h_plan.p[3] : 0; }

@@ -468,6 +468,7 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
             for (auto& e : sl->ev_t) CG_HIP(hipEventCreate(&e));
             const bool latency = c->latency;
             sl->eh.latency_mode = sl->el.latency_mode = sl->ea.latency_mode = sl->eb1.latency_mode = sl->eb2.latency_mode = latency;
+            if (getenv("CG_BA_H_ONLY")) sl->el.ba_allowed = sl->ea.ba_allowed = sl->eb1.ba_allowed = false;   // experiment switch
             sl->eh.init(&c->bh); sl->el.init(&c->bl); sl->ea.init(&c->ba); sl->eb1.init(&c->bb1); sl->eb2.init(&c->bb2);
             sl->h_canon.alloc(D);
             sl->wm.alloc(M, D, std::max(c->A.sell_scratch, std::max(c->B.sell_scratch, c->C.sell_scratch)));

@@ -70,12 +70,14 @@ static int msm_load(cg_msm_ctx** out, int group, const uint8_t* bases, uint32_t 
                 import_bases<Fq>(bases, form, n, tmp.p, c->st);
                 c->b1.build(tmp.p, n, cbits, true, c->st);
                 CG_HIP(hipStreamSynchronize(c->st));
+                c->e1.latency_mode = true;      // one MSM at a time (calls on a handle serialise): short segments, tree reduction
                 c->e1.init(&c->b1);
             } else {
                 DevBuf<G2Affine> tmp(n);
                 import_bases<Fq2>(bases, form, n, tmp.p, c->st);
                 c->b2.build(tmp.p, n, cbits, true, c->st);
                 CG_HIP(hipStreamSynchronize(c->st));
+                c->e2.latency_mode = true;
                 c->e2.init(&c->b2);
             }
             c->scalars.alloc(n);
@@ -181,6 +183,7 @@ static int msm_unit(const uint8_t* bases, uint32_t form, uint64_t n_bases, const
         if (c < 2 || c > 22) throw HipError(CG_ERR_INVALID_ARGUMENT, "window_bits must be in [2, 22]");
         mb.build(pts.p, n, c, false, st);
         MsmEngine<F> eng;
+        eng.latency_mode = true;
         eng.init(&mb);
         eng.digits(sc.p, n, st);
         eng.accumulate(st);

@@ -382,6 +382,49 @@ def test_msm_grouping_and_combine_edge_cases(cc, oracle, group, n):
             ctx.close()
 
 
+@pytest.mark.parametrize("rounds", [1, 2, 4])
+def test_batch_affine_rounds_agree(cc, oracle, rounds, monkeypatch):
+    """The batch-affine pair rounds (csrc/batchaff.hpp; an experiment that is off by default, profiles/r03_s_batch_affine.txt)
+    give the same sums as the XYZZ accumulation, on the populations that reach their slow paths: one base repeated (every
+    pair a doubling, round after round), P and -P mixed (cancellations: identity records in the next round), an identity
+    base, an odd element count, buckets of one element (split pairs), uniform scalars."""
+    monkeypatch.setenv("CG_BA_ROUNDS", str(rounds))       # read when an engine is initialised
+    rng = random.Random(900 + rounds)
+    n = 3001
+    k0 = rng.randrange(1, oracle.R)
+    keysets = {
+        "distinct": [rng.randrange(1, oracle.R) for _ in range(n)],
+        "one base": [k0] * n,
+        "P and -P": [k0 if rng.random() < 0.5 else oracle.R - k0 for _ in range(n)],
+    }
+    keysets["distinct"][5] = 0
+    big = rng.randrange(oracle.R)
+    for kname, ks in keysets.items():
+        bases = cc.fixed_base_g1(_scalars(ks))
+        for wb in (5, 11, 0):
+            ctx = cc.MsmContext(bases, group=1, window_bits=wb)
+            try:
+                pops = {
+                    "one value": [big] * n,
+                    "ones": [1] * n,
+                    "uniform": [rng.randrange(oracle.R) for _ in range(n)],
+                    "sparse": [rng.randrange(oracle.R) if i % 97 == 0 else 0 for i in range(n)],
+                    "short": [rng.randrange(oracle.R) for _ in range(1000)],
+                }
+                for pname, sc in pops.items():
+                    e = sum(k * s_ for k, s_ in zip(ks, sc)) % oracle.R
+                    exp = oracle.g1_packed(oracle.G1.to_affine(oracle.G1.mul_affine(oracle.G1_GEN, e))) if e else bytes(64)
+                    assert ctx.run(_scalars(sc)) == exp, (rounds, kname, wb, pname)
+            finally:
+                ctx.close()
+    # the one-shot entry point (window index in the key, no window tables) takes the same rounds
+    ks = keysets["P and -P"]
+    sc = [rng.randrange(oracle.R) for _ in range(n)]
+    e = sum(k * s_ for k, s_ in zip(ks, sc)) % oracle.R
+    exp = oracle.g1_packed(oracle.G1.to_affine(oracle.G1.mul_affine(oracle.G1_GEN, e))) if e else bytes(64)
+    assert cc.msm_bigint_g1(cc.fixed_base_g1(_scalars(ks)), _scalars(sc)) == exp
+
+
 # ------------------------------------------------------------------------------------------- setup
 def _pk_from_json(cc, j):
     a = lambda h: np.frombuffer(bytes.fromhex(h), dtype=np.uint8).copy()
