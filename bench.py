@@ -66,6 +66,11 @@ def parse():
     ap.add_argument("--no-host-witness", action="store_true", help="skip the host-witness (cg_prove) sub-record")
     ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the sharded-proof sub-record")
     ap.add_argument("--sharded-steps", type=int, default=20)
+    ap.add_argument("--stall-rank", type=int, default=-1,
+                    help="testing aid: this rank stops before the sharded leg, as a rank that failed alone would (exercises --leg-timeout)")
+    ap.add_argument("--leg-timeout", type=int, default=300,
+                    help="N > 1: seconds the secondary legs (host witness, sharded proof) may take before rank 0 prints the line "
+                         "it has and every rank leaves (0 = no watchdog)")
     ap.add_argument("--shard-sim", type=int, default=0,
                     help="N = 1 only: time one proof split over this many sharded contexts on the one GPU, shard by shard")
     ap.add_argument("--window", type=int, default=0)
@@ -425,6 +430,23 @@ def main():
         "g1_msm_scalar_adds_per_s": round(g1_pairs * value, 1),      # pairs consumed per second of whole-job time
     }
 
+    # N > 1: the secondary legs below run collectives on a path that no multi-GPU box has exercised before the driver's own
+    # run.  Should one of them stall (a rank that failed alone leaves the others in a barrier), the headline measured above
+    # must not be lost with it: after --leg-timeout seconds rank 0 prints the line as it stands here, marked, and every rank
+    # leaves with exit code 0.
+    watchdog = None
+    if world > 1 and a.leg_timeout > 0:
+        core_line = json.dumps(out)
+
+        def bail():
+            if rank == 0:
+                note = "secondary legs did not finish within %d s: line printed by the watchdog without them" % a.leg_timeout
+                os.write(stdout_fd, (core_line[:-1] + ', "incomplete": %s}\n' % json.dumps(note)).encode())
+            os._exit(0)
+        watchdog = threading.Timer(a.leg_timeout + (0 if rank == 0 else 5), bail)
+        watchdog.daemon = True
+        watchdog.start()
+
     # ---- SURVEY §8d's metric as written: witness in HOST memory -> proof (cg_prove), pageable and page-locked ------------
     if not a.no_host_witness:
         hw = {"note": "the same steady-state measurement through cg_prove: every proof uploads its 32·M-byte assignment from "
@@ -471,6 +493,8 @@ def main():
 
     # ---- N > 1: one proof sharded over the ranks (config 4), measured in the same run --------------------------------
     if world > 1 and not a.no_sharded:
+        if rank == a.stall_rank:
+            time.sleep(10 ** 6)
         try:
             sp_ctx = cc.Prover(pk, cm, device=local_rank, window_bits=a.window, shard_rank=rank, shard_count=world,
                                h_coefficient_basis=a.h_coefficient_basis)
@@ -636,12 +660,18 @@ def main():
         if u:
             out["g1_msm_scalar_adds_per_s_uniform_scalars"] = u[0]["g1_msm_scalar_adds_per_s"]   # SURVEY §8d's definition
 
+    if watchdog:
+        watchdog.cancel()
     sys.stdout.flush()
     os.dup2(stdout_fd, 1)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         os.dup2(2, 1)
+        # the line is out: a process group that does not come down must not keep the ranks (and the driver) waiting
+        t_exit = threading.Timer(30, lambda: os._exit(0))
+        t_exit.daemon = True
+        t_exit.start()
         dist.destroy_process_group()
 
 

@@ -337,6 +337,14 @@ def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
     sh = d["sharded"]
     assert sh["ranks"] == 2 and sh["backend"] == "gloo" and sh["bytes_identical_to_unsharded"] is True
     assert sh["all_gathers"] == sh["proofs"] == 6 and set(sh["ms_breakdown_rank0"]) == {"partial", "gather", "assemble"}
+    # a rank that stops alone inside a secondary leg leaves the others in a barrier: the watchdog prints the headline that
+    # was measured, marked incomplete, and every rank leaves with exit code 0
+    run = subprocess.run(cmd + ["--stall-rank", "1", "--leg-timeout", "20"], env=env, capture_output=True, text=True, timeout=1500)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [x for x in run.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1, run.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "sharded" not in d and "watchdog" in d["incomplete"]
     # and with RCCL two ranks cannot share the one GPU: refused up front with a message, not a hang
     if __import__("torch").cuda.device_count() == 1:
         run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=env,
