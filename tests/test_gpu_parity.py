@@ -832,3 +832,36 @@ def test_non_canonical_witness_is_rejected(cc, oracle):
         assert prover.prove(_scalars(w), int(case["r"], 16), int(case["s"], 16)).data.hex() == case["proof"]
     finally:
         prover.close()
+
+
+def test_rejected_witnesses_among_proofs_in_flight(cc, oracle):
+    """A caller that hands over a non-canonical assignment gets its error; the proofs of the other callers in flight on
+    the same context at that moment are untouched (the rejection flag belongs to the proof slot), host and device witnesses
+    alike."""
+    from concurrent.futures import ThreadPoolExecutor
+    from crescent_credentials_amd import workloads as wl
+    l, m, M = 6, 3_000, 3_100
+    cm, w = wl.synthetic_circuit(78, l, m, M, 0.5, 3)
+    rng = random.Random(6)
+    pk = cc.generate_parameters_with_qap(cm, *(rng.randrange(1, oracle.R) for _ in range(4)))
+    bad = w.copy()
+    bad.reshape(-1, 32)[M // 2] = np.frombuffer(oracle.R.to_bytes(32, "little"), dtype=np.uint8)
+    jobs = [(k % 3 == 1, rng.randrange(oracle.R), rng.randrange(oracle.R)) for k in range(36)]
+    serial = cc.Prover(pk, cm)
+    par = cc.Prover(pk, cm, proof_slots=4)
+    try:
+        expect = [None if is_bad else serial.prove(w, r, s).data for is_bad, r, s in jobs]
+
+        def one(job):
+            is_bad, r, s = job
+            try:
+                return par.prove(bad if is_bad else w, r, s).data
+            except cc.CrescentGpuError as e:
+                assert e.code == -1 and "modulus" in str(e)
+                return None
+        with ThreadPoolExecutor(max_workers=6) as ex:
+            got = list(ex.map(one, jobs))
+        assert got == expect
+    finally:
+        serial.close(); par.close()
+
