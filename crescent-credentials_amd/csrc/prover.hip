@@ -212,6 +212,9 @@ struct cg_ctx {
     std::atomic<bool> tuned{false};   // read outside tune_mu by every finished proof
     std::atomic<int> retune_attempts{0};        // finished proofs whose statistics were looked at for the re-tune
     std::atomic<int> retune_skipped_memory{0};  // queries whose re-tuned table did not fit next to the old one
+    // a re-tune that failed AFTER a table was rebuilt, while the slots' engines were being re-sized for it: some engines
+    // are cut for the old window, the table is the new one.  Every later proof is refused (reload the circuit)
+    std::atomic<bool> broken{false};
     std::shared_mutex tune_mu;   // proofs hold it shared; a retune (and cg_circuit_free) holds it exclusively
     bool latency = false;
     // device bytes that stay resident (cg_ctx_get_info): window tables + validity flags | matrices and domain tables | one slot
@@ -734,9 +737,14 @@ static void snapshot_tune_stats(const cg_ctx* c, const ProofSlot* S, bool skip_b
 // a query's table changed size: every slot's engine for it is re-sized (the first slot's change is booked)
 template <class F>
 static void reinit_engines(cg_ctx* c, MsmEngine<F> ProofSlot::*eng, const MsmBases<F>& bases) {
-    for (size_t k = 0; k < c->slots.size(); ++k) {
-        AllocScope booking(k == 0 ? &c->slot_bytes : nullptr);
-        ((*c->slots[k]).*eng).init(&bases);
+    try {
+        for (size_t k = 0; k < c->slots.size(); ++k) {
+            AllocScope booking(k == 0 ? &c->slot_bytes : nullptr);
+            ((*c->slots[k]).*eng).init(&bases);
+        }
+    } catch (...) {
+        c->broken = true;     // the table is already the new one: engines and table no longer agree
+        throw;
     }
 }
 template <class F>
@@ -789,6 +797,7 @@ static void maybe_retune(cg_ctx* c, const TuneStats& ts) {
     }
 }
 
+static const char* const BROKEN_CONTEXT = "a window re-tune ran out of device memory while re-sizing the proof slots: free this context and load the circuit again";
 static int check_rs(const uint8_t r[32], const uint8_t s[32]) {
     if (!r || !s) return fail(CG_ERR_INVALID_ARGUMENT, "null r/s");
     if (!scalar_is_canonical(r) || !scalar_is_canonical(s)) return fail(CG_ERR_INVALID_ARGUMENT, "r/s not canonical (>= field modulus)");
@@ -800,6 +809,7 @@ static int prove_common(cg_ctx* ctx, const void* assignment, bool on_device, con
     if (!ctx || !assignment || !proof_out) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
     if (int e = check_rs(r, s)) return e;
     if (ctx->shard_count != 1) return fail(CG_ERR_INVALID_ARGUMENT, "context is a shard; use cg_prove_partial + cg_assemble");
+    if (ctx->broken) return fail(CG_ERR_OUT_OF_MEMORY, "%s", BROKEN_CONTEXT);
     try {
         Partials P;
         DeltaMultiples pre;
@@ -848,6 +858,7 @@ extern "C" int cg_prove_partial(cg_ctx* ctx, const void* full_assignment, int as
                                 uint8_t out_partials[384], cg_timings* timings) {
     if (!ctx || !full_assignment || !out_partials || !r) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
     if (!scalar_is_canonical(r)) return fail(CG_ERR_INVALID_ARGUMENT, "r not canonical");
+    if (ctx->broken) return fail(CG_ERR_OUT_OF_MEMORY, "%s", BROKEN_CONTEXT);
     try {
         Partials P;
         TuneStats ts;
