@@ -161,7 +161,9 @@ void cg_circuit_free(cg_ctx* ctx);
  * r, s: 32 B canonical each (prover.rs:150-151 samples them; r = s = 0 gives the no-zk proof,
  *       prover.rs:160-173).
  * proof_out: 256 B = ark-serialize uncompressed a ‖ b ‖ c (data_structures.rs:7-14).
- * timings may be NULL. */
+ * timings may be NULL.
+ * A failed one-time window re-tune never fails the proof it follows; if it ran out of device memory while the proof
+ * slots were being re-sized, every LATER proof on the context returns CG_ERR_OUT_OF_MEMORY (free and reload). */
 int cg_prove(cg_ctx* ctx, const uint8_t* full_assignment, const uint8_t r[32], const uint8_t s[32],
              uint8_t proof_out[256], cg_timings* timings);
 
