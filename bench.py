@@ -17,18 +17,30 @@ assignments of the same value distribution, so that no step repeats the previous
 
 Timed region.  Several proofs are in flight per GPU (that is how the latency-bound tails of one proof hide under the bulk
 kernels of another), so a region of K proofs that starts and ends with an empty GPU contains a ramp-up and a drain that
-weigh more the smaller K is (K = 20 with 12 in flight is 1.7 pipeline fills).  The headline is therefore measured in
+weigh more the smaller K is (K = 20 with 16 in flight is 1.25 pipeline fills).  The headline is therefore measured in
 steady state: after W warm-up proofs the stream of proofs keeps running and B consecutive blocks of EXACTLY K
-completions each are timed (B chosen so that B·K >= 640, odd); `ms_per_step` is the MEDIAN block's time / K, `blocks`
-and `spread_pct` say how many and how far apart they were.  The classical bracket (barrier + synchronise, K proofs,
-synchronise + barrier; max over ranks) is measured in the same run and reported as `bracketed`.
+completions each are timed (B chosen so that B·K >= 1500 whatever K is).  `value` = B·K proofs ÷ the time from the last
+warm-up completion to the last timed completion - proofs ÷ elapsed over the WHOLE steady window, no block dropped
+(max elapsed over ranks) - and `ms_per_step` is that time ÷ (B·K).  The median block (round 3's headline, which is biased
+high by up to 3 % on a bursty stream: long blocks are the ones a median drops) is kept as `timing.median_block`, and the
+classical bracket (barrier + synchronise, K proofs, synchronise + barrier; max over ranks) is measured in the same run
+and reported as `timing.bracketed`.
 
 Multi-GPU: `value` is always the replica throughput — proofs are independent objects, each rank proves its
-own stream with a full copy of the key, no data-path collective (config 5).  With N > 1 the same run then measures ONE
-proof range-sharded over the ranks (cg_prove_partial, a 384-byte all_gather, cg_assemble: config 4) and reports it as
-the `sharded` sub-record, with where its time went.
+own stream with a full copy of the key, no data-path collective (config 5); `value_per_rank` lists every rank's own rate.
+The CONTROL plane (barriers, max over ranks) always runs over gloo: the headline does not depend on RCCL coming up.  With
+N > 1 the same run then measures proofs range-sharded over the ranks (cg_prove_partial, a 384-byte all_gather,
+cg_assemble: config 4) - one at a time (latency) and several in flight per rank - and reports them as the `sharded`
+sub-record.  Only that leg opens an RCCL group, lazily, under the watchdog; if RCCL does not come up on every rank the
+failure is recorded in `sharded.error` and the leg runs over gloo, labelled `backend_fallback`.
+
+Checker (rank 0, after the timed region; the oracle is never the thing measured): one proof taken from the TIMED stream
+is verified by the Python oracle's pairing (`proof_verifies`, the reference's own acceptance criterion:
+forks/groth16/src/test.rs:70-71, verifier.rs:44-65) and compared with the trapdoor's closed form, and the GPU-made key
+the bench proves on is checked entry by entry against the trapdoor (`key_check`, oracle/keycheck.py).
 """
 import argparse
+import glob
 import json
 import math
 import os
@@ -65,7 +77,16 @@ def parse():
     ap.add_argument("--no-sweep", action="store_true", help="skip the secondary witness_sweep measurements")
     ap.add_argument("--no-host-witness", action="store_true", help="skip the host-witness (cg_prove) sub-record")
     ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the sharded-proof sub-record")
-    ap.add_argument("--sharded-steps", type=int, default=20)
+    ap.add_argument("--sharded-steps", type=int, default=20, help="N > 1: sharded proofs timed one at a time (latency)")
+    ap.add_argument("--sharded-inflight", type=int, default=4, help="N > 1: sharded proofs kept in flight per rank in the pipelined leg")
+    ap.add_argument("--sharded-stream", type=int, default=160, help="N > 1: sharded proofs of the pipelined leg")
+    ap.add_argument("--rccl-deadline", type=float, default=90.0,
+                    help="N > 1: seconds the RCCL data group may take to come up (creation + first all_gather) before the sharded leg "
+                         "falls back to gloo")
+    ap.add_argument("--strict-exit", action="store_true",
+                    help="N > 1: when the watchdog has to print the line, leave with exit code 4 instead of 0 (default 0: the line itself "
+                         "says `incomplete`, and a non-zero rank exit makes the launcher discard it)")
+    ap.add_argument("--no-check", action="store_true", help="skip the checker leg (proof_verifies, key_check)")
     ap.add_argument("--stall-rank", type=int, default=-1,
                     help="testing aid: this rank stops before the sharded leg, as a rank that failed alone would (exercises --leg-timeout)")
     ap.add_argument("--leg-timeout", type=int, default=300,
@@ -76,7 +97,9 @@ def parse():
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--h-coefficient-basis", action="store_true",
                     help="keep the h query as loaded and run the seventh transform per proof (A/B against the default)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for plumbing tests)")
+    ap.add_argument("--backend", default="nccl",
+                    help="N > 1: backend of the DATA plane (the sharded leg's 384-byte all_gather): nccl = RCCL, gloo for plumbing tests; "
+                         "the control plane is always gloo")
     ap.add_argument("--allow-shared-gpu", action="store_true",
                     help="N > visible GPUs: let several ranks share a GPU (implied by --backend gloo; RCCL needs a GPU per rank)")
     ap.add_argument("--inflight", type=int, default=16,
@@ -86,8 +109,27 @@ def parse():
     ap.add_argument("--no-clock-probe", action="store_true",
                     help="do not sample the shader clock during the timed proofs (profiling runs: under rocprofv3 --pmc kernels "
                          "are serialised and the probe's sleeping wave would hold the others up)")
-    ap.add_argument("--blocks", type=int, default=0, help="timed blocks of --steps proofs (0 = enough for 640 proofs, at least 5, odd)")
+    ap.add_argument("--blocks", type=int, default=0, help="timed blocks of --steps proofs (0 = enough for 1500 proofs, at least 3)")
     return ap.parse_args()
+
+
+def visible_gpus_without_hip() -> int:
+    """GPUs this process will see, counted without initialising the HIP runtime (which reads GPU_MAX_HW_QUEUES once, when
+    it starts): the *_VISIBLE_DEVICES list if there is one, else the KFD topology nodes that have SIMDs.  0 = unknown."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip():
+            return len([x for x in v.split(",") if x.strip()])
+    n = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            with open(f) as fh:
+                for line in fh:
+                    if line.startswith("simd_count "):
+                        n += int(line.split()[1]) > 0
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def self_launch(a) -> int:
@@ -224,8 +266,7 @@ def block_times(done, warmup, steps, blocks, t_start):
 def n_blocks(a):
     if a.blocks > 0:
         return a.blocks
-    b = max(5, math.ceil(640 / max(1, a.steps)))      # with 16 proofs in flight completions come in bursts: short blocks need many
-    return b | 1
+    return max(3, math.ceil(1500 / max(1, a.steps)))  # the steady window is >= 1500 proofs whatever --steps is
 
 
 def main():
@@ -240,10 +281,19 @@ def main():
     # (default 4), and kernels of streams that share a queue cannot overlap.  More than ~24 user queues per GPU and the
     # hardware scheduler time-slices them (15 ms stalls for a lone proof or a shard), so ranks that share a GPU (plumbing
     # runs) split the budget.  Must be set before the HIP runtime initialises.
-    import torch
-    ndev = max(1, torch.cuda.device_count())
-    ranks_per_gpu = max(1, math.ceil(world / ndev))
+    # (Counted without a torch device call: should torch ever count devices through hipGetDeviceCount, the runtime would
+    # have read its flags before the variable is set.)
+    ndev = visible_gpus_without_hip()
+    if ndev == 0:
+        import torch
+        ndev = max(1, torch.cuda.device_count())
+    ranks_per_gpu = max(1, math.ceil(int(os.environ.get("LOCAL_WORLD_SIZE", world)) / ndev))
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(16 if ranks_per_gpu == 1 else max(4, 16 // ranks_per_gpu)))
+    # the RCCL group of the sharded leg must never take the process down: no asynchronous tear-down on a failed or
+    # timed-out collective, no heartbeat monitor (the leg has its own deadline and falls back to gloo)
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+    os.environ.setdefault("TORCH_NCCL_ENABLE_MONITORING", "0")
+    import torch
     import numpy as np
     import torch.distributed as dist
 
@@ -258,14 +308,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(a.backend)
+        dist.init_process_group("gloo")        # the control plane; RCCL is opened by the sharded leg only (open_data_group)
 
     import crescent_credentials_amd as cc
     from crescent_credentials_amd import workloads as wl
-    from crescent_credentials_amd.distributed import ShardedProver, barrier_sync, max_over_ranks
+    from crescent_credentials_amd.distributed import (ShardedProver, barrier_sync, gather_over_ranks, max_over_ranks,
+                                                      open_data_group)
 
     assert cc.lib().cg_init(0, None) == 0, cc.lib().cg_last_error()
     cc.set_device(local_rank)          # the key generation below has no device argument (the library's runtime is not torch's)
@@ -295,9 +343,11 @@ def main():
         torch.cuda.synchronize()
 
     def measure(prove_k, steps, warmup, blocks, sync_ranks, clock=None, threads=None):
-        """-> (median block seconds [max over ranks], record).  prove_k(k): the k-th proof of the stream."""
+        """-> (seconds of the steady window of blocks x steps proofs [max over ranks], record, every rank's own proofs/s).
+        prove_k(k): the k-th proof of the stream."""
         threads = threads or inflight
-        total = warmup + blocks * steps + threads            # the tail keeps the last timed block in steady state
+        n_timed = blocks * steps
+        total = warmup + n_timed + threads                   # the tail keeps the end of the window in steady state
         if sync_ranks:
             barrier_sync(world)
         t_start = time.perf_counter()
@@ -309,15 +359,20 @@ def main():
             done = steady_stream(prove_k, total, threads)
         cpu_busy = (time.process_time() - cpu0) / max(1e-9, time.perf_counter() - t_start)
         torch.cuda.synchronize()
+        window = done[warmup + n_timed - 1] - (done[warmup - 1] if warmup > 0 else t_start)
         bt = sorted(block_times(done, warmup, steps, blocks, t_start))
         med = bt[len(bt) // 2]
-        rec = {"blocks": blocks, "spread_pct": round((bt[-1] - bt[0]) / med * 100.0, 2),
-               "block_ms_min_median_max": [round(bt[0] * 1e3, 2), round(med * 1e3, 2), round(bt[-1] * 1e3, 2)],
+        rec = {"window_proofs": n_timed, "window_s": round(window, 4), "blocks": blocks,
+               "median_block": {"ms_per_step": round(med / steps * 1e3, 3), "value_this_rank": round(steps / med, 3),
+                                "spread_pct": round((bt[-1] - bt[0]) / med * 100.0, 2),
+                                "block_ms_min_median_max": [round(bt[0] * 1e3, 2), round(med * 1e3, 2), round(bt[-1] * 1e3, 2)]},
                "host_cpus_busy": round(cpu_busy, 2)}     # process CPU seconds per second of the stream: what the callers cost the host
+        per_rank = [n_timed / window]
         if sync_ranks:
             barrier_sync(world)
-            med = max_over_ranks(med, world, dev)
-        return med, rec
+            per_rank = gather_over_ranks(n_timed / window, world)
+            window = max_over_ranks(window, world)
+        return window, rec, per_rank
 
     def bracketed(prove_k, steps, sync_ranks):
         """the classical region: empty GPU, K proofs, empty GPU"""
@@ -331,7 +386,7 @@ def main():
         if sync_ranks:
             barrier_sync(world)
         dt = time.perf_counter() - t0
-        return max_over_ranks(dt, world, dev) if sync_ranks else dt
+        return max_over_ranks(dt, world) if sync_ranks else dt
 
     def phase_record(prover, w_dev, reps=3):
         accs = [prover.prove_dev(w_dev.data_ptr(), *fresh_rs(), timings=True)[1] for _ in range(reps)]
@@ -352,18 +407,27 @@ def main():
     ws_dev = [torch.from_numpy(x).to(dev) for x in ws_np]
     torch.cuda.synchronize()
 
+    timed_sample = {}       # the latest proof the stream made on the SATISFYING assignment (the permuted ones satisfy nothing)
+
     def prove_dev_k(k):
-        prover.prove_dev(ws_dev[k % len(ws_dev)].data_ptr(), *fresh_rs())
+        j = k % len(ws_dev)
+        r_, s_ = fresh_rs()
+        p = prover.prove_dev(ws_dev[j].data_ptr(), r_, s_)
+        if j == 0:
+            timed_sample["proof"] = (k, r_, s_, p.data)
 
     blocks = n_blocks(a)
+    n_timed = blocks * a.steps
     prime(prove_dev_k)
     clock = ClockSampler(cc, local_rank) if rank == 0 and not a.no_clock_probe else None
-    dt, timing = measure(prove_dev_k, a.steps, a.warmup, blocks, True, clock)
-    value = a.steps * world / dt
+    dt, timing, per_rank = measure(prove_dev_k, a.steps, a.warmup, blocks, True, clock)
+    value = n_timed * world / dt
+    checked_proof = timed_sample.get("proof")           # taken before any later leg overwrites it
     dt_br = bracketed(prove_dev_k, a.steps, True)
     info = prover.info()
-    log("steady state %.2f proofs/s (median of %d blocks of %d, spread %.1f %%); bracketed %.2f; shader clock %s GHz" %
-        (value, blocks, a.steps, timing["spread_pct"], a.steps * world / dt_br, clock.median() if clock else None))
+    log("steady state %.2f proofs/s (%d proofs in %.2f s; median block %.2f, spread %.1f %%); bracketed %.2f; shader clock %s GHz" %
+        (value, n_timed, dt, timing["median_block"]["value_this_rank"] * world, timing["median_block"]["spread_pct"],
+         a.steps * world / dt_br, clock.median() if clock else None))
 
     tm, phases = phase_record(prover, ws_dev[0])
     g1_pairs, g2_pairs = tm["msm_g1_pairs"], tm["msm_g2_pairs"]
@@ -404,18 +468,19 @@ def main():
     out = {
         "metric": "Groth16 proofs/sec (rs256-sd-shaped circuit, BN254), G1 MSM scalar-adds/sec reported alongside",
         "value": round(value, 3), "unit": "proofs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+        "ms_per_step": round(dt / n_timed * 1e3, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (BN254 Fq/Fr, 254-bit modular integers)",
         "data": "synthetic",
-        "timing": dict(timing, method="steady state: median of `blocks` consecutive blocks of `steps` proof completions, "
-                                      "pipeline kept primed (max over ranks)",
+        "value_per_rank": [round(x, 3) for x in per_rank],
+        "timing": dict(timing, method="steady state: `blocks` x `steps` consecutive proof completions with the pipeline kept primed; "
+                                      "value = proofs / elapsed over that whole window (max elapsed over ranks)",
                        bracketed={"ms_per_step": round(dt_br / a.steps * 1e3, 3), "value": round(a.steps * world / dt_br, 3),
                                   "method": "barrier + synchronise, `steps` proofs, synchronise + barrier (max over ranks)"}),
         "config": {"workload": "%s shape: D=2^%d, m=%d, M=%d, l=%d, nnz=%d (%s mix); bit_fraction=%.2f; pk from seeded trapdoor (GPU setup)" %
                    (a.shape, prover.domain_size.bit_length() - 1, m, M, l, nnz, a.profile, a.bits),
                    "wires": wires, "mode": "throughput (one full key replica per GPU)",
                    "h_query_basis": "coefficient" if a.h_coefficient_basis else "coset evaluation (transformed at load)",
-                   "proofs_per_rank": a.steps * blocks, "proofs_in_flight_per_gpu": inflight,
+                   "proofs_per_rank": n_timed, "proofs_in_flight_per_gpu": inflight,
                    "inputs": "%d assignments resident in HBM, taken in rotation; (r,s) fresh per proof" % len(ws_dev),
                    "context": {"resident_GB": round(info["total_bytes"] / 1e9, 2), "tables_GB": round(info["table_bytes"] / 1e9, 2),
                                "per_slot_GB": round(info["slot_bytes"] / 1e9, 3), "matrices_GB": round(info["matrix_bytes"] / 1e9, 3),
@@ -430,10 +495,32 @@ def main():
         "g1_msm_scalar_adds_per_s": round(g1_pairs * value, 1),      # pairs consumed per second of whole-job time
     }
 
+    # ---- checker, first part (rank 0, any N): the reference's acceptance criterion on a proof of the TIMED stream --------
+    # (the oracle is the checker here, never the thing measured; ~1.5 s of Python pairing)
+    oracle_mods = None
+    if rank == 0 and not a.no_check:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import bn254_oracle
+            import cpu_ref
+            import keycheck
+            oracle_mods = (bn254_oracle, cpu_ref, keycheck)
+            k_, r_, s_, data_ = checked_proof
+            out["proof_verifies"] = bool(keycheck.verify(bn254_oracle, pk, l, w_np, data_))
+            out["proof_checked"] = {"which": "proof %d of the timed stream (the latest one on the satisfying assignment)" % k_,
+                                    "how": "verifier.rs:44-65 by the Python oracle's pairing on the GPU-made vk; a flipped public "
+                                           "input is refused"}
+            log("timed proof %d verifies: %s" % (k_, out["proof_verifies"]))
+        except Exception as e:   # a checker that cannot run is reported, a proof that does not verify fails the run below
+            out["proof_verifies"] = None
+            out["proof_checked"] = {"error": repr(e)}
+        assert out["proof_verifies"] is not False, "a proof of the timed stream does not verify"
+
     # N > 1: the secondary legs below run collectives on a path that no multi-GPU box has exercised before the driver's own
     # run.  Should one of them stall (a rank that failed alone leaves the others in a barrier), the headline measured above
-    # must not be lost with it: after --leg-timeout seconds rank 0 prints the line as it stands here, marked, and every rank
-    # leaves with exit code 0.
+    # must not be lost with it: after --leg-timeout seconds rank 0 prints the line as it stands here, marked `incomplete`,
+    # and every rank leaves - with exit code 0 by default, because a non-zero rank makes the launcher (and whoever runs it)
+    # discard the line that was just printed; --strict-exit turns that into exit code 4.
     watchdog = None
     if world > 1 and a.leg_timeout > 0:
         core_line = json.dumps(out)
@@ -442,7 +529,8 @@ def main():
             if rank == 0:
                 note = "secondary legs did not finish within %d s: line printed by the watchdog without them" % a.leg_timeout
                 os.write(stdout_fd, (core_line[:-1] + ', "incomplete": %s}\n' % json.dumps(note)).encode())
-            os._exit(0)
+            print("[bench] rank %d: watchdog after %d s in the secondary legs" % (rank, a.leg_timeout), file=sys.stderr, flush=True)
+            os._exit(4 if a.strict_exit else 0)
         watchdog = threading.Timer(a.leg_timeout + (0 if rank == 0 else 5), bail)
         watchdog.daemon = True
         watchdog.start()
@@ -452,7 +540,8 @@ def main():
         hw = {"note": "the same steady-state measurement through cg_prove: every proof uploads its 32·M-byte assignment from "
                       "host memory first (the reference's caller has the witness on the host, creds/src/lib.rs:274-283); "
                       "uploads overlap the other proofs in flight (proof_slots + 2 caller threads)"}
-        hblocks = max(3, blocks // 2) | 1
+        hblocks = max(3, blocks // 2)
+        hn = hblocks * a.steps
         try:
             def prove_pageable_k(k):
                 x = ws_np[k % len(ws_np)]
@@ -462,8 +551,8 @@ def main():
             # assignments arrive while every working set is busy
             callers = inflight + 2
             steady_stream(prove_pageable_k, prime_n, callers)
-            d_p, rec_p = measure(prove_pageable_k, a.steps, min(a.warmup, inflight), hblocks, True, threads=callers)
-            hw["pageable"] = dict(rec_p, proofs_per_s=round(a.steps * world / d_p, 3), ms_per_step=round(d_p / a.steps * 1e3, 3))
+            d_p, rec_p, _ = measure(prove_pageable_k, a.steps, min(a.warmup, inflight), hblocks, True, threads=callers)
+            hw["pageable"] = dict(rec_p, proofs_per_s=round(hn * world / d_p, 3), ms_per_step=round(d_p / hn * 1e3, 4))
             pinned = [cc.HostBuffer(x.size) for x in ws_np]
             for hb, x in zip(pinned, ws_np):
                 hb.array[:] = x
@@ -471,10 +560,10 @@ def main():
             def prove_pinned_k(k):
                 prover.prove_host_ptr(pinned[k % len(pinned)].ptr, *fresh_rs())
             steady_stream(prove_pinned_k, prime_n, callers)
-            d_l, rec_l = measure(prove_pinned_k, a.steps, min(a.warmup, inflight), hblocks, True, threads=callers)
-            hw["pinned"] = dict(rec_l, proofs_per_s=round(a.steps * world / d_l, 3), ms_per_step=round(d_l / a.steps * 1e3, 3))
-            hw["pinned_over_device_resident"] = round((a.steps * world / d_l) / value, 4)
-            hw["pageable_over_device_resident"] = round((a.steps * world / d_p) / value, 4)
+            d_l, rec_l, _ = measure(prove_pinned_k, a.steps, min(a.warmup, inflight), hblocks, True, threads=callers)
+            hw["pinned"] = dict(rec_l, proofs_per_s=round(hn * world / d_l, 3), ms_per_step=round(d_l / hn * 1e3, 4))
+            hw["pinned_over_device_resident"] = round((hn * world / d_l) / value, 4)
+            hw["pageable_over_device_resident"] = round((hn * world / d_p) / value, 4)
             _, tmu = prover.prove_host_ptr(pinned[0].ptr, *fresh_rs(), timings=True)
             hw["upload_ms_one_proof_alone"] = round(tmu["upload_ms"], 3)
             hw["upload_bytes"] = int(ws_np[0].size)
@@ -491,15 +580,25 @@ def main():
             hw["error"] = repr(e)
         out["host_witness"] = hw
 
-    # ---- N > 1: one proof sharded over the ranks (config 4), measured in the same run --------------------------------
+    # ---- N > 1: proofs sharded over the ranks (config 4), measured in the same run -------------------------------------
     if world > 1 and not a.no_sharded:
         if rank == a.stall_rank:
             time.sleep(10 ** 6)
+        sh = {"ranks": world, "ranks_per_gpu": ranks_per_gpu, "backend_requested": a.backend}
         try:
+            # the DATA plane: RCCL, opened here and nowhere else, with a deadline; every rank ends up on the same backend
+            grp, used, rccl_err = open_data_group(dev, a.backend, a.rccl_deadline)
+            sh["backend"] = used
+            if rccl_err:
+                sh["error"] = "%s group did not come up on this rank set: %s" % (a.backend, rccl_err)
+                sh["backend_fallback"] = used
+                log("sharded leg: %s -> falling back to %s" % (sh["error"], used))
+            srng = random.Random(99)                     # the same (r, s) on every rank
+            kfl = max(1, a.sharded_inflight)
+            # one proof at a time: a latency context (five streams); several in flight: a throughput context with kfl slots
             sp_ctx = cc.Prover(pk, cm, device=local_rank, window_bits=a.window, shard_rank=rank, shard_count=world,
                                h_coefficient_basis=a.h_coefficient_basis)
-            sp = ShardedProver(sp_ctx, dev)
-            srng = random.Random(99)                     # the same (r, s) on every rank
+            sp = ShardedProver(sp_ctx, dev, group=grp)
             for _ in range(3):
                 sp.prove_dev(ws_dev[0].data_ptr(), srng.randrange(R), srng.randrange(R))
             barrier_sync(world)
@@ -510,7 +609,7 @@ def main():
                 sp.prove_dev(ws_dev[k % len(ws_dev)].data_ptr(), srng.randrange(R), srng.randrange(R))
             torch.cuda.synchronize()
             barrier_sync(world)
-            ds = max_over_ranks(time.perf_counter() - t_start, world, dev)
+            ds = max_over_ranks(time.perf_counter() - t_start, world)
             gathers = sp.all_gathers - gathers0
             breakdown = sp.breakdown_ms()
             # this rank's shard with nothing else on the GPU queue (ranks that share a GPU take turns): the time a rank of a
@@ -524,25 +623,57 @@ def main():
                         sp_ctx.prove_partial(ws_dev[k % len(ws_dev)].data_ptr(), srng.randrange(R), on_device=True)
                     alone = (time.perf_counter() - t1) / 5 * 1e3
             barrier_sync(world)
-            alone_max = max_over_ranks(alone, world, dev)
+            alone_max = max_over_ranks(alone, world)
             # every rank assembled the same bytes as the unsharded context does
             r_, s_ = srng.randrange(R), srng.randrange(R)
-            same = sp.prove_dev(ws_dev[0].data_ptr(), r_, s_).data == prover.prove_dev(ws_dev[0].data_ptr(), r_, s_).data
-            out["sharded"] = {"mode": "one proof: l/a/b queries range-sharded over the ranks, the h query by coset points j = rank (mod ranks) "
-                                      "(two of a shard's four transforms shrink by the rank count); 5 partial points per rank",
-                              "ranks": world, "backend": dist.get_backend(), "proofs": a.sharded_steps,
-                              "ranks_per_gpu": ranks_per_gpu,
-                              "ms_per_proof": round(ds / a.sharded_steps * 1e3, 3), "proofs_per_s": round(a.sharded_steps / ds, 3),
-                              "ms_breakdown_rank0": breakdown,
-                              "ms_per_shard_alone_on_its_gpu_max": round(alone_max, 3),
-                              "all_gathers": gathers, "all_gather_bytes_per_rank": 384,
-                              "scaling": "strong", "bytes_identical_to_unsharded": bool(same)}
+            want = prover.prove_dev(ws_dev[0].data_ptr(), r_, s_).data
+            same = sp.prove_dev(ws_dev[0].data_ptr(), r_, s_).data == want
+            sh.update({"mode": "l/a/b queries range-sharded over the ranks, the h query by coset points j = rank (mod ranks) (two of a "
+                               "shard's four transforms shrink by the rank count); 5 partial points per rank and proof",
+                       "proofs": a.sharded_steps, "proofs_in_flight": 1,
+                       "ms_per_proof": round(ds / a.sharded_steps * 1e3, 3), "proofs_per_s": round(a.sharded_steps / ds, 3),
+                       "ms_breakdown_rank0": breakdown, "ms_per_shard_alone_on_its_gpu_max": round(alone_max, 3),
+                       "all_gathers": gathers, "all_gather_bytes_per_rank": 384,
+                       "scaling": "strong", "bytes_identical_to_unsharded": bool(same)})
             assert same, "sharded and unsharded proofs differ"
             sp_ctx.close()
+            # several sharded proofs in flight per rank (the reference's host runs one task per credential concurrently,
+            # sample/client_helper/src/main.rs:177-216): partial sums of proofs k+1.. on the GPU while proof k's record is
+            # exchanged and finished
+            if kfl > 1:
+                pp_ctx = cc.Prover(pk, cm, device=local_rank, window_bits=a.window, shard_rank=rank, shard_count=world,
+                                   proof_slots=kfl, h_coefficient_basis=a.h_coefficient_basis)
+                pp = ShardedProver(pp_ctx, dev, group=grp)
+                njobs = max(4 * kfl, a.sharded_stream)
+                mk = lambda n_: [(ws_dev[k % len(ws_dev)].data_ptr(), srng.randrange(R), srng.randrange(R)) for k in range(n_)]
+                pp.prove_stream(mk(2 * kfl), kfl)              # first proofs + the one-time re-tune
+                barrier_sync(world)
+                jobs = mk(njobs)
+                times = []
+                g0 = pp.all_gathers
+                pp.reset_breakdown()
+                proofs = pp.prove_stream(jobs, kfl, done_times=times)
+                torch.cuda.synchronize()
+                barrier_sync(world)
+                times.sort()
+                skip = kfl                                     # the ramp-up: the first kfl completions
+                win = max_over_ranks(times[-1] - times[skip - 1], world)
+                rate = (njobs - skip) / win
+                same_p = proofs[0] is not None and proofs[0].data == prover.prove_dev(jobs[0][0], jobs[0][1], jobs[0][2]).data
+                sh["in_flight"] = {"proofs_in_flight": kfl, "proofs": njobs, "proofs_per_s": round(rate, 3),
+                                   "ms_per_proof": round(1e3 / rate, 3), "over_replica_rate_of_the_same_ranks": round(rate / value, 4),
+                                   "ms_breakdown_rank0": pp.breakdown_ms(), "all_gathers": pp.all_gathers - g0,
+                                   "bytes_identical_to_unsharded": bool(same_p),
+                                   "note": "every shard repeats the two sparse products and the two full-size inverse transforms of the "
+                                           "witness map (DESIGN.md 6), so sharded proofs cost more GPU time in total than whole ones: "
+                                           "sharding buys latency, replicas buy throughput"}
+                assert same_p, "pipelined sharded proof differs from the unsharded one"
+                pp_ctx.close()
         except AssertionError:
             raise
         except Exception as e:     # the throughput value above stands on its own: report the failure instead of losing the line
-            out["sharded"] = {"error": repr(e), "ranks": world}
+            sh["error"] = (sh.get("error", "") + " | " if sh.get("error") else "") + repr(e)
+        out["sharded"] = sh
 
     # ---- N = 1 diagnostic: one proof over k sharded contexts on this one GPU, shard by shard ----------------
     if world == 1 and a.shard_sim > 1:
@@ -570,6 +701,26 @@ def main():
             sh.close()
 
     # ---- CPU baseline: the arkworks-equivalent C restatement on this box's host cores, SAME inputs -------
+    # ---- checker, second part (rank 0): is the key the bench proves on a Groth16 key for this circuit? -----------------
+    if rank == 0 and oracle_mods is not None:
+        try:
+            bn254_oracle, cpu_ref, keycheck = oracle_mods
+            t_k = time.perf_counter()
+            ktrap = tuple(trap)                                   # (alpha, beta, delta, tau), the order cg_setup takes
+            scal = keycheck.check_key(bn254_oracle, cpu_ref, pk, cm, l, m, M, ktrap, nthreads=cpu_ref.best_threads())
+            k_, r_, s_, data_ = checked_proof
+            cf = keycheck.closed_form(bn254_oracle, cpu_ref, scal, ktrap, r_, s_, w_np, l) == keycheck.decode_proof(bn254_oracle, data_)
+            out["key_check"] = {"ok": True, "proof_equals_trapdoor_closed_form": bool(cf), "seconds": round(time.perf_counter() - t_k, 1),
+                                "how": "oracle/keycheck.py: fixed points and gamma_abc, a strided sample, and a random linear combination "
+                                       "over ALL entries of the five queries against the trapdoor's scalars (r1cs_to_qap.rs:103-147, "
+                                       "generator.rs:118-194 restated in oracle/cpu_ref.c) - no code shared with cg_setup"}
+            assert cf, "the timed proof is not the trapdoor's closed form"
+        except AssertionError as e:
+            out["key_check"] = {"ok": False, "error": repr(e)}
+            raise
+        except Exception as e:
+            out["key_check"] = {"ok": None, "error": repr(e)}
+
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -647,12 +798,13 @@ def main():
             def prove_sweep_k(k, ps=ps, wsd=wsd):
                 ps.prove_dev(wsd[k % len(wsd)].data_ptr(), *fresh_rs())
             prime(prove_sweep_k)
-            d_s, rec_s = measure(prove_sweep_k, ksteps, inflight, 3, False)
+            d_s, rec_s, _ = measure(prove_sweep_k, ksteps, inflight, 3, False)
             tms, phs = phase_record(ps, wsd[0], reps=1)
             sweep.append({"bit_fraction": bf, "wires": wl.wire_stats(w_s), "nnz": cm_s.a.nnz + cm_s.b.nnz + cm_s.c.nnz,
-                          "proofs_per_s": round(ksteps / d_s, 3), "g1_msm_scalar_adds_per_s": round(tms["msm_g1_pairs"] * ksteps / d_s, 1),
+                          "proofs_per_s": round(3 * ksteps / d_s, 3), "g1_msm_scalar_adds_per_s": round(tms["msm_g1_pairs"] * 3 * ksteps / d_s, 1),
                           "entries_g1": tms["entries_g1"], "entries_g2": tms["entries_g2"],
-                          "accum_g1_ms": phs["accum_g1_ms"], "witness_map_ms": phs["witness_map_ms"], "spread_pct": rec_s["spread_pct"]})
+                          "accum_g1_ms": phs["accum_g1_ms"], "witness_map_ms": phs["witness_map_ms"],
+                          "window_proofs": rec_s["window_proofs"], "block_spread_pct": rec_s["median_block"]["spread_pct"]})
             ps.close()
             del wsd
         out["witness_sweep"] = sweep

@@ -216,6 +216,9 @@ struct cg_ctx {
     // are cut for the old window, the table is the new one.  Every later proof is refused (reload the circuit)
     std::atomic<bool> broken{false};
     std::shared_mutex tune_mu;   // proofs hold it shared; a retune (and cg_circuit_free) holds it exclusively
+    // entry points that are still somewhere inside this context (CallGuard): a call lets go of tune_mu before its re-tune
+    // check and its host finish, both of which read the context, so cg_circuit_free waits for this count as well
+    std::atomic<int> calls_inside{0};
     bool latency = false;
     // device bytes that stay resident (cg_ctx_get_info): window tables + validity flags | matrices and domain tables | one slot
     int64_t table_bytes = 0, matrix_bytes = 0, slot_bytes = 0;
@@ -235,6 +238,13 @@ struct cg_ctx {
         std::lock_guard<std::mutex> lk(pick_mu);
         pick_cv.notify_one();
     }
+};
+struct CallGuard {
+    cg_ctx* c;
+    explicit CallGuard(cg_ctx* ctx) : c(ctx) { if (c) c->calls_inside.fetch_add(1, std::memory_order_acq_rel); }
+    CallGuard(const CallGuard&) = delete;
+    CallGuard& operator=(const CallGuard&) = delete;
+    ~CallGuard() { if (c) c->calls_inside.fetch_sub(1, std::memory_order_acq_rel); }
 };
 struct UploadGuard {
     cg_ctx* c = nullptr;
@@ -439,9 +449,10 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         // the saturated-form tables were only the source of the packed ones
         c->dom.tw_fwd.release(); c->dom.tw_inv.release(); c->dom.coset_br.release(); c->dom.icoset_br.release();
         c->A.dict.release(); c->B.dict.release(); c->C.dict.release();
-        // a shard of one proof, or a context that proves one proof at a time, is a latency job; several proofs in
-        // flight are a throughput job
-        c->latency = c->shard_count > 1 || n_slots == 1;
+        // a context that proves one proof at a time (whole, or its shard of one) is a latency job; several proofs in
+        // flight - whole proofs, or this rank's shards of several proofs (distributed.ShardedProver, proofs_in_flight) -
+        // are a throughput job
+        c->latency = n_slots == 1;
         if (const char* e = getenv("CG_LATENCY_MODE")) c->latency = e[0] == '1';    // profiling aid: force either segment length
         for (int k = 0; k < n_slots; ++k) {
             book(k == 0 ? &c->slot_bytes : nullptr);      // the slots are identical: the first one is booked
@@ -497,10 +508,13 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
 extern "C" void cg_circuit_free(cg_ctx* ctx) {
     if (!ctx) return;
     {   // proofs hold tune_mu shared from slot acquisition to their last stream synchronisation: taking it exclusively
-        // waits for every cg_prove* still inside this context (a caller must not START a call after this one, as with
-        // any handle)
+        // waits for the GPU part of every cg_prove* still inside this context ...
         std::unique_lock<std::shared_mutex> drain(ctx->tune_mu);
     }
+    // ... and the count of calls inside covers their tails, which run without the lock (the re-tune check takes it
+    // exclusively itself; the host finish reads the context's fixed points).  A caller must not START a call after this
+    // one, as with any handle.
+    while (ctx->calls_inside.load(std::memory_order_acquire) > 0) std::this_thread::sleep_for(std::chrono::microseconds(50));
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     delete ctx;
@@ -738,6 +752,8 @@ static void snapshot_tune_stats(const cg_ctx* c, const ProofSlot* S, bool skip_b
 template <class F>
 static void reinit_engines(cg_ctx* c, MsmEngine<F> ProofSlot::*eng, const MsmBases<F>& bases) {
     try {
+        // CG_FAULT_RETUNE=1 (testing aid): fail here as an allocation would, table rebuilt and engines not yet re-sized
+        if (const char* f = getenv("CG_FAULT_RETUNE")) if (f[0] == '1') throw HipError(CG_ERR_OUT_OF_MEMORY, "injected: out of device memory while re-sizing the proof slots");
         for (size_t k = 0; k < c->slots.size(); ++k) {
             AllocScope booking(k == 0 ? &c->slot_bytes : nullptr);
             ((*c->slots[k]).*eng).init(&bases);
@@ -810,6 +826,7 @@ static int prove_common(cg_ctx* ctx, const void* assignment, bool on_device, con
     if (int e = check_rs(r, s)) return e;
     if (ctx->shard_count != 1) return fail(CG_ERR_INVALID_ARGUMENT, "context is a shard; use cg_prove_partial + cg_assemble");
     if (ctx->broken) return fail(CG_ERR_OUT_OF_MEMORY, "%s", BROKEN_CONTEXT);
+    CallGuard inside(ctx);
     try {
         Partials P;
         DeltaMultiples pre;
@@ -818,6 +835,9 @@ static int prove_common(cg_ctx* ctx, const void* assignment, bool on_device, con
         int e;
         {
             std::shared_lock<std::shared_mutex> tl(ctx->tune_mu);
+            // a caller that passed the check above can have waited here for another thread's re-tune, and that re-tune can
+            // have failed half-way: the engines of the slots are then cut for the old window against the rebuilt table
+            if (ctx->broken) return fail(CG_ERR_OUT_OF_MEMORY, "%s", BROKEN_CONTEXT);
             UploadGuard up;                       // declared before the slot: released after it
             float upload_ms = 0.f;
             const Fr* w_dev = (const Fr*)assignment;
@@ -859,12 +879,14 @@ extern "C" int cg_prove_partial(cg_ctx* ctx, const void* full_assignment, int as
     if (!ctx || !full_assignment || !out_partials || !r) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
     if (!scalar_is_canonical(r)) return fail(CG_ERR_INVALID_ARGUMENT, "r not canonical");
     if (ctx->broken) return fail(CG_ERR_OUT_OF_MEMORY, "%s", BROKEN_CONTEXT);
+    CallGuard inside(ctx);
     try {
         Partials P;
         TuneStats ts;
         int e;
         {
             std::shared_lock<std::shared_mutex> tl(ctx->tune_mu);
+            if (ctx->broken) return fail(CG_ERR_OUT_OF_MEMORY, "%s", BROKEN_CONTEXT);     // as in prove_common
             UploadGuard up;
             float upload_ms = 0.f;
             const Fr* w_dev = (const Fr*)full_assignment;
@@ -891,6 +913,7 @@ extern "C" int cg_assemble(cg_ctx* ctx, const uint8_t* partials, uint32_t n_shar
                            uint8_t proof_out[256]) {
     if (!ctx || !partials || !proof_out || n_shards == 0) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
     if (int e = check_rs(r, s)) return e;
+    CallGuard inside(ctx);
     try {
         G1XYZZ h = G1XYZZ::inf(), l = G1XYZZ::inf(), a = G1XYZZ::inf(), b1 = G1XYZZ::inf();
         G2XYZZ b2 = G2XYZZ::inf();
@@ -912,9 +935,11 @@ extern "C" int cg_assemble(cg_ctx* ctx, const uint8_t* partials, uint32_t n_shar
 
 extern "C" int cg_witness_map(cg_ctx* ctx, const uint8_t* full_assignment, uint8_t* h_out) {
     if (!ctx || !full_assignment || !h_out) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
+    CallGuard inside(ctx);
     try {
         CG_HIP(hipSetDevice(ctx->device));
         std::shared_lock<std::shared_mutex> tl(ctx->tune_mu);
+        if (ctx->broken) return fail(CG_ERR_OUT_OF_MEMORY, "%s", BROKEN_CONTEXT);
         UploadGuard up;
         up.take(ctx);
         (void)upload_assignment(ctx, up.u, full_assignment, false);

@@ -1,4 +1,4 @@
-"""Multi-GPU plumbing: one process per GPU, torch.distributed over RCCL ("nccl").
+"""Multi-GPU plumbing: one process per GPU, torch.distributed.
 
 The prove path shards in two ways:
   * independent proofs (the reference's own concurrency model: one credential per task,
@@ -7,17 +7,27 @@ The prove path shards in two ways:
     each rank computes partial sums over its contiguous range of every query, and the only exchange
     step is an all_gather of 384 bytes per rank (four G1 points + one G2 point), after which every rank
     (or just rank 0) finishes A, B, C exactly as prover.rs:76-135.
+
+Two process groups, on purpose:
+  * the CONTROL plane (barriers, max-over-ranks of a timing, agreement on what to do next) always runs over gloo on host
+    tensors: it carries a few bytes, and nothing that is measured may depend on a GPU collective having come up;
+  * the DATA plane - the 384-byte all_gather of a sharded proof - runs over RCCL ("nccl") on device tensors, on a group
+    that is created lazily by `open_data_group`, in a helper thread with a deadline, and agreed on over the control plane:
+    if RCCL does not come up on every rank (or hangs), every rank falls back to the gloo group together and says so.
 """
 from __future__ import annotations
 
+import threading
 import time
-from typing import Tuple
+from typing import Optional, Tuple
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
 PARTIAL_BYTES = 384
+
+_control = None
 
 
 def shard_range(n: int, rank: int, count: int) -> Tuple[int, int]:
@@ -27,52 +37,122 @@ def shard_range(n: int, rank: int, count: int) -> Tuple[int, int]:
     return n * rank // count, n * (rank + 1) // count
 
 
-def barrier_sync(world: int) -> None:
+def control_group():
+    """the gloo group the control plane runs on: the default group when that is gloo, else a gloo group made once"""
+    global _control
+    if not dist.is_initialized():
+        return None
+    if _control is None:
+        _control = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+    return _control
+
+
+def _on_host(group) -> bool:
+    return dist.get_backend(group) == "gloo"
+
+
+def barrier_sync(world: int, group=None) -> None:
+    """device idle, every rank here, device idle.  `group` defaults to the control plane."""
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=group if group is not None else control_group())
     if torch.cuda.is_available():
         torch.cuda.synchronize()
 
 
-def max_over_ranks(x: float, world: int, device) -> float:
+def max_over_ranks(x: float, world: int, device=None, group=None) -> float:
     if world <= 1:
         return x
-    if dist.get_backend() == "gloo":
-        device = torch.device("cpu")
-    t = torch.tensor([x], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    group = group if group is not None else control_group()
+    t = torch.tensor([x], dtype=torch.float64, device=torch.device("cpu") if _on_host(group) else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
 
 
-class PartialGather:
-    """The one exchange step of a sharded proof: an all_gather of 384 bytes per rank (four G1 partial sums + one G2).
-    The tensors are allocated once and reused for every proof; with RCCL ("nccl") they live on the device and the
-    collective runs over xGMI, with gloo they are host tensors."""
+def min_over_ranks(x: float, world: int, device=None, group=None) -> float:
+    return -max_over_ranks(-x, world, device, group)
 
-    def __init__(self, device, group=None):
+
+def gather_over_ranks(x: float, world: int, group=None) -> list:
+    """every rank's value, rank order (control plane)"""
+    if world <= 1:
+        return [x]
+    group = group if group is not None else control_group()
+    t = torch.tensor([x], dtype=torch.float64)
+    out = torch.empty(world, dtype=torch.float64)
+    dist.all_gather_into_tensor(out, t, group=group)
+    return [float(v) for v in out]
+
+
+def open_data_group(device, backend: str = "nccl", deadline_s: float = 90.0):
+    """-> (group, backend actually in use, error or None).  backend "nccl" = RCCL: the group is created and one
+    device all_gather is pushed through it in a helper thread; whether it worked is agreed over the control plane (min
+    over ranks), so that either every rank uses RCCL or every rank uses the gloo control group.  A helper thread that is
+    still inside RCCL at the deadline is left behind (daemon) and counts as a failure."""
+    world = dist.get_world_size()
+    ctl = control_group()
+    if backend == "gloo":
+        return ctl, "gloo", None
+    res = {}
+
+    def attempt():
+        try:
+            torch.cuda.set_device(device)        # a new thread starts on device 0, whatever the main thread chose
+            g = dist.new_group(backend=backend, device_id=device) if backend == "nccl" else dist.new_group(backend=backend)
+            mine = torch.full((8,), float(dist.get_rank()), device=device)
+            allv = torch.empty(8 * world, device=device)
+            dist.all_gather_into_tensor(allv, mine, group=g)
+            torch.cuda.current_stream(device).synchronize()
+            got = allv.cpu().view(world, 8)[:, 0].tolist()
+            if got != [float(k) for k in range(world)]:
+                raise RuntimeError("first all_gather returned %r" % (got,))
+            res["group"] = g
+        except BaseException as e:   # noqa: BLE001 - reported, never raised into the measurement
+            res["error"] = "%s: %s" % (type(e).__name__, str(e).strip().splitlines()[0][:300] if str(e).strip() else "")
+    th = threading.Thread(target=attempt, daemon=True)
+    th.start()
+    th.join(deadline_s)
+    if th.is_alive():
+        res["error"] = "no answer from the %s group after %.0f s" % (backend, deadline_s)
+    ok = 1.0 if "group" in res and "error" not in res else 0.0
+    all_ok = min_over_ranks(ok, world, group=ctl) > 0.5
+    if all_ok:
+        return res["group"], backend, None
+    err = res.get("error") or "another rank could not open its %s group" % backend
+    return ctl, "gloo", err
+
+
+class PartialGather:
+    """The one exchange step of a sharded proof: an all_gather of 384 bytes per rank (four G1 partial sums + one G2), or of
+    `batch` such records at once.  The tensors are allocated once and reused for every proof; with RCCL ("nccl") they
+    live on the device and the collective runs over xGMI, with gloo they are host tensors."""
+
+    def __init__(self, device, group=None, batch: int = 1):
         self.group = group
         self.world = dist.get_world_size(group)
-        self.on_host = dist.get_backend(group) == "gloo"
+        self.on_host = _on_host(group)
+        self.batch = batch
+        n = PARTIAL_BYTES * batch
         dev = torch.device("cpu") if self.on_host else device
-        self._mine = torch.empty(PARTIAL_BYTES, dtype=torch.uint8, device=dev)
-        self._all = torch.empty(self.world * PARTIAL_BYTES, dtype=torch.uint8, device=dev)
+        self._mine = torch.empty(n, dtype=torch.uint8, device=dev)
+        self._all = torch.empty(self.world * n, dtype=torch.uint8, device=dev)
         if self.on_host:
             self._stage_in = self._mine
             self._stage_out = self._all
-        else:   # page-locked staging on the host side of the two 384-byte copies
-            self._stage_in = torch.empty(PARTIAL_BYTES, dtype=torch.uint8).pin_memory()
-            self._stage_out = torch.empty(self.world * PARTIAL_BYTES, dtype=torch.uint8).pin_memory()
+        else:   # page-locked staging on the host side of the two small copies
+            self._stage_in = torch.empty(n, dtype=torch.uint8).pin_memory()
+            self._stage_out = torch.empty(self.world * n, dtype=torch.uint8).pin_memory()
 
     def __call__(self, partial: bytes) -> bytes:
+        """partial: batch x 384 bytes -> world x batch x 384 bytes, rank-major"""
         self._stage_in.numpy()[:] = np.frombuffer(partial, dtype=np.uint8)
         if not self.on_host:
             self._mine.copy_(self._stage_in, non_blocking=True)
         dist.all_gather_into_tensor(self._all, self._mine, group=self.group)
         if not self.on_host:
             self._stage_out.copy_(self._all, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
+            torch.cuda.current_stream(self._all.device).synchronize()
         return self._stage_out.numpy().tobytes()
 
 
@@ -86,7 +166,14 @@ class ShardedProver:
     """One proof across all ranks.  `prover` is any object with prove_partial(assignment, r, on_device) and
     assemble(partials, n_shards, r, s) — a crescent_credentials_amd.Prover loaded with shard_rank/shard_count
     on the GPU, or a stand-in in the CPU (gloo) tests.  `seconds` accumulates where the wall time of the proofs went
-    (this rank's partial sums, the all_gather, the host finish)."""
+    (this rank's partial sums, the all_gather, the host finish).
+
+    `prove*` is one proof at a time (latency).  `prove_stream` keeps several sharded proofs in flight per rank, as the
+    reference's host does with whole proofs (one task per credential, sample/client_helper/src/main.rs:177-216): worker
+    threads compute this rank's partial sums of proofs k, k+1, ... concurrently (a shard context with proof_slots > 1),
+    ONE gather thread exchanges the 384-byte records strictly in proof order (every rank issues the same sequence of
+    collectives whatever order its partial sums finish in), and the host finish of proof k runs while the partial sums
+    of the next proofs are on the GPU."""
 
     def __init__(self, prover, device, group=None):
         self.prover = prover
@@ -121,6 +208,87 @@ class ShardedProver:
 
     def prove_dev(self, d_ptr: int, r: int, s: int):
         return self._prove(d_ptr, True, r, s)
+
+    def prove_stream(self, jobs, in_flight: int, on_device: bool = True, done_times: Optional[list] = None):
+        """jobs: list of (assignment, r, s) - the SAME list, in the same order, on every rank.  -> proofs in job order.
+        `in_flight` sharded proofs are kept going on this rank.  done_times (optional list) receives perf_counter() of
+        every proof's completion, job order."""
+        n = len(jobs)
+        if n == 0:
+            return []
+        in_flight = max(1, min(in_flight, n))
+        parts = [None] * n           # this rank's 384-byte record of proof k
+        gathered = [None] * n        # all ranks' records of proof k
+        proofs = [None] * n
+        if done_times is not None:
+            done_times[:] = [0.0] * n
+        have_part = [threading.Event() for _ in range(n)]
+        have_all = [threading.Event() for _ in range(n)]
+        nxt = [0]
+        lock = threading.Lock()
+        err = []
+
+        def fail(e):
+            err.append(e)
+            for ev in have_part + have_all:      # nobody stays blocked behind a failure
+                ev.set()
+
+        def worker():
+            while not err:
+                with lock:
+                    k = nxt[0]
+                    nxt[0] += 1
+                if k >= n:
+                    return
+                try:
+                    a, r, s = jobs[k]
+                    t0 = time.perf_counter()
+                    parts[k] = self.prover.prove_partial(a, r, on_device=on_device)
+                    t1 = time.perf_counter()
+                    have_part[k].set()
+                    have_all[k].wait()
+                    if err:
+                        return
+                    t2 = time.perf_counter()
+                    proofs[k] = self.prover.assemble(gathered[k], self.world, r, s)
+                    t3 = time.perf_counter()
+                    if done_times is not None:
+                        done_times[k] = t3
+                    with lock:
+                        self.seconds["partial"] += t1 - t0
+                        self.seconds["assemble"] += t3 - t2
+                        self.proofs += 1
+                except BaseException as e:   # noqa: BLE001 - surfaces below
+                    fail(e)
+                    return
+
+        def gatherer():
+            try:
+                if self._gather is not None and not self._gather.on_host:
+                    torch.cuda.set_device(self.device)   # a new thread starts on device 0
+                for k in range(n):
+                    have_part[k].wait()
+                    if err:
+                        return
+                    t0 = time.perf_counter()
+                    if self.world > 1:
+                        gathered[k] = self._gather(parts[k])
+                        self.all_gathers += 1
+                    else:
+                        gathered[k] = parts[k]
+                    self.seconds["gather"] += time.perf_counter() - t0
+                    have_all[k].set()
+            except BaseException as e:       # noqa: BLE001
+                fail(e)
+
+        ts = [threading.Thread(target=worker) for _ in range(in_flight)] + [threading.Thread(target=gatherer)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if err:
+            raise err[0]
+        return proofs
 
     def breakdown_ms(self) -> dict:
         """mean milliseconds per proof spent in each step since construction (or the last reset_breakdown)"""

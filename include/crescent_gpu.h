@@ -89,7 +89,8 @@ typedef struct cg_options {
     int32_t device;        /* HIP device ordinal; -1 = current device */
     int32_t window_bits;   /* Pippenger window c; 0 = library default for the size */
     int32_t shard_rank;    /* multi-GPU MSM range sharding: this context's rank ... */
-    int32_t shard_count;   /* ... of shard_count; 0 or 1 = unsharded */
+    int32_t shard_count;   /* ... of shard_count; 0 or 1 = unsharded.  A shard with proof_slots > 1 keeps that many
+                              sharded proofs in flight (cg_prove_partial from as many threads) */
     int32_t proof_slots;   /* proofs that may be in flight on this context at once (each has its own working
                               set and streams; cg_prove* from different threads overlap on the GPU); 0 = 1 */
     int32_t flags;         /* CG_FLAG_* */
@@ -151,6 +152,8 @@ int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_csr abc[3],
                     uint64_t num_inputs, uint64_t num_constraints, uint64_t num_variables,
                     const cg_options* opt);
 
+/* Waits for every call that is still inside the context (cg_prove*, cg_prove_partial, cg_assemble, cg_witness_map: their GPU
+ * work AND their host tails) and then frees it.  No call may START on the context once this one has. */
 void cg_circuit_free(cg_ctx* ctx);
 
 /* Create one Groth16 proof.

@@ -597,6 +597,81 @@ int ref_witness_map(const csr_t abc[3], uint64_t l, uint64_t m, uint64_t M, cons
     return 0;
 }
 
+/* ---- the QAP at one point: what the KEY CHECK of the full-size tests needs (oracle/keycheck.py) -----------------
+ * LibsnarkReduction::instance_map_with_evaluation (r1cs_to_qap.rs:103-147) at t: u_j = L_j(t) over the size-D subgroup
+ * (ark-poly evaluate_all_lagrange_coefficients [ark-mem]: L_j(t) = (t^D - 1)/D * w^j / (t - w^j), t outside the domain),
+ * a_i(t) = sum_j u_j A[j][i] (+ u_{m+i} for the instance wires, :128-133), b_i(t), c_i(t), zt = t^D - 1.
+ * Column accumulation in row order, one thread (it is a checker: a few seconds at 16 M terms).
+ * a_out/b_out/c_out: M x 32 canonical; u_out (nullable): D x 32.  Returns -5 when t lies in the domain. */
+int ref_qap_at(const csr_t abc[3], uint64_t l, uint64_t m, uint64_t M, const uint8_t t_b[32], uint8_t* a_out, uint8_t* b_out,
+               uint8_t* c_out, uint8_t zt_out[32], uint8_t* u_out) {
+    int logd = ilog2_ceil(m + l);
+    if (logd > 28) return -5;
+    uint64_t D = 1ull << logd;
+    fe t, w, zt, zd, nn, ninv;
+    fe_from_canonical(&FR, &t, t_b);
+    fr_root_of_unity(&w, logd);
+    uint64_t e[4] = {D, 0, 0, 0};
+    fe_pow(&FR, &zt, &t, e); fe_sub(&FR, &zt, &zt, &FR.one);       /* evaluate_vanishing_polynomial */
+    if (fe_is_zero(&zt)) return -5;
+    fe_from_u64(&FR, &nn, D); fe_inv(&FR, &ninv, &nn); fe_mul(&FR, &zd, &zt, &ninv);
+    fe* u = (fe*)malloc(sizeof(fe) * D);      /* first t - w^j, then its inverse by one shared inversion, then L_j(t) */
+    fe* pre = (fe*)malloc(sizeof(fe) * D);
+    fe p = FR.one, run = FR.one;
+    for (uint64_t j = 0; j < D; ++j) { fe_sub(&FR, &u[j], &t, &p); pre[j] = run; fe_mul(&FR, &run, &run, &u[j]); fe_mul(&FR, &p, &p, &w); }
+    fe inv; fe_inv(&FR, &inv, &run);
+    for (uint64_t j = D; j-- > 0;) { fe d = u[j]; fe_mul(&FR, &u[j], &inv, &pre[j]); fe_mul(&FR, &inv, &inv, &d); }
+    p = zd;                                                         /* zd * w^j */
+    for (uint64_t j = 0; j < D; ++j) { fe_mul(&FR, &u[j], &u[j], &p); fe_mul(&FR, &p, &p, &w); }
+    free(pre);
+    fe* acc[3]; uint8_t* outs[3] = {a_out, b_out, c_out};
+    for (int k = 0; k < 3; ++k) acc[k] = (fe*)calloc(M, sizeof(fe));
+    for (uint64_t i = 0; i < l; ++i) acc[0][i] = u[m + i];          /* :128-133 */
+    for (int k = 0; k < 3; ++k)                                     /* :135-145 */
+        for (uint64_t j = 0; j < m; ++j)
+            for (uint64_t q = abc[k].row_ptr[j]; q < abc[k].row_ptr[j + 1]; ++q) {
+                fe c, v; fe_from_canonical(&FR, &c, abc[k].coeff + 32 * q);
+                fe_mul(&FR, &v, &u[j], &c);
+                fe* dst = &acc[k][abc[k].col[q]];
+                fe_add(&FR, dst, dst, &v);
+            }
+    for (int k = 0; k < 3; ++k) {
+        for (uint64_t i = 0; i < M; ++i) fe_to_canonical(&FR, outs[k] + 32 * i, &acc[k][i]);
+        free(acc[k]);
+    }
+    if (u_out) for (uint64_t j = 0; j < D; ++j) fe_to_canonical(&FR, u_out + 32 * j, &u[j]);
+    fe_to_canonical(&FR, zt_out, &zt);
+    free(u);
+    return 0;
+}
+/* sum_i a_i * b_i over Fr, canonical in and out */
+int ref_fr_inner(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t out[32]) {
+    fe acc = {{0, 0, 0, 0}};
+    for (uint64_t i = 0; i < n; ++i) {
+        fe x, y; fe_from_canonical(&FR, &x, a + 32 * i); fe_from_canonical(&FR, &y, b + 32 * i);
+        fe_mul(&FR, &x, &x, &y); fe_add(&FR, &acc, &acc, &x);
+    }
+    fe_to_canonical(&FR, out, &acc);
+    return 0;
+}
+/* out_i = (x * a_i + y * b_i + c_i) * z over Fr (the l_query / gamma_abc scalars of generator.rs:118-128), and
+ * out_i = s * t^i (h_query scalars, r1cs_to_qap.rs:215-225) */
+int ref_fr_combine(const uint8_t* a, const uint8_t* b, const uint8_t* c, uint64_t n, const uint8_t x_b[32], const uint8_t y_b[32],
+                   const uint8_t z_b[32], uint8_t* out) {
+    fe x, y, z; fe_from_canonical(&FR, &x, x_b); fe_from_canonical(&FR, &y, y_b); fe_from_canonical(&FR, &z, z_b);
+    for (uint64_t i = 0; i < n; ++i) {
+        fe p, q, r; fe_from_canonical(&FR, &p, a + 32 * i); fe_from_canonical(&FR, &q, b + 32 * i); fe_from_canonical(&FR, &r, c + 32 * i);
+        fe_mul(&FR, &p, &p, &x); fe_mul(&FR, &q, &q, &y); fe_add(&FR, &p, &p, &q); fe_add(&FR, &p, &p, &r); fe_mul(&FR, &p, &p, &z);
+        fe_to_canonical(&FR, out + 32 * i, &p);
+    }
+    return 0;
+}
+int ref_fr_powers(const uint8_t s_b[32], const uint8_t t_b[32], uint64_t n, uint8_t* out) {
+    fe p, t; fe_from_canonical(&FR, &p, s_b); fe_from_canonical(&FR, &t, t_b);
+    for (uint64_t i = 0; i < n; ++i) { fe_to_canonical(&FR, out + 32 * i, &p); fe_mul(&FR, &p, &p, &t); }
+    return 0;
+}
+
 /* prover.rs:256-274 */
 static void calculate_coeff1(jac1* res, const jac1* initial, const aff1* query, uint64_t qlen, const aff1* vk_param,
                              const uint64_t (*assignment)[4], uint64_t alen, int nt) {

@@ -43,6 +43,10 @@ def lib():
         L.ref_witness_map.argtypes = [C.POINTER(_Csr), C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
         L.ref_prove.argtypes = [C.POINTER(_Pk), C.POINTER(_Csr), C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_int, C.POINTER(RefTimings)]
+        L.ref_qap_at.argtypes = [C.POINTER(_Csr), C.c_uint64, C.c_uint64, C.c_uint64] + [C.c_void_p] * 6
+        L.ref_fr_inner.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.ref_fr_combine.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64] + [C.c_void_p] * 4
+        L.ref_fr_powers.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         _lib = L
     return _lib
 
@@ -135,6 +139,55 @@ def witness_map(mats, l, m, M, witness, nthreads=1) -> np.ndarray:
     rc = lib().ref_witness_map(arr, l, m, M, w.ctypes.data, h.ctypes.data, nthreads)
     assert rc == 0
     return h
+
+
+def _fr(x: int) -> np.ndarray:
+    return np.frombuffer(int(x).to_bytes(32, "little"), np.uint8).copy()
+
+
+def qap_at(mats, l, m, M, t: int, want_u=False):
+    """instance_map_with_evaluation (r1cs_to_qap.rs:103-147) at the point t: (a, b, c) as M x 32 canonical bytes each, zt as
+    an int (and u = L_j(t), D x 32, when asked for)."""
+    D = 1
+    while D < m + l:
+        D <<= 1
+    arr, _k = _csr3(mats)
+    a, b, c = (np.zeros(M * 32, np.uint8) for _ in range(3))
+    zt = np.zeros(32, np.uint8)
+    u = np.zeros(D * 32, np.uint8) if want_u else None
+    tb = _fr(t)
+    rc = lib().ref_qap_at(arr, l, m, M, tb.ctypes.data, a.ctypes.data, b.ctypes.data, c.ctypes.data, zt.ctypes.data,
+                          u.ctypes.data if want_u else None)
+    assert rc == 0, rc
+    out = (a, b, c, int.from_bytes(zt.tobytes(), "little"))
+    return out + (u,) if want_u else out
+
+
+def fr_inner(a, b) -> int:
+    a, b = _u8(a), _u8(b)
+    n = min(a.size, b.size) // 32
+    out = np.zeros(32, np.uint8)
+    lib().ref_fr_inner(a.ctypes.data, b.ctypes.data, n, out.ctypes.data)
+    return int.from_bytes(out.tobytes(), "little")
+
+
+def fr_combine(a, b, c, x: int, y: int, z: int) -> np.ndarray:
+    """(x*a_i + y*b_i + c_i) * z"""
+    a, b, c = _u8(a), _u8(b), _u8(c)
+    n = a.size // 32
+    out = np.zeros(n * 32, np.uint8)
+    xb, yb, zb = _fr(x), _fr(y), _fr(z)
+    lib().ref_fr_combine(a.ctypes.data, b.ctypes.data, c.ctypes.data, n, xb.ctypes.data, yb.ctypes.data, zb.ctypes.data,
+                         out.ctypes.data)
+    return out
+
+
+def fr_powers(s: int, t: int, n: int) -> np.ndarray:
+    """s * t^i, i < n"""
+    out = np.zeros(n * 32, np.uint8)
+    sb, tb = _fr(s), _fr(t)
+    lib().ref_fr_powers(sb.ctypes.data, tb.ctypes.data, n, out.ctypes.data)
+    return out
 
 
 def prove(pk, mats, l, m, M, witness, r: int, s: int, nthreads=1, timings=False):

@@ -44,9 +44,11 @@ def test_block_count_and_block_times():
     class A:
         blocks = 0
         steps = 20
-    assert bench.n_blocks(A) == 33                      # 33 x 20 >= 640, odd
+    assert bench.n_blocks(A) == 75                      # 75 x 20 = 1500: the steady window does not depend on --steps
     A.steps = 400
-    assert bench.n_blocks(A) == 5
+    assert bench.n_blocks(A) == 4
+    A.steps = 5000
+    assert bench.n_blocks(A) == 3
     A.blocks = 4
     assert bench.n_blocks(A) == 4
     # completions one per millisecond from t = 1 ms: every block of 10 lasts 10 ms whatever the warm-up
@@ -55,6 +57,33 @@ def test_block_count_and_block_times():
     assert all(abs(x - 0.010) < 1e-12 for x in bt) and len(bt) == 5
     # without warm-up the first block starts at t_start
     assert abs(bench.block_times(done, 0, 10, 1, 0.0)[0] - 0.010) < 1e-12
+
+
+def test_gpus_are_counted_without_touching_hip(monkeypatch):
+    """GPU_MAX_HW_QUEUES has to be in the environment before the HIP runtime starts, so the ranks-per-GPU arithmetic may
+    not go through a torch device call"""
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+    assert bench.visible_gpus_without_hip() == 3
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "3")
+    assert bench.visible_gpus_without_hip() == 1
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
+    assert bench.visible_gpus_without_hip() >= 0            # the KFD topology, 0 when there is none (this container)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main_src = src[src.index("def main():"):]
+    assert main_src.index('setdefault("GPU_MAX_HW_QUEUES"') < main_src.index("import torch\n    import numpy")
+
+
+def test_no_rccl_collective_outside_the_sharded_leg():
+    """the control plane is gloo: the only place bench.py may reach RCCL is open_data_group inside the sharded leg"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'init_process_group("gloo")' in src and 'init_process_group("nccl"' not in src
+    assert src.count("open_data_group(") == 1
+    leg = src[src.index("# ---- N > 1: proofs sharded over the ranks"):src.index("# ---- N = 1 diagnostic")]
+    assert "open_data_group(" in leg
+    watchdog_at = src.index("watchdog = threading.Timer")
+    assert watchdog_at < src.index("open_data_group(dev")    # and it is under the watchdog
 
 
 def test_steady_stream_keeps_n_in_flight_and_surfaces_errors():

@@ -95,6 +95,19 @@ def _worker(rank, world, port, q):
             proof = sp.prove(w, int(case["r"], 16), int(case["s"], 16))
             ok = ok and proof.hex() == case["proof"]
         ok = ok and sp.all_gathers == len(g["proofs"])          # exactly one collective per proof
+        # several sharded proofs in flight per rank (K = 4): worker threads finish their partial sums in any order, the
+        # records are exchanged strictly in proof order, every proof is the golden one
+        cases = g["proofs"] * 3
+        jobs = [(w, int(c["r"], 16), int(c["s"], 16)) for c in cases]
+        times = []
+        got = sp.prove_stream(jobs, in_flight=4, on_device=False, done_times=times)
+        ok = ok and [p.hex() for p in got] == [c["proof"] for c in cases]
+        ok = ok and sp.all_gathers == len(g["proofs"]) + len(jobs) and len(times) == len(jobs) and all(t > 0 for t in times)
+        ok = ok and sp.prove_stream([], in_flight=4) == []
+        from crescent_credentials_amd.distributed import control_group, gather_over_ranks, min_over_ranks
+        ok = ok and control_group() is dist.group.WORLD          # gloo default group IS the control plane
+        ok = ok and gather_over_ranks(float(10 + rank), world) == [10.0, 11.0]
+        ok = ok and min_over_ranks(float(rank + 1), world) == 1.0
         barrier_sync(world)
         mx = max_over_ranks(float(rank + 1), world, torch.device("cpu"))
         q.put((rank, ok, mx))

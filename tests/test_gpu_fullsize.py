@@ -39,7 +39,7 @@ def _workload(cc, oracle, shape, bit_fraction, seed_off):
     rng = random.Random(SEED + seed_off)
     trap = [rng.randrange(1, oracle.R) for _ in range(4)]
     pk = cc.generate_parameters_with_qap(cm, *trap)
-    return (l, m, M), cm, w, pk, rng
+    return (l, m, M), cm, w, pk, rng, tuple(trap)            # trap = (alpha, beta, delta, tau)
 
 
 @pytest.mark.parametrize("shape,bit_fraction", [("rs256", 0.9), ("rs256-sd", 0.9), ("rs256-sd", 0.0), ("rs256-db", 0.9),
@@ -48,10 +48,21 @@ def _workload(cc, oracle, shape, bit_fraction, seed_off):
 def test_full_size_prove_equals_cpu_restatement(cc, oracle, shape, bit_fraction):
     """forks/groth16/src/prover.rs:26-136 at the sizes BASELINE.json names"""
     import cpu_ref
-    (l, m, M), cm, w, pk, rng = _workload(cc, oracle, shape, bit_fraction, 1 + len(shape))
+    import keycheck
+    (l, m, M), cm, w, pk, rng, trap = _workload(cc, oracle, shape, bit_fraction, 1 + len(shape))
     nt = _threads()
     cases = [(0, 0), (rng.randrange(oracle.R), rng.randrange(oracle.R))]
     expect = [cpu_ref.prove(pk, (cm.a, cm.b, cm.c), l, m, M, w, r, s, nthreads=nt) for r, s in cases]
+    # The key every proof below is made on comes out of cg_setup (the product): is it a Groth16 key for THIS circuit?
+    # Fixed points, gamma_abc, a strided sample and a random linear combination over ALL entries of the five queries
+    # against the trapdoor's scalars (generator.rs:118-194), none of it through csrc/setup.hip - oracle/keycheck.py.
+    scal = keycheck.check_key(oracle, cpu_ref, pk, cm, l, m, M, trap, nthreads=nt)
+    for (r, s), exp in zip(cases, expect):
+        # the proofs are the trapdoor's closed form (no transform, no MSM) ...
+        assert keycheck.closed_form(oracle, cpu_ref, scal, trap, r, s, w, l) == keycheck.decode_proof(oracle, exp), (shape, r != 0)
+        # ... and the reference's acceptance criterion holds at this size (forks/groth16/src/test.rs:70-71,
+        # creds/src/lib.rs:286-290, verifier.rs:44-65); a flipped public input is refused
+        assert keycheck.verify(oracle, pk, l, w, exp), (shape, r != 0)
     for coefficient_basis in (False, True):
         prover = cc.Prover(pk, cm, proof_slots=2, h_coefficient_basis=coefficient_basis)
         try:
@@ -73,7 +84,8 @@ def test_full_size_sharded_contexts_assemble_to_the_same_proof(cc, oracle, shape
     4's own size - S22 (mdl1, D = 2^22) over 8 strided shards (Wm29Strided / k_fold29), and S21 over 3 shards (not a power
     of two: contiguous ranges of the h query's points); a satisfying and an arbitrary assignment each."""
     import cpu_ref
-    (l, m, M), cm, w, pk, rng = _workload(cc, oracle, shape, 0.9, 77 + n)
+    import keycheck
+    (l, m, M), cm, w, pk, rng, trap = _workload(cc, oracle, shape, 0.9, 77 + n)
     r, s = rng.randrange(oracle.R), rng.randrange(oracle.R)
     nt = _threads()
     # an assignment that satisfies nothing: the aux wires of the witness in another order (the prover's identities hold
@@ -88,7 +100,9 @@ def test_full_size_sharded_contexts_assemble_to_the_same_proof(cc, oracle, shape
         for k in range(n):
             shards.append(cc.Prover(pk, cm, shard_rank=k, shard_count=n))
         parts = b"".join(p.prove_partial(w, r) for p in shards)
-        assert shards[n // 2].assemble(parts, n, r, s).data == exp
+        got = shards[n // 2].assemble(parts, n, r, s).data
+        assert got == exp
+        assert keycheck.verify(oracle, pk, l, w, got)                      # verifier.rs:44-65 on the assembled proof
         parts = b"".join(p.prove_partial(w2, r) for p in shards)           # second proof of every shard: re-tuned windows
         assert shards[0].assemble(parts, n, r, s).data == exp2
         parts = b"".join(p.prove_partial(w, 0) for p in shards)            # r = 0: b1 skipped (prover.rs:102-112)

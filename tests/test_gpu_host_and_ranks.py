@@ -11,6 +11,7 @@ import os
 import random
 import socket
 import subprocess
+import time
 import sys
 
 import numpy as np
@@ -126,6 +127,55 @@ def test_ctx_info_reports_memory_windows_and_the_retune(cc, oracle, medium):
         assert (i["shard_rank"], i["shard_count"], i["latency_mode"]) == (1, 4, 1)
     finally:
         sh.close()
+    # a shard that keeps several sharded proofs in flight is a throughput context
+    sh = cc.Prover(pk, cm, shard_rank=1, shard_count=4, proof_slots=3)
+    try:
+        i = sh.info()
+        assert (i["shard_rank"], i["shard_count"], i["latency_mode"], i["proof_slots"]) == (1, 4, 0, 3)
+    finally:
+        sh.close()
+
+
+def test_a_retune_that_fails_half_way_refuses_every_later_proof_even_callers_already_waiting(cc, oracle, medium):
+    """`broken` was tested only before the shared lock, so a caller blocked behind another thread's re-tune could
+    go on to prove on engines cut for the old window against the rebuilt table.  CG_FAULT_RETUNE=1 makes the re-size of the
+    proof slots fail as an allocation would (table rebuilt, engines not), with several callers in flight: every call
+    returns either the right bytes (it finished before the re-tune) or CG_ERR_OUT_OF_MEMORY with the reload message -
+    never other bytes, never a fault - and once one call has been refused every later one is."""
+    import cpu_ref
+    from concurrent.futures import ThreadPoolExecutor
+    (l, m, M), cm, w, pk = medium
+    want = cpu_ref.prove(pk, (cm.a, cm.b, cm.c), l, m, M, w, 5, 6, nthreads=8)
+    prover = cc.Prover(pk, cm, proof_slots=4)
+    os.environ["CG_FAULT_RETUNE"] = "1"
+    try:
+        def one(_):
+            try:
+                return prover.prove(w, 5, 6).data
+            except cc.CrescentGpuError as e:
+                return e
+        with ThreadPoolExecutor(max_workers=6) as ex:
+            got = list(ex.map(one, range(24)))
+        good = [g for g in got if isinstance(g, bytes)]
+        bad = [g for g in got if not isinstance(g, bytes)]
+        assert good and all(g == want for g in good)                 # the proof that triggered the re-tune is itself fine
+        assert bad and all(e.code == -4 and "load the circuit again" in str(e) for e in bad)
+        first_bad = next(i for i, g in enumerate(got) if not isinstance(g, bytes))
+        assert len(good) <= first_bad + 6                            # nothing is proved once the context is refused
+        for _ in range(3):
+            with pytest.raises(cc.CrescentGpuError):
+                prover.prove(w, 5, 6)
+        with pytest.raises(cc.CrescentGpuError):
+            prover.witness_map(w)
+    finally:
+        del os.environ["CG_FAULT_RETUNE"]
+        prover.close()
+    # the same circuit loads and proves again
+    p2 = cc.Prover(pk, cm, proof_slots=2)
+    try:
+        assert p2.prove(w, 5, 6).data == want and p2.prove(w, 5, 6).data == want and p2.info()["tuned"] == 1
+    finally:
+        p2.close()
 
 
 def test_contexts_come_and_go_while_others_prove(cc, oracle, medium):
@@ -226,6 +276,15 @@ for i, (r, s) in enumerate(cases):
     proofs.append((sp.prove(w, r, s) if i == 1 else sp.prove_dev(wd.data_ptr(), r, s)).data.hex())
 res = {"rank": rank, "proofs": proofs, "all_gathers": sp.all_gathers, "n": len(cases), "breakdown_ms": sp.breakdown_ms(),
        "info": ctx.info()["shard_count"]}
+# K = 4 sharded proofs in flight per rank: a shard context with four proof slots (a throughput context: one stream per
+# proof), records exchanged in proof order by ShardedProver.prove_stream
+ctx4 = cc.Prover(pk, cm, device=gpu, shard_rank=rank, shard_count=world, proof_slots=4)
+sp4 = ShardedProver(ctx4, torch.device("cuda", gpu))
+jobs = [(wd.data_ptr(), r, s) for r, s in cases * 3]
+res["stream"] = [p.data.hex() for p in sp4.prove_stream(jobs, 4)]
+res["stream_gathers"] = sp4.all_gathers
+res["stream_latency_mode"] = ctx4.info()["latency_mode"]
+ctx4.close()
 if rank == 0:
     import cpu_ref
     res["want"] = [cpu_ref.prove(pk, (cm.a, cm.b, cm.c), l, m, M, w, r, s, nthreads=16).hex() for r, s in cases]
@@ -257,6 +316,7 @@ def test_two_gloo_ranks_with_real_hip_shards_under_sharded_prover(shape, tmp_pat
         assert r["proofs"] == want, "rank %d assembled other bytes than the CPU restatement" % r["rank"]
         assert r["all_gathers"] == r["n"] == 3              # exactly one collective per proof
         assert r["info"] == 2
+        assert r["stream"] == want * 3 and r["stream_gathers"] == 9 and r["stream_latency_mode"] == 0
     assert len(set(want)) == 3
 
 
@@ -302,6 +362,7 @@ def test_two_rccl_ranks_with_real_hip_shards_under_sharded_prover(tmp_path):
     res = [json.load(open(out + ".%d" % k)) for k in range(2)]
     for r in res:
         assert r["proofs"] == res[0]["want"] and r["all_gathers"] == r["n"] == 3
+        assert r["stream"] == res[0]["want"] * 3 and r["stream_gathers"] == 9
 
 
 @pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs")
@@ -337,6 +398,13 @@ def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
     sh = d["sharded"]
     assert sh["ranks"] == 2 and sh["backend"] == "gloo" and sh["bytes_identical_to_unsharded"] is True
     assert sh["all_gathers"] == sh["proofs"] == 6 and set(sh["ms_breakdown_rank0"]) == {"partial", "gather", "assemble"}
+    assert "error" not in sh and "backend_fallback" not in sh
+    fl = sh["in_flight"]
+    assert fl["proofs_in_flight"] == 4 and fl["all_gathers"] == fl["proofs"] and fl["bytes_identical_to_unsharded"] is True
+    assert fl["proofs_per_s"] > 0
+    assert len(d["value_per_rank"]) == 2 and abs(sum(d["value_per_rank"]) - d["value"]) < 0.35 * d["value"]
+    assert d["proof_verifies"] is True and d["key_check"]["ok"] is True and d["key_check"]["proof_equals_trapdoor_closed_form"] is True
+    assert d["timing"]["window_proofs"] == 36 and abs(d["ms_per_step"] * d["value"] / 2 - 1000.0) < 1.0
     # a rank that stops alone inside a secondary leg leaves the others in a barrier: the watchdog prints the headline that
     # was measured, marked incomplete, and every rank leaves with exit code 0
     run = subprocess.run(cmd + ["--stall-rank", "1", "--leg-timeout", "20"], env=env, capture_output=True, text=True, timeout=1500)
@@ -350,3 +418,31 @@ def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
         run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=env,
                              capture_output=True, text=True, timeout=300)
         assert run.returncode == 2 and "one GPU per rank" in run.stderr
+
+
+@pytest.mark.skipif(_gpus() != 1, reason="the RCCL failure is provoked by two ranks sharing the one GPU")
+def test_bench_survives_an_rccl_group_that_does_not_come_up():
+    """the first multi-GPU run of the RCCL leg will be the driver's own: it must not be able to lose the headline.  Two ranks
+    forced onto the one GPU with --backend nccl: the control plane is gloo, so the headline is measured; RCCL refuses two
+    ranks on one device (or, at worst, says nothing until --rccl-deadline), which the sharded leg records as `error` and
+    answers by running over gloo, labelled `backend_fallback` - rc 0, one line, no hang."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "nccl", "--allow-shared-gpu", "--steps", "12",
+           "--warmup", "2", "--inflight", "4", "--blocks", "3", "--shape", "medium", "--no-host-witness", "--sharded-steps", "6",
+           "--sharded-stream", "24", "--rccl-deadline", "60", "--leg-timeout", "400"]
+    t0 = time.time()
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [x for x in run.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1, run.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and len(d["value_per_rank"]) == 2 and "incomplete" not in d
+    sh = d["sharded"]
+    assert sh["backend_requested"] == "nccl"
+    if sh["backend"] == "nccl":        # an RCCL that accepts two ranks on one device: then the leg simply ran over it
+        assert "error" not in sh
+    else:
+        assert sh["backend"] == "gloo" and sh["backend_fallback"] == "gloo" and "nccl" in sh["error"]
+    assert sh["bytes_identical_to_unsharded"] is True and sh["all_gathers"] == sh["proofs"] == 6
+    assert sh["in_flight"]["bytes_identical_to_unsharded"] is True
+    assert time.time() - t0 < 900

@@ -809,7 +809,15 @@ def test_prove_medium_properties(cc, oracle, bit_fraction):
         d1 = oracle.g1_unpack(bytes(pk.delta_g1))
         exp = oracle.G1.to_affine(oracle.G1.add(oracle.G1.to_jac(g1(a0.a)), oracle.G1.mul_affine(d1, r)))
         assert g1(a.a) == exp
-        # A(0) itself against the trapdoor closed form: [alpha + Σ w_i a_i(tau)]·G, with a_i(tau) recomputed sparsely
+        # A, B, C themselves against the trapdoor closed form ([alpha + Σ w_i a_i(tau) + r·delta]·G, ...), with a_i(tau),
+        # b_i(tau), c_i(tau) recomputed sparsely on the host (oracle/keycheck.py over oracle/cpu_ref.c: r1cs_to_qap.rs:103-147)
+        import cpu_ref
+        import keycheck
+        trap = (alpha, beta, delta, tau)
+        scal = keycheck.check_key(oracle, cpu_ref, pk, cm, l, m, M, trap, stride=1021)
+        assert keycheck.closed_form(oracle, cpu_ref, scal, trap, r, s, w, l) == keycheck.decode_proof(oracle, a.data)
+        assert keycheck.closed_form(oracle, cpu_ref, scal, trap, 0, 0, w, l) == keycheck.decode_proof(oracle, a0.data)
+        assert keycheck.verify(oracle, pk, l, w, a.data)
     finally:
         p1.close(); p2.close()
 
