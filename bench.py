@@ -483,7 +483,11 @@ def main():
                    "proofs_per_rank": n_timed, "proofs_in_flight_per_gpu": inflight,
                    "inputs": "%d assignments resident in HBM, taken in rotation; (r,s) fresh per proof" % len(ws_dev),
                    "context": {"resident_GB": round(info["total_bytes"] / 1e9, 2), "tables_GB": round(info["table_bytes"] / 1e9, 2),
-                               "per_slot_GB": round(info["slot_bytes"] / 1e9, 3), "matrices_GB": round(info["matrix_bytes"] / 1e9, 3),
+                               "per_slot_GB": round(info["slot_bytes"] / 1e9, 3),
+                               "per_slot_GB_by_kind": {k[5:-6]: round(info[k] / 1e9, 3) for k in
+                                                       ("slot_entry_bytes", "slot_piece_bytes", "slot_bucket_bytes", "slot_transform_bytes",
+                                                        "slot_upload_bytes")},
+                               "matrices_GB": round(info["matrix_bytes"] / 1e9, 3),
                                "window_bits": info["window_bits"], "tuned": bool(info["tuned"]),
                                "retune_skipped_for_memory": info["retune_skipped_for_memory"]}},
         "roofline": roof, "roofline_valu": roof_valu, "phase_ms": phases,
@@ -783,7 +787,7 @@ def main():
     if rank == 0 and world == 1 and not a.no_sweep:
         prover.close()
         sweep = []
-        ksteps = max(inflight, min(a.steps, 100))
+        ksteps = 100                                       # 3 blocks: a 300-proof steady window per workload
         for bf in SWEEP_FRACTIONS:
             if abs(bf - a.bits) < 1e-9:
                 sweep.append({"bit_fraction": bf, "wires": wires, "nnz": nnz, "proofs_per_s": round(value, 3),

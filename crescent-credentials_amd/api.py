@@ -73,7 +73,8 @@ class CgCtxInfo(C.Structure):
                 ("device_free_bytes", C.c_uint64), ("device_total_bytes", C.c_uint64), ("proof_slots", C.c_int32),
                 ("window_bits", C.c_int32 * 5), ("tuned", C.c_int32), ("retune_skipped_for_memory", C.c_int32),
                 ("retune_attempts", C.c_int32), ("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("latency_mode", C.c_int32),
-                ("reserved", C.c_int32 * 4)]
+                ("reserved", C.c_int32 * 4), ("slot_entry_bytes", C.c_uint64), ("slot_piece_bytes", C.c_uint64),
+                ("slot_bucket_bytes", C.c_uint64), ("slot_transform_bytes", C.c_uint64), ("slot_upload_bytes", C.c_uint64)]
 
 
 class _CgProverParamsView(C.Structure):
@@ -570,25 +571,42 @@ def _content_digest(*arrays) -> bytes:
     return h.digest()
 
 
+def _freeze(*arrays) -> tuple:
+    """The digest of an object is remembered on it, so its arrays must not change afterwards: they are made read-only
+    (an in-place write then raises instead of silently proving against the old resident copy), and the memo also carries
+    where each array lives - an attribute REPLACED by another array (the supported way to change a key or a matrix) is
+    seen and hashed again."""
+    for a in arrays:
+        if isinstance(a, np.ndarray):
+            a.setflags(write=False)
+    return _where(arrays)
+
+
+def _where(arrays) -> tuple:
+    return tuple((id(a), a.__array_interface__["data"][0], a.size) if isinstance(a, np.ndarray) else (id(a), 0, len(a)) for a in arrays)
+
+
 def _matrices_key(m: "ConstraintMatrices") -> tuple:
     """what the three matrices ARE, not where they live: shape + a digest of every index and coefficient (computed once
-    per object and remembered on it)"""
-    k = getattr(m, "_content_key", None)
-    if k is None:
-        k = (m.num_instance_variables, m.num_witness_variables, m.num_constraints, m.a.nnz, m.b.nnz, m.c.nnz,
-             _content_digest(m.a.row_ptr, m.a.col, m.a.coeff, m.b.row_ptr, m.b.col, m.b.coeff, m.c.row_ptr, m.c.col, m.c.coeff))
-        m._content_key = k
+    per object and remembered on it; the arrays are immutable from then on, see _freeze)"""
+    arrays = (m.a.row_ptr, m.a.col, m.a.coeff, m.b.row_ptr, m.b.col, m.b.coeff, m.c.row_ptr, m.c.col, m.c.coeff)
+    memo = getattr(m, "_content_key", None)
+    if memo is not None and memo[0] == _where(arrays):
+        return memo[1]
+    k = (m.num_instance_variables, m.num_witness_variables, m.num_constraints, m.a.nnz, m.b.nnz, m.c.nnz, _content_digest(*arrays))
+    m._content_key = (_freeze(*arrays), k)
     return k
 
 
 def _pk_key(pk: "ProvingKey") -> tuple:
     """a proving key by content: the verifying key's points, the query lengths and a digest of the queries"""
-    k = getattr(pk, "_content_key", None)
-    if k is None:
-        k = (pk.coord_form, pk.a_query.size, pk.h_query.size, pk.l_query.size,
-             _content_digest(pk.vk.alpha_g1, pk.vk.beta_g2, pk.vk.gamma_g2, pk.vk.delta_g1, pk.vk.delta_g2, pk.vk.gamma_abc_g1,
-                             pk.beta_g1, pk.delta_g1, pk.a_query, pk.b_g1_query, pk.b_g2_query, pk.h_query, pk.l_query))
-        pk._content_key = k
+    arrays = (pk.vk.alpha_g1, pk.vk.beta_g2, pk.vk.gamma_g2, pk.vk.delta_g1, pk.vk.delta_g2, pk.vk.gamma_abc_g1,
+              pk.beta_g1, pk.delta_g1, pk.a_query, pk.b_g1_query, pk.b_g2_query, pk.h_query, pk.l_query)
+    memo = getattr(pk, "_content_key", None)
+    if memo is not None and memo[0] == _where(arrays) and memo[2] == pk.coord_form:
+        return memo[1]
+    k = (pk.coord_form, pk.a_query.size, pk.h_query.size, pk.l_query.size, _content_digest(*arrays))
+    pk._content_key = (_freeze(*arrays), k, pk.coord_form)
     return k
 
 

@@ -920,7 +920,11 @@ static bool g2_pair_kernel(bool latency_mode) {
     return latency_mode;
 }
 }  // namespace cg
+// the batch-affine pair rounds (an experiment that measured 16-21 % slower, profiles/r03_s_batch_affine.txt) are only in
+// builds made with -DCG_WITH_BATCH_AFFINE (tools/ab_build.sh); the shipped library does not carry them
+#ifdef CG_WITH_BATCH_AFFINE
 #include "batchaff.hpp"
+#endif
 namespace cg {
 // T_max: the largest segment count the plan can hold for this engine (lanes beyond the plan's T return at once)
 template <class F29T>
@@ -1281,8 +1285,6 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
     nbuckets_total = b->precomputed ? nb : nb * (uint32_t)W;
     part_bits(b->c, W, b->precomputed, bits1, bits2);
     if (bits1 > PART_MAX_BITS || bits2 > PART_MAX_BITS) throw HipError(CG_ERR_INVALID_ARGUMENT, "bucket key space too large");
-    ent_a.alloc(cap_entries);
-    ent_b.alloc(bits2 ? cap_entries : 1);
     const uint32_t B1 = 1u << bits1;
     const uint64_t tiles = n ? ceil_div(n, PART_TILE) : 1;
     blk_hist.alloc(tiles * B1);
@@ -1301,8 +1303,7 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
     if (t1 > acc_target_segments<F29T>(latency_mode)) t1 = acc_target_segments<F29T>(latency_mode);
     max_segments = (uint32_t)t1;
     const uint64_t pa = 2 * t1, pb = 2 * ceil_div(t1, 64);   // two pieces per segment, then two per wave of 64 segments
-    part_keys_a.alloc(pa); part_pts_a.alloc(pa * ACC);
-    part_keys_b.alloc(pb); part_pts_b.alloc(pb * ACC);
+    mem().reserve(cap_entries, bits2 ? cap_entries : 1, pa, pa * ACC, pb, pb * ACC);
     const uint32_t wins = b->precomputed ? 1u : (uint32_t)W;
     {
         const int cbits = red_cbits(b->c);
@@ -1316,6 +1317,7 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
             colp_buf.alloc((size_t)ceil_div(R, RED_CHUNK) * C * wins * ACC);
         }
     }
+#ifdef CG_WITH_BATCH_AFFINE
     ba_rounds = 0;
     if constexpr (Words29<F29T>::NF == 1) {
         if (const char* e = getenv("CG_BA_ROUNDS"); e && ba_allowed) ba_rounds = atoi(e) < 0 ? 0 : (atoi(e) > 6 ? 6 : atoi(e));
@@ -1344,11 +1346,24 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
         ba_rec_b.alloc((out2 + 1) * BA_REC);
         ba_plan.alloc((size_t)(ba_rounds + 1) * BAP_WORDS + PLAN_WORDS);
     }
+#endif
     h_plan.alloc(PLAN_WORDS);
     for (int k = 0; k < PLAN_WORDS; ++k) h_plan.p[k] = 0;
     h_result.alloc((size_t)wins * (red_rbits + red_cbits1) * ACC);   // per window: the per-bit sums of rows, then of columns
     if (!ev_t[0])
         for (auto& e : ev_t) CG_HIP(hipEventCreate(&e));
+}
+
+template <class F>
+void MsmEngine<F>::device_bytes(uint64_t& entries, uint64_t& pieces, uint64_t& other) const {
+    entries += own_mem.entry_bytes();
+    pieces += own_mem.piece_bytes();
+    other += blk_hist.bytes() + counters.bytes() + starts.bytes() + bucket_sums.bytes() + rows_buf.bytes() + cols_buf.bytes() +
+             rowp_buf.bytes() + colp_buf.bytes();
+#ifdef CG_WITH_BATCH_AFFINE
+    other += ba_prefix.bytes() + ba_totals.bytes() + ba_inv.bytes() + ba_chain.bytes() + ba_wpre.bytes() + ba_rec_a.bytes() +
+             ba_rec_b.bytes() + ba_plan.bytes() + ba_split.bytes() + ba_exc.bytes();
+#endif
 }
 
 static float elapsed_ms(hipEvent_t a, hipEvent_t b) {
@@ -1397,13 +1412,13 @@ void MsmEngine<F>::digits(const Fr* scalars_dev, uint64_t n, hipStream_t st) {
     CG_KERNEL_CHECK();
     k_part_plan<<<1, 1024, (size_t)B1 * 4, st>>>(bits1, bits2 ? 1 : 0, hist1, start1, chunk0, plan, acc_target_segments<F29T>(latency_mode), min_L);
     CG_KERNEL_CHECK();
-    launch_part_level1(false, sh, tiles, (size_t)B1 * 4, st, scalars_dev, bases->valid.p, blk_hist.p, nullptr, nullptr, start1, cur1, ent_a.p);
+    launch_part_level1(false, sh, tiles, (size_t)B1 * 4, st, scalars_dev, bases->valid.p, blk_hist.p, nullptr, nullptr, start1, cur1, mem().ent_a.p);
     CG_KERNEL_CHECK();
     if (bits2) {
         const uint32_t B2 = 1u << bits2;
-        k_part_count2<<<max_chunks, 256, (size_t)B2 * 4, st>>>(bits1, bits2, ent_a.p, chunk0, start1, hist2);
+        k_part_count2<<<max_chunks, 256, (size_t)B2 * 4, st>>>(bits1, bits2, mem().ent_a.p, chunk0, start1, hist2);
         CG_KERNEL_CHECK();
-        k_part_place2<<<max_chunks, 256, (size_t)B2 * 16 + (size_t)PART_CHUNK * 8, st>>>(bits1, bits2, ent_a.p, chunk0, start1, hist2, cur2, ent_b.p);
+        k_part_place2<<<max_chunks, 256, (size_t)B2 * 16 + (size_t)PART_CHUNK * 8, st>>>(bits1, bits2, mem().ent_a.p, chunk0, start1, hist2, cur2, mem().ent_b.p);
         CG_KERNEL_CHECK();
     }
     CG_HIP(hipEventRecord(ev_t[2], st));
@@ -1432,8 +1447,9 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
     fill_zero(bucket_sums.p, bucket_sums.bytes(), st);
     if (n_scalars) {
         const uint32_t* plan = counters.p;
-        const uint64_t* grouped = adopted ? adopted : (bits2 ? ent_b.p : ent_a.p);
+        const uint64_t* grouped = adopted ? adopted : this->grouped();
         CG_HIP(hipEventRecord(ev_t[3], st));
+#ifdef CG_WITH_BATCH_AFFINE
         bool ba_done = false;
         if constexpr (Words29<F29T>::NF == 1) {
             if (ba_rounds) {
@@ -1460,13 +1476,15 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
                     CG_KERNEL_CHECK();
                     recs_in = out;
                 }
-                k_accum_records<<<ceil_div(max_segments, 256u), 256, 0, st>>>(recs_in, plan2, bucket_sums.p, part_keys_a.p, part_pts_a.p);
+                k_accum_records<<<ceil_div(max_segments, 256u), 256, 0, st>>>(recs_in, plan2, bucket_sums.p, mem().part_keys_a.p, mem().part_pts_a.p);
                 CG_KERNEL_CHECK();
                 plan = plan2;
                 ba_done = true;
             }
         }
-        if (!ba_done) launch_accum_affine<F29T>(grouped, plan, max_segments, bases->table.p, bucket_sums.p, part_keys_a.p, part_pts_a.p, latency_mode, st);
+        if (!ba_done)
+#endif
+        launch_accum_affine<F29T>(grouped, plan, max_segments, bases->table.p, bucket_sums.p, mem().part_keys_a.p, mem().part_pts_a.p, latency_mode, st);
         CG_KERNEL_CHECK();
         CG_HIP(hipEventRecord(ev_t[4], st));
         // combine the segments' pieces wave by wave until one wave covers them all (k_combine_wave); the grids cover the
@@ -1475,10 +1493,11 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
         uint32_t segs = max_segments;
         for (int level = 0; segs > 1; ++level) {
             const uint32_t waves = ceil_div(segs, 64u);
-            const uint32_t* ik = from_a ? part_keys_a.p : part_keys_b.p;
-            const uint32_t* ip = from_a ? part_pts_a.p : part_pts_b.p;
-            uint32_t* ok = from_a ? part_keys_b.p : part_keys_a.p;
-            uint32_t* op = from_a ? part_pts_b.p : part_pts_a.p;
+            MsmScratch& S = mem();
+            const uint32_t* ik = from_a ? S.part_keys_a.p : S.part_keys_b.p;
+            const uint32_t* ip = from_a ? S.part_pts_a.p : S.part_pts_b.p;
+            uint32_t* ok = from_a ? S.part_keys_b.p : S.part_keys_a.p;
+            uint32_t* op = from_a ? S.part_pts_b.p : S.part_pts_a.p;
             k_combine_wave<F29T><<<waves, 64, 0, st>>>(ik, ip, plan, level, 0u, bucket_sums.p, ok, op);
             CG_KERNEL_CHECK();
             segs = waves;

@@ -41,6 +41,27 @@ int msm_default_window(uint64_t n, bool precomputed);
 // g2 = the additions are over Fq2 (the ratio of the two addition kinds is the same, so only the bucket term's weight differs).
 int msm_best_window(uint64_t n_bases, double nz_small, double nz_full);
 
+// The memory an engine needs only from its digits() to the end of its accumulate(): the two entry lists and the pieces of
+// the segments.  It is most of a proof slot (the entry lists are 8 B x bases x windows, twice), and in a throughput context
+// the MSMs of a proof run one after another on one stream, so the five engines of a slot SHARE one MsmScratch sized for
+// the largest of them (prover.hip); an engine that was given none owns one.
+struct MsmScratch {
+    DevBuf<uint64_t> ent_a, ent_b;            // entries grouped by the high key bits (level 1) / by the whole key (level 2)
+    DevBuf<uint32_t> part_keys_a, part_keys_b;
+    DevBuf<uint32_t> part_pts_a, part_pts_b;  // u32 words: engines over Fq and Fq2 store 36- and 72-word accumulators in it
+    // grows what is too small (contents are not kept), never shrinks
+    uint64_t entry_bytes() const { return ent_a.bytes() + ent_b.bytes(); }
+    uint64_t piece_bytes() const { return part_keys_a.bytes() + part_keys_b.bytes() + part_pts_a.bytes() + part_pts_b.bytes(); }
+    void reserve(size_t n_ent_a, size_t n_ent_b, size_t keys_a, size_t pts_a, size_t keys_b, size_t pts_b) {
+        if (ent_a.n < n_ent_a) ent_a.alloc(n_ent_a);
+        if (ent_b.n < n_ent_b) ent_b.alloc(n_ent_b);
+        if (part_keys_a.n < keys_a) part_keys_a.alloc(keys_a);
+        if (part_pts_a.n < pts_a) part_pts_a.alloc(pts_a);
+        if (part_keys_b.n < keys_b) part_keys_b.alloc(keys_b);
+        if (part_pts_b.n < pts_b) part_pts_b.alloc(pts_b);
+    }
+};
+
 // Per-MSM working set; reusable across proofs.
 template <class F>
 struct MsmEngine {
@@ -49,9 +70,12 @@ struct MsmEngine {
     const MsmBases<F>* bases = nullptr;
     uint64_t cap_entries = 0;
     uint32_t nbuckets_total = 0;  // buckets per window * windows-in-key-space
-    // digit entries: bucket key in the high word, table index | sign<<31 in the low word; ent_a grouped by the high key
-    // bits (level 1), ent_b by the whole key (level 2; unused when one level covers the key)
-    DevBuf<uint64_t> ent_a, ent_b;
+    // digit entries: bucket key in the high word, table index | sign<<31 in the low word; mem().ent_a grouped by the high
+    // key bits (level 1), mem().ent_b by the whole key (level 2; unused when one level covers the key)
+    MsmScratch own_mem;
+    MsmScratch* shared_mem = nullptr; // set before init(): scratch shared with engines whose MSMs never overlap this one's
+    MsmScratch& mem() { return shared_mem ? *shared_mem : own_mem; }
+    const MsmScratch& mem() const { return shared_mem ? *shared_mem : own_mem; }
     int bits1 = 0, bits2 = 0;         // key bits taken by the two partition levels
     DevBuf<uint32_t> blk_hist;        // per level-1 block: its counts per bin
     DevBuf<uint32_t> counters;        // plan | level-1 histogram, cursors | level-2 histogram, cursors (zeroed per MSM)
@@ -60,8 +84,6 @@ struct MsmEngine {
     uint32_t min_L = 16;              // shortest segment (entries per lane) the plan may choose
     uint32_t max_segments = 0;        // launch bound of the accumulation (the plan's segment count is at most this)
     DevBuf<uint32_t> bucket_sums;     // nbuckets_total * ACC
-    DevBuf<uint32_t> part_keys_a, part_keys_b;
-    DevBuf<uint32_t> part_pts_a, part_pts_b;
     DevBuf<uint32_t> rows_buf, cols_buf;   // row / column sums of the bucket matrix (bucket reduction)
     DevBuf<uint32_t> rowp_buf, colp_buf;   // sums of 32-bucket chunks of the rows / columns (throughput contexts)
     int red_rbits = 0, red_cbits1 = 0;     // bits of the row weights r < R and of the column weights col + 1 <= C
@@ -70,6 +92,7 @@ struct MsmEngine {
     PinnedBuf<uint32_t> h_result;     // per window: red_rbits + red_cbits1 per-bit sums of the rows / the columns
     uint64_t n_scalars = 0;
     bool latency_mode = false;        // set before init(): short segments (one proof at a time matters more than proofs per second)
+#ifdef CG_WITH_BATCH_AFFINE
     // batch-affine pair rounds in front of the accumulation (batchaff.hpp; G1 only; 0 = off)
     bool ba_allowed = true;           // set before init()
     int ba_rounds = 0;
@@ -77,6 +100,7 @@ struct MsmEngine {
     uint32_t ba_tcap[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // launch bound (lanes) of every round
     DevBuf<uint32_t> ba_prefix, ba_totals, ba_inv, ba_chain, ba_wpre, ba_rec_a, ba_rec_b, ba_plan;
     DevBuf<uint64_t> ba_split, ba_exc;
+#endif
     // valid once the stream has been synchronised
     uint32_t n_entries() const { return h_plan.p ? h_plan.p[0] : 0; }
     uint32_t n_nonzero() const { return h_plan.p ? h_plan.p[3] : 0; }
@@ -90,6 +114,9 @@ struct MsmEngine {
 
     void init(const MsmBases<F>* b);
     ~MsmEngine();
+    // device memory this engine holds, by kind (cg_ctx_get_info): entry lists and segment pieces it OWNS (nothing when it
+    // works in a shared scratch), and the rest (bucket array, reduction buffers, partition counters)
+    void device_bytes(uint64_t& entries, uint64_t& pieces, uint64_t& other) const;
     // phase 1: signed-digit extraction of `n` canonical scalars -> (bucket, index) entries grouped by bucket
     void digits(const Fr* scalars_dev, uint64_t n, hipStream_t st);
     // phase 1 taken over from another engine that grouped the SAME scalars against bases with the same identity pattern,
@@ -101,7 +128,7 @@ struct MsmEngine {
                bits1 == src.bits1 && bits2 == src.bits2;
     }
     void adopt(const uint64_t* grouped_entries, const uint32_t* plan_dev, uint64_t n, hipStream_t st);
-    const uint64_t* grouped() const { return bits2 ? ent_b.p : ent_a.p; }
+    const uint64_t* grouped() const { return bits2 ? mem().ent_b.p : mem().ent_a.p; }
     const uint64_t* adopted = nullptr;    // non-null: the grouped entries of the engine adopted for the current MSM
     // phase 2: accumulate, combine, reduce; per-bit sums and the plan copied to pinned memory.  Neither phase waits
     // for the host.

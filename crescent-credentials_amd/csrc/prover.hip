@@ -127,6 +127,9 @@ using namespace cg;
 // of another); the key tables, matrices and NTT tables are shared and read-only.
 struct ProofSlot {
     std::mutex busy;
+    // one-stream slots: the five MSMs of a proof run one after another, so their entry lists and segment pieces live in
+    // ONE scratch sized for the largest (declared before the engines that point into it: destroyed after them)
+    MsmScratch scratch;
     MsmEngine<Fq> eh, el, ea, eb1;
     MsmEngine<Fq2> eb2;
     DevBuf<Fr> h_canon;
@@ -221,7 +224,10 @@ struct cg_ctx {
     std::atomic<int> calls_inside{0};
     bool latency = false;
     // device bytes that stay resident (cg_ctx_get_info): window tables + validity flags | matrices and domain tables | one slot
+    // (slot_bytes is the sum of slot_part: entry lists, segment pieces, bucket arrays and reduction buffers, the witness
+    // map's vectors + the h MSM's scalars, one upload buffer - account_slot)
     int64_t table_bytes = 0, matrix_bytes = 0, slot_bytes = 0;
+    uint64_t slot_part[5] = {0, 0, 0, 0, 0};
     std::mutex pick_mu;
     std::condition_variable pick_cv;
     // blocks until a slot is free; returns it locked
@@ -239,6 +245,23 @@ struct cg_ctx {
         pick_cv.notify_one();
     }
 };
+// what ONE proof slot holds on the device, by kind, read off the first slot's buffers (the slots are identical); called
+// when the slots are made and after a re-tune has re-sized them
+static void account_slot(cg_ctx* c) {
+    uint64_t ent = 0, pcs = 0, oth = 0;
+    if (!c->slots.empty()) {
+        const ProofSlot& S = *c->slots[0];
+        ent = S.scratch.entry_bytes(); pcs = S.scratch.piece_bytes();
+        S.eh.device_bytes(ent, pcs, oth); S.el.device_bytes(ent, pcs, oth); S.ea.device_bytes(ent, pcs, oth);
+        S.eb1.device_bytes(ent, pcs, oth); S.eb2.device_bytes(ent, pcs, oth);
+        c->slot_part[3] = S.wm.device_bytes() + S.h_canon.bytes();
+    }
+    c->slot_part[0] = ent; c->slot_part[1] = pcs; c->slot_part[2] = oth;
+    c->slot_part[4] = c->uploads.empty() ? 0 : c->uploads[0]->w.bytes();      // about one upload buffer per proof in flight
+    c->slot_bytes = 0;
+    for (uint64_t v : c->slot_part) c->slot_bytes += (int64_t)v;
+}
+
 struct CallGuard {
     cg_ctx* c;
     explicit CallGuard(cg_ctx* ctx) : c(ctx) { if (c) c->calls_inside.fetch_add(1, std::memory_order_acq_rel); }
@@ -293,7 +316,13 @@ static int translate_exception() { return cg::translate_current_exception(); }
 
 extern "C" const char* cg_last_error(void) { return last_error().c_str(); }
 
-extern "C" const char* cg_version(void) { return "crescent_gpu 0.1 (gfx950; BN254 Groth16 prove path: MSM G1/G2 + NTT + witness map)"; }
+extern "C" const char* cg_version(void) {
+#ifdef CG_WITH_BATCH_AFFINE
+    return "crescent_gpu 0.1 (gfx950; BN254 Groth16 prove path: MSM G1/G2 + NTT + witness map) [experiment build: batch-affine]";
+#else
+    return "crescent_gpu 0.1 (gfx950; BN254 Groth16 prove path: MSM G1/G2 + NTT + witness map)";
+#endif
+}
 
 extern "C" int cg_init(int n_devices, const int* device_ids) {
     // The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); kernels of streams that share a
@@ -454,8 +483,8 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         // are a throughput job
         c->latency = n_slots == 1;
         if (const char* e = getenv("CG_LATENCY_MODE")) c->latency = e[0] == '1';    // profiling aid: force either segment length
+        book(nullptr);                                    // slots are accounted by kind from their buffers (account_slot)
         for (int k = 0; k < n_slots; ++k) {
-            book(k == 0 ? &c->slot_bytes : nullptr);      // the slots are identical: the first one is booked
             std::unique_ptr<ProofSlot> sl(new ProofSlot());
             // A throughput context runs every proof on ONE stream: with a dozen proofs in flight the overlap comes from the
             // other proofs, and twelve streams fit the hardware queues one each, where 60 share them (and anything above
@@ -482,14 +511,16 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
             for (auto& e : sl->ev_t) CG_HIP(hipEventCreate(&e));
             const bool latency = c->latency;
             sl->eh.latency_mode = sl->el.latency_mode = sl->ea.latency_mode = sl->eb1.latency_mode = sl->eb2.latency_mode = latency;
+#ifdef CG_WITH_BATCH_AFFINE
             if (getenv("CG_BA_H_ONLY")) sl->el.ba_allowed = sl->ea.ba_allowed = sl->eb1.ba_allowed = false;   // experiment switch
+#endif
+            if (serial) sl->eh.shared_mem = sl->el.shared_mem = sl->ea.shared_mem = sl->eb1.shared_mem = sl->eb2.shared_mem = &sl->scratch;
             sl->eh.init(&c->bh); sl->el.init(&c->bl); sl->ea.init(&c->ba); sl->eb1.init(&c->bb1); sl->eb2.init(&c->bb2);
             sl->h_canon.alloc(D);
             sl->wm.alloc(M, D, std::max(c->A.sell_scratch, std::max(c->B.sell_scratch, c->C.sell_scratch)));
             c->slots.push_back(std::move(sl));
         }
         for (int k = 0; k < n_slots + 2; ++k) {
-            book(k == 0 ? &c->slot_bytes : nullptr);      // booked with the slot: about one per proof in flight
             std::unique_ptr<Upload> u(new Upload());
             u->w.alloc(M);
             CG_HIP(hipStreamCreateWithFlags(&u->st, hipStreamNonBlocking));
@@ -497,7 +528,7 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
             CG_HIP(hipEventCreateWithFlags(&u->ev_done, hipEventDisableTiming));
             c->uploads.push_back(std::move(u));
         }
-        book(nullptr);
+        account_slot(c.get());
         *out = c.release();
         return CG_OK;
     } catch (...) {
@@ -599,34 +630,55 @@ static int prove_partial_impl(cg_ctx* c, ProofSlot* S, const Fr* w_dev, bool ski
     const uint64_t M = c->M, l = c->l;
     (void)M;
     hipStream_t s0 = S->st[0];
-    CG_HIP(hipEventRecord(S->ev_w, s0));
-    for (int i = 1; i < 5; ++i) CG_HIP(hipStreamWaitEvent(S->st[i], S->ev_w, 0));
     // assignment-driven MSMs: operands (prover.rs:70-74, 84-89, 265-266)
     //   l: l_query[i] x w[l + i];  a, b1, b2: query[1 + i] x w[1 + i]
-    S->el.digits(w_dev + (c->folded ? 0 : l) + c->rl.lo, c->rl.hi - c->rl.lo, S->st[1]);   // folded l query: one base per wire
-    S->ea.digits(w_dev + 1 + c->ra.lo, c->ra.hi - c->ra.lo, S->st[2]);
-    if (!skip_b1) S->eb1.digits(w_dev + 1 + c->ra.lo, c->ra.hi - c->ra.lo, S->st[3]);
+    const Fr* w_l = w_dev + (c->folded ? 0 : l) + c->rl.lo;          // folded l query: one base per wire
+    const uint64_t n_l = c->rl.hi - c->rl.lo, n_a = c->ra.hi - c->ra.lo;
+    const Fr* w_a = w_dev + 1 + c->ra.lo;
     // b1 and b2 take the same scalars against bases that vanish together: with equal windows the grouped entry list of
     // one IS the other's, so the G2 MSM skips its own grouping (five launches, ~0.9 % of a proof's instructions)
     static const bool no_share = getenv("CG_NO_SHARE_B") != nullptr;        // A/B aid
-    if (!skip_b1 && !no_share && c->b_same_identities && S->eb2.can_adopt(S->eb1) && c->ra.hi > c->ra.lo) {
-        CG_HIP(hipEventRecord(S->ev_b1, S->st[3]));
-        CG_HIP(hipStreamWaitEvent(S->st[4], S->ev_b1, 0));
-        S->eb2.adopt(S->eb1.grouped(), S->eb1.counters.p, c->ra.hi - c->ra.lo, S->st[4]);
+    const bool b2_adopts = !skip_b1 && !no_share && c->b_same_identities && S->eb2.can_adopt(S->eb1) && n_a > 0;
+    if (S->one_stream) {
+        // everything on one stream, every MSM grouped and accumulated before the next one starts: the engines share the
+        // slot's scratch (entry lists, segment pieces), which is what a slot's memory mostly is
+        S->el.digits(w_l, n_l, s0); S->el.accumulate(s0);
+        S->ea.digits(w_a, n_a, s0); S->ea.accumulate(s0);
+        if (!skip_b1) S->eb1.digits(w_a, n_a, s0);
+        if (b2_adopts) S->eb2.adopt(S->eb1.grouped(), S->eb1.counters.p, n_a, s0);    // b1's list is still in the scratch ...
+        if (!skip_b1) S->eb1.accumulate(s0);
+        if (!b2_adopts) S->eb2.digits(w_a, n_a, s0);
+        S->eb2.accumulate(s0);                                                         // ... until here
+        if (tm) CG_HIP(hipEventRecord(S->ev_t[0], s0));
+        run_witness_map(c, S, w_dev, s0, c->folded);   // h_canon: coefficients of h, or the coset values vinv·a·b for a folded key
+        if (tm) CG_HIP(hipEventRecord(S->ev_t[1], s0));
+        S->eh.digits(S->h_canon.p + c->rh.lo, c->rh.hi - c->rh.lo, s0);
+        S->eh.accumulate(s0);
     } else {
-        S->eb2.digits(w_dev + 1 + c->ra.lo, c->ra.hi - c->ra.lo, S->st[4]);
+        CG_HIP(hipEventRecord(S->ev_w, s0));
+        for (int i = 1; i < 5; ++i) CG_HIP(hipStreamWaitEvent(S->st[i], S->ev_w, 0));
+        S->el.digits(w_l, n_l, S->st[1]);
+        S->ea.digits(w_a, n_a, S->st[2]);
+        if (!skip_b1) S->eb1.digits(w_a, n_a, S->st[3]);
+        if (b2_adopts) {
+            CG_HIP(hipEventRecord(S->ev_b1, S->st[3]));
+            CG_HIP(hipStreamWaitEvent(S->st[4], S->ev_b1, 0));
+            S->eb2.adopt(S->eb1.grouped(), S->eb1.counters.p, n_a, S->st[4]);
+        } else {
+            S->eb2.digits(w_a, n_a, S->st[4]);
+        }
+        // witness map, then h digits, on stream 0
+        if (tm) CG_HIP(hipEventRecord(S->ev_t[0], s0));
+        run_witness_map(c, S, w_dev, s0, c->folded);   // h_canon: coefficients of h, or the coset values vinv·a·b for a folded key
+        if (tm) CG_HIP(hipEventRecord(S->ev_t[1], s0));
+        S->eh.digits(S->h_canon.p + c->rh.lo, c->rh.hi - c->rh.lo, s0);
+        // second phase (each waits for its own entry count)
+        S->el.accumulate(S->st[1]);
+        S->ea.accumulate(S->st[2]);
+        if (!skip_b1) S->eb1.accumulate(S->st[3]);
+        S->eb2.accumulate(S->st[4]);
+        S->eh.accumulate(s0);
     }
-    // witness map, then h digits, on stream 0
-    if (tm) CG_HIP(hipEventRecord(S->ev_t[0], s0));
-    run_witness_map(c, S, w_dev, s0, c->folded);   // h_canon: coefficients of h, or the coset values vinv·a·b for a folded key
-    if (tm) CG_HIP(hipEventRecord(S->ev_t[1], s0));
-    S->eh.digits(S->h_canon.p + c->rh.lo, c->rh.hi - c->rh.lo, s0);
-    // second phase (each waits for its own entry count)
-    S->el.accumulate(S->st[1]);
-    S->ea.accumulate(S->st[2]);
-    if (!skip_b1) S->eb1.accumulate(S->st[3]);
-    S->eb2.accumulate(S->st[4]);
-    S->eh.accumulate(s0);
     if (while_gpu_runs) (*while_gpu_runs)();      // host work that needs no MSM value
     if (S->one_stream && !spin_wait()) {
         CG_HIP(hipEventRecord(S->ev_done, s0));
@@ -754,10 +806,7 @@ static void reinit_engines(cg_ctx* c, MsmEngine<F> ProofSlot::*eng, const MsmBas
     try {
         // CG_FAULT_RETUNE=1 (testing aid): fail here as an allocation would, table rebuilt and engines not yet re-sized
         if (const char* f = getenv("CG_FAULT_RETUNE")) if (f[0] == '1') throw HipError(CG_ERR_OUT_OF_MEMORY, "injected: out of device memory while re-sizing the proof slots");
-        for (size_t k = 0; k < c->slots.size(); ++k) {
-            AllocScope booking(k == 0 ? &c->slot_bytes : nullptr);
-            ((*c->slots[k]).*eng).init(&bases);
-        }
+        for (size_t k = 0; k < c->slots.size(); ++k) ((*c->slots[k]).*eng).init(&bases);
     } catch (...) {
         c->broken = true;     // the table is already the new one: engines and table no longer agree
         throw;
@@ -805,7 +854,9 @@ static void maybe_retune(cg_ctx* c, const TuneStats& ts) {
             if (rc > 0) reinit_engines(c, &ProofSlot::eb1, c->bb1);
         }
         c->tuned = true;
+        account_slot(c);
     } catch (...) {
+        account_slot(c);
         // the proof this call belongs to is already computed: a failed re-tune (out of memory beside another tenant of the
         // GPU, say) leaves the size-based windows in force and is retried by a later proof, never reported as that
         // proof's failure
@@ -1008,6 +1059,8 @@ extern "C" int cg_ctx_get_info(cg_ctx* ctx, cg_ctx_info* out) {
         out->shard_rank = ctx->shard_rank;
         out->shard_count = ctx->shard_count;
         out->latency_mode = ctx->latency ? 1 : 0;
+        out->slot_entry_bytes = ctx->slot_part[0]; out->slot_piece_bytes = ctx->slot_part[1]; out->slot_bucket_bytes = ctx->slot_part[2];
+        out->slot_transform_bytes = ctx->slot_part[3]; out->slot_upload_bytes = ctx->slot_part[4];
         return CG_OK;
     } catch (...) {
         return translate_exception();

@@ -58,6 +58,7 @@ struct Wm29Buffers {     // per proof slot
         sp_a.alloc((size_t)(sparse_scratch ? sparse_scratch : 1) * 8); sp_b.alloc((size_t)(sparse_scratch ? sparse_scratch : 1) * 8);
         h_bad_input.alloc(1);
     }
+    uint64_t device_bytes() const { return w29.bytes() + va.bytes() + vb.bytes() + vc.bytes() + vt.bytes() + sp_a.bytes() + sp_b.bytes(); }
 };
 
 // Unit-level transform over the same kernels (cg_ntt_*): 2^logn canonical scalars on the device, natural order in

@@ -209,6 +209,14 @@ typedef struct cg_ctx_info {
     int32_t shard_count;
     int32_t latency_mode;        /* 1: short accumulation segments + tree reductions (one proof at a time); 0: throughput */
     int32_t reserved[4];
+    /* slot_bytes by kind (they add up to it).  In a throughput context the five MSMs of a proof run one after another and
+     * share one set of entry lists and segment pieces, sized for the largest of them; a latency context (proof_slots = 1)
+     * runs them concurrently and holds a set per MSM. */
+    uint64_t slot_entry_bytes;     /* digit-entry lists: 8 B x bases x windows, two of them (grouped by the high / by the whole key) */
+    uint64_t slot_piece_bytes;     /* first / last run of every accumulation segment, for the wave-combine levels */
+    uint64_t slot_bucket_bytes;    /* bucket arrays, row / column sums of the reduction, partition histograms and cursors */
+    uint64_t slot_transform_bytes; /* the witness map's vectors (assignment + four domain-sized vectors) and the h MSM's scalars */
+    uint64_t slot_upload_bytes;    /* one device copy of an assignment arriving from the host (the context holds proof_slots + 2) */
 } cg_ctx_info;
 int cg_ctx_get_info(cg_ctx* ctx, cg_ctx_info* out);
 

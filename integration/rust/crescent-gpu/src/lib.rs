@@ -91,13 +91,14 @@ struct PinnedBytes {
     len: usize,
 }
 impl PinnedBytes {
-    fn new(len: usize) -> Result<Self, SynthesisError> {
+    /// None when the page-lock fails (the caller then falls back to pageable memory, which `cg_prove` also takes)
+    fn new(len: usize) -> Option<Self> {
         let p = unsafe { sys::cg_host_alloc(len as u64) } as *mut u8;
         if p.is_null() {
-            eprintln!("crescent-gpu: {}", last_error());
-            return Err(SynthesisError::AssignmentMissing);
+            eprintln!("crescent-gpu: page-locked witness buffer unavailable ({}): using pageable memory", last_error());
+            return None;
         }
-        Ok(PinnedBytes { ptr: p, len })
+        Some(PinnedBytes { ptr: p, len })
     }
     #[allow(clippy::mut_from_ref)]
     fn slice_mut(&self) -> &mut [u8] {
@@ -110,9 +111,18 @@ impl Drop for PinnedBytes {
     }
 }
 
+// PinnedBytes is only ever touched by the thread that took it out of the pool
+unsafe impl Send for PinnedBytes {}
+
 pub struct GpuCircuit {
     ctx: *mut sys::cg_ctx,
     num_variables: usize,
+    /// Page-locked witness buffers, kept for the life of the circuit: `hipHostMalloc` page-locks 48 MB at full size (a few
+    /// milliseconds) and `hipHostFree` synchronises the WHOLE device, so allocating and freeing one per proof would stall
+    /// every finishing caller behind every proof in flight.  A proof takes a buffer out and puts it back; at most
+    /// `pool_max` (= proof_slots + 2, the upload buffers the context holds) are retained, all freed in `Drop`.
+    pool: Mutex<Vec<PinnedBytes>>,
+    pool_max: usize,
 }
 // calls on one context are multiplexed over its proof slots inside the library
 unsafe impl Send for GpuCircuit {}
@@ -160,7 +170,7 @@ impl GpuCircuit {
         if rc != 0 {
             return Err(map_err(rc));
         }
-        Ok(GpuCircuit { ctx, num_variables })
+        Ok(GpuCircuit { ctx, num_variables, pool: Mutex::new(Vec::new()), pool_max: proof_slots.max(1) as usize + 2 })
     }
 
     /// forks/groth16/src/prover.rs:26-51 with the key and the matrices already resident on the GPU.
@@ -169,15 +179,31 @@ impl GpuCircuit {
         if full_assignment.len() != self.num_variables {
             return Err(SynthesisError::AssignmentMissing);
         }
-        // the canonical bytes are written straight into page-locked memory (cg_host_alloc): cg_prove's upload is then
-        // one asynchronous DMA at PCIe speed that overlaps the other proofs in flight
-        let w = PinnedBytes::new(full_assignment.len() * 32)?;
+        // the canonical bytes are written straight into page-locked memory from the circuit's pool: cg_prove's upload is
+        // then one asynchronous DMA at PCIe speed that overlaps the other proofs in flight.  Should page-locking fail
+        // (locked-memory limit of the host), a pageable Vec does the same job a little slower - never an error.
+        let len = full_assignment.len() * 32;
+        let pinned = self.pool.lock().unwrap().pop().or_else(|| PinnedBytes::new(len));
+        let mut pageable: Vec<u8> = Vec::new();
+        let buf: &mut [u8] = match &pinned {
+            Some(p) => p.slice_mut(),
+            None => {
+                pageable.resize(len, 0);
+                &mut pageable[..]
+            }
+        };
         for (i, x) in full_assignment.iter().enumerate() {
-            w.slice_mut()[i * 32..i * 32 + 32].copy_from_slice(&x.into_bigint().to_bytes_le()); // prover.rs:64,71,86 take the same form
+            buf[i * 32..i * 32 + 32].copy_from_slice(&x.into_bigint().to_bytes_le()); // prover.rs:64,71,86 take the same form
         }
         let (rb, sb) = (r.into_bigint().to_bytes_le(), s.into_bigint().to_bytes_le());
         let mut out = [0u8; 256];
-        let rc = unsafe { sys::cg_prove(self.ctx, w.ptr as *const u8, rb.as_ptr(), sb.as_ptr(), out.as_mut_ptr(), std::ptr::null_mut()) };
+        let rc = unsafe { sys::cg_prove(self.ctx, buf.as_ptr(), rb.as_ptr(), sb.as_ptr(), out.as_mut_ptr(), std::ptr::null_mut()) };
+        if let Some(p) = pinned {
+            let mut pool = self.pool.lock().unwrap();
+            if pool.len() < self.pool_max {
+                pool.push(p); // kept for the next proof; a surplus buffer (more callers than slots + 2) is freed here
+            }
+        }
         if rc != 0 {
             return Err(map_err(rc));
         }
@@ -200,7 +226,8 @@ impl GpuCircuit {
 
 impl Drop for GpuCircuit {
     fn drop(&mut self) {
-        unsafe { sys::cg_circuit_free(self.ctx) }
+        unsafe { sys::cg_circuit_free(self.ctx) } // waits for calls still inside the context
+        self.pool.lock().unwrap().clear(); // cg_host_free: the one place the pinned buffers are released
     }
 }
 

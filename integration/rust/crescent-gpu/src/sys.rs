@@ -90,6 +90,11 @@ pub struct cg_ctx_info {
     pub shard_count: i32,
     pub latency_mode: i32,
     pub reserved: [i32; 4],
+    pub slot_entry_bytes: u64,
+    pub slot_piece_bytes: u64,
+    pub slot_bucket_bytes: u64,
+    pub slot_transform_bytes: u64,
+    pub slot_upload_bytes: u64,
 }
 
 pub enum cg_ctx {}

@@ -115,3 +115,61 @@ def test_full_size_sharded_contexts_assemble_to_the_same_proof(cc, oracle, shape
         assert got0 == whole.prove(w, 0, 0).data
     finally:
         whole.close()
+
+
+def _random_canonical(n, seed):
+    """n uniform field elements as canonical bytes: the top byte is kept below 0x30 (the modulus' top byte), which loses
+    nothing that matters to a transform or an MSM"""
+    a = np.random.default_rng(seed).integers(0, 256, size=(n, 32), dtype=np.uint8)
+    a[:, 31] %= 0x30
+    return a.reshape(-1)
+
+
+@pytest.mark.parametrize("logn", [21, 22])
+def test_full_size_transforms_equal_cpu_restatement(cc, logn):
+    """cg_ntt_run at the sizes of S21 / S22 in all four modes (forward / inverse, subgroup / coset 5·<w>), element by element
+    against the C restatement's radix-2 transform (r1cs_to_qap.rs:179-210) - not by round trips"""
+    import cpu_ref
+    nt = _threads()
+    data = _random_canonical(1 << logn, 100 + logn)
+    ctx = cc.NttContext(logn)
+    try:
+        for inverse in (False, True):
+            for coset in (False, True):
+                got = ctx.run(data, inverse=inverse, coset=coset)
+                want = cpu_ref.ntt(data, inverse=inverse, coset=coset, nthreads=nt)
+                assert np.array_equal(np.asarray(got).reshape(-1), want.reshape(-1)), (logn, inverse, coset)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("group,logn", [(1, 21), (2, 20)], ids=lambda v: str(v))
+def test_full_size_msm_equals_cpu_restatement(cc, group, logn):
+    """cg_msm_run at full size - G1 over 2^21 bases, G2 over 2^20 - with uniform and with circom-like scalars (56 % zero,
+    34 % one, 10 % uniform), scalars in host memory and already on the device, against the C restatement's Pippenger
+    (prover.rs:66,74,266): the value itself, not a closed form"""
+    import cpu_ref
+    import torch
+    nt = _threads()
+    n = 1 << logn
+    ks = _random_canonical(n, 7 + group)
+    bases = np.frombuffer(cc.fixed_base_g1(ks) if group == 1 else cc.fixed_base_g2(ks), np.uint8)
+    uniform = _random_canonical(n, 11 + group)
+    u = np.random.default_rng(13 + group).random(n)
+    circom = uniform.reshape(n, 32).copy()
+    circom[u < 0.56] = 0
+    ones = (u >= 0.56) & (u < 0.90)
+    circom[ones] = 0
+    circom[ones, 0] = 1
+    circom = circom.reshape(-1)
+    ref = cpu_ref.msm_g1 if group == 1 else cpu_ref.msm_g2
+    ctx = cc.MsmContext(bases, group=group)
+    try:
+        for name, sc in (("uniform", uniform), ("circom-like", circom)):
+            want = ref(bases, sc, nthreads=nt)
+            assert ctx.run(sc) == want, (group, name, "host scalars")
+            d = torch.from_numpy(sc).cuda()
+            assert ctx.run_dev(d.data_ptr(), n) == want, (group, name, "device scalars")
+            assert ctx.run(sc[:32 * (n - 12345)]) == ref(bases, sc[:32 * (n - 12345)], nthreads=nt), (group, name, "shorter scalar vector")
+    finally:
+        ctx.close()

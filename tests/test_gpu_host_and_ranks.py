@@ -81,6 +81,11 @@ def test_ctx_info_reports_memory_windows_and_the_retune(cc, oracle, medium):
         assert i0["proof_slots"] == 2 and i0["tuned"] == 0 and i0["retune_attempts"] == 0 and i0["latency_mode"] == 0
         assert i0["table_bytes"] > 0 and i0["slot_bytes"] > 0 and i0["matrix_bytes"] > 0
         assert i0["total_bytes"] == i0["table_bytes"] + i0["matrix_bytes"] + 2 * i0["slot_bytes"]
+        kinds = ("slot_entry_bytes", "slot_piece_bytes", "slot_bucket_bytes", "slot_transform_bytes", "slot_upload_bytes")
+        assert all(i0[k] > 0 for k in kinds) and sum(i0[k] for k in kinds) == i0["slot_bytes"]
+        # a throughput slot holds ONE set of entry lists for its five MSMs (sized for the largest: h, 2 x 8 B x D x windows)
+        W_h = (255 + wb_h - 1) // wb_h if (wb_h := i0["window_bits"]["h"]) else 0
+        assert i0["slot_entry_bytes"] == 2 * 8 * prover.domain_size * W_h
         assert i0["device_total_bytes"] > i0["device_free_bytes"] > 0
         # tables: at least the h query's rows (64 B per point and window)
         D = prover.domain_size
@@ -98,6 +103,7 @@ def test_ctx_info_reports_memory_windows_and_the_retune(cc, oracle, medium):
         assert i2["tuned"] == 1 and i2["retune_skipped_for_memory"] == 0 and i2["window_bits"]["h"] == wb["h"]
         assert i2["window_bits"]["a"] <= wb["a"]
         assert i2["total_bytes"] == i2["table_bytes"] + i2["matrix_bytes"] + 2 * i2["slot_bytes"]
+        assert sum(i2[k] for k in kinds) == i2["slot_bytes"]
         prover.prove(w, 1, 2)
         assert prover.info()["retune_attempts"] == i2["retune_attempts"]
     finally:
@@ -111,6 +117,8 @@ def test_ctx_info_reports_memory_windows_and_the_retune(cc, oracle, medium):
             p2.prove(z, 3, 4)
         i = p2.info()
         assert i["tuned"] == 0 and i["retune_attempts"] == 8 and i["latency_mode"] == 1
+        # a latency context runs its five MSMs concurrently: an entry-list set per MSM
+        assert i["slot_entry_bytes"] > 2 * i0["slot_entry_bytes"]
     finally:
         p2.close()
     # a fixed window is never re-tuned
