@@ -299,7 +299,7 @@ static constexpr uint32_t PART_TILE = 4096;       // scalars per block, level 1 
 static constexpr uint32_t PART_THREADS = 1024;    // threads of a level-1 block
 static constexpr uint32_t PART_CHUNK = 8192;      // entries per block, level 2
 static constexpr uint32_t PART_PAD = 16;          // level-1 global counters sit 64 B apart: atomics of different bins do not share a line
-enum { PLAN_N = 0, PLAN_L = 1, PLAN_T = 2, PLAN_NONZERO = 3, PLAN_CHUNKS = 4, PLAN_WORDS = 8 };
+enum { PLAN_N = 0, PLAN_L = 1, PLAN_T = 2, PLAN_NONZERO = 3, PLAN_CHUNKS = 4, PLAN_DONE = 5, PLAN_WORDS = 8 };   // PLAN_DONE: counting blocks that have finished
 
 struct PartShape {
     uint32_t n;            // scalars
@@ -325,10 +325,19 @@ __device__ __forceinline__ void for_each_entry(const PartShape& sh, const Fr& s,
     else for_each_digit(s.l, sh.c, sh.W, emit);
 }
 
+// what the plan needs besides the histogram (k_part_count's last block writes the plan: part_plan_block)
+struct PlanArgs {
+    uint32_t* start1;          // B1 + 1: first slot of every level-1 bin
+    uint32_t* chunk0;          // B1 + 1: first level-2 chunk of every bin
+    uint32_t target_threads, min_L;
+    int two_level;
+};
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t* sc, uint32_t n);
+__device__ __forceinline__ void part_plan_block(int bits1, const PlanArgs& pa, const uint32_t* hist1, uint32_t* plan, uint32_t* lds);
+
 template <int C>
 __global__ void __launch_bounds__(PART_THREADS) k_part_count(PartShape sh, const Fr* __restrict__ scalars, const uint8_t* __restrict__ valid,
-                                                    uint32_t* __restrict__ blk_hist, uint32_t* __restrict__ hist1,
-                                                    uint32_t* __restrict__ plan) {
+                                                    uint32_t* __restrict__ blk_hist, uint32_t* hist1, uint32_t* plan, PlanArgs pa) {
     extern __shared__ uint32_t lds[];
     const uint32_t B1 = 1u << sh.bits1;
     for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) lds[k] = 0;
@@ -368,6 +377,22 @@ __global__ void __launch_bounds__(PART_THREADS) k_part_count(PartShape sh, const
         row[k] = v;
         if (v) atomicAdd(&hist1[(size_t)k * PART_PAD], v);
     }
+    // The block that finishes LAST turns the histogram into the plan (entry total, segment geometry, bin starts, chunk
+    // table) - what a one-block launch of its own did before.  Everything the blocks hand to it goes through agent-scope
+    // ATOMICS (the histogram adds, the PLAN_DONE count, the last block's loads), which are performed at the coherence
+    // point of the eight XCDs' L2s: each wave waits for its own adds to be acknowledged (a workgroup-scope release is the
+    // s_waitcnt), the block meets at the barrier, one thread counts the block in.  No __threadfence(): at agent scope that
+    // is an L2 write-back + invalidate, and with it in every wave of this kernel the pipeline lost 17 %
+    // (profiles/r04_f_fold_ab.txt).
+    if (!pa.start1) return;            // CG_PLAN_LAUNCH=1 (A/B aid): the plan is made by a launch of its own
+    __shared__ uint32_t is_last;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0)
+        is_last = __hip_atomic_fetch_add(&plan[PLAN_DONE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+    __syncthreads();
+    if (!is_last) return;
+    part_plan_block(sh.bits1, pa, hist1, plan, lds);
 }
 
 // exclusive scan of `vals` (n <= 4096, in LDS `sc` of n words) by one block; total returned to every thread
@@ -397,36 +422,42 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t* sc, uint32_t 
     return grand;
 }
 
-// start1[b] = first slot of level-1 bin b (B1 + 1 values); chunk0[b] = first level-2 chunk of bin b (B1 + 1 values)
-__global__ void __launch_bounds__(1024) k_part_plan(int bits1, int two_level, const uint32_t* __restrict__ hist1,
-                                                    uint32_t* __restrict__ start1, uint32_t* __restrict__ chunk0,
-                                                    uint32_t* __restrict__ plan, uint32_t target_threads, uint32_t min_L) {
-    extern __shared__ uint32_t lds[];
+// start1[b] = first slot of level-1 bin b (B1 + 1 values); chunk0[b] = first level-2 chunk of bin b (B1 + 1 values).
+// Run by ONE block (the last block of k_part_count); lds: B1 words.
+__device__ __forceinline__ void part_plan_block(int bits1, const PlanArgs& pa, const uint32_t* hist1, uint32_t* plan, uint32_t* lds) {
     const uint32_t B1 = 1u << bits1;
-    for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) lds[k] = hist1[(size_t)k * PART_PAD];
+    auto hist = [&](uint32_t k) { return __hip_atomic_load(&hist1[(size_t)k * PART_PAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) lds[k] = hist(k);
     __syncthreads();
     const uint32_t N = block_exclusive_scan(lds, B1);
-    for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) start1[k] = lds[k];
+    for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) pa.start1[k] = lds[k];
     if (threadIdx.x == 0) {
-        start1[B1] = N;
-        uint32_t L = (uint32_t)(((uint64_t)N + target_threads - 1) / target_threads);
-        if (L < min_L) L = min_L;
+        pa.start1[B1] = N;
+        uint32_t L = (uint32_t)(((uint64_t)N + pa.target_threads - 1) / pa.target_threads);
+        if (L < pa.min_L) L = pa.min_L;
         plan[PLAN_N] = N;
         plan[PLAN_L] = L;
         plan[PLAN_T] = N ? (N + L - 1) / L : 0;
     }
-    if (!two_level) return;
+    if (!pa.two_level) return;
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) lds[k] = (hist1[(size_t)k * PART_PAD] + PART_CHUNK - 1) / PART_CHUNK;
+    for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) lds[k] = (hist(k) + PART_CHUNK - 1) / PART_CHUNK;
     __syncthreads();
     const uint32_t chunks = block_exclusive_scan(lds, B1);
-    for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) chunk0[k] = lds[k];
-    if (threadIdx.x == 0) { chunk0[B1] = chunks; plan[PLAN_CHUNKS] = chunks; }
+    for (uint32_t k = threadIdx.x; k < B1; k += blockDim.x) pa.chunk0[k] = lds[k];
+    if (threadIdx.x == 0) { pa.chunk0[B1] = chunks; plan[PLAN_CHUNKS] = chunks; }
+}
+
+__global__ void __launch_bounds__(1024) k_part_plan(int bits1, PlanArgs pa, const uint32_t* hist1, uint32_t* plan) {
+    extern __shared__ uint32_t lds[];
+    part_plan_block(bits1, pa, hist1, plan, lds);
 }
 
 // a plan taken over with another engine's entries: the segment geometry is re-cut for THIS engine's accumulation kernel
 // (the entry list itself does not care where it is cut)
-__global__ void k_replan(uint32_t* __restrict__ plan, uint32_t target_segments, uint32_t min_L) {
+__global__ void k_replan(uint32_t* __restrict__ plan, const uint32_t* __restrict__ src_plan, uint32_t target_segments, uint32_t min_L) {
+    for (int k = 0; k < PLAN_WORDS; ++k) plan[k] = src_plan[k];      // entry count and statistics travel with the entries
     const uint32_t N = plan[PLAN_N];
     uint32_t L = (uint32_t)(((uint64_t)N + target_segments - 1) / target_segments);
     if (L < min_L) L = min_L;
@@ -537,8 +568,8 @@ __global__ void __launch_bounds__(PART_THREADS) k_part_place_staged(PartShape sh
 template <int C>
 static void launch_part_level1_c(bool count, const PartShape& sh, uint32_t tiles, size_t lds, hipStream_t st, const Fr* scalars,
                                  const uint8_t* valid, uint32_t* blk_hist, uint32_t* hist1, uint32_t* plan, const uint32_t* start1,
-                                 uint32_t* cur1, uint64_t* out) {
-    if (count) { k_part_count<C><<<tiles, PART_THREADS, lds, st>>>(sh, scalars, valid, blk_hist, hist1, plan); return; }
+                                 uint32_t* cur1, uint64_t* out, const PlanArgs& pa) {
+    if (count) { k_part_count<C><<<tiles, PART_THREADS, lds, st>>>(sh, scalars, valid, blk_hist, hist1, plan, pa); return; }
     if constexpr (C >= STAGE_MIN_C) {
         // latency contexts only: the staging costs 15 M wave-instructions per proof more than it saves in stores (23.9 M against
         // 9.1 M for the h MSM), which is 0.1 ms off a lone proof and 0.7 % ON a proof in the pipeline.  CG_PLACE_STAGED=1 / 0 forces either.
@@ -557,12 +588,12 @@ static void launch_part_level1_c(bool count, const PartShape& sh, uint32_t tiles
 }
 static void launch_part_level1(bool count, const PartShape& sh, uint32_t tiles, size_t lds, hipStream_t st, const Fr* scalars,
                                const uint8_t* valid, uint32_t* blk_hist, uint32_t* hist1, uint32_t* plan, const uint32_t* start1,
-                               uint32_t* cur1, uint64_t* out) {
-#define CG_PART_CASE(C) case C: launch_part_level1_c<C>(count, sh, tiles, lds, st, scalars, valid, blk_hist, hist1, plan, start1, cur1, out); break;
+                               uint32_t* cur1, uint64_t* out, const PlanArgs& pa = PlanArgs{}) {
+#define CG_PART_CASE(C) case C: launch_part_level1_c<C>(count, sh, tiles, lds, st, scalars, valid, blk_hist, hist1, plan, start1, cur1, out, pa); break;
     switch (sh.c) {
         CG_PART_CASE(10) CG_PART_CASE(11) CG_PART_CASE(12) CG_PART_CASE(13) CG_PART_CASE(14) CG_PART_CASE(15) CG_PART_CASE(16)
         CG_PART_CASE(17) CG_PART_CASE(18) CG_PART_CASE(19) CG_PART_CASE(20) CG_PART_CASE(21) CG_PART_CASE(22)
-        default: launch_part_level1_c<0>(count, sh, tiles, lds, st, scalars, valid, blk_hist, hist1, plan, start1, cur1, out);
+        default: launch_part_level1_c<0>(count, sh, tiles, lds, st, scalars, valid, blk_hist, hist1, plan, start1, cur1, out, pa);
     }
 #undef CG_PART_CASE
 }
@@ -1009,79 +1040,96 @@ __device__ __forceinline__ XYZZ29<F29T> shfl_up_acc(const XYZZ29<F29T>& a, unsig
     return r;
 }
 
-// T = the segment count of this level (T_fixed), or, when `plan` is given, the plan's count divided by 64 `level` times
+// One launch per level; level k reads the pieces of level k - 1 and writes its own region of keys_b / pts_b (level k at
+// record offset 2·(W_0 + .. + W_{k-1}), W_k = waves of level k).  (Round 4 tried all levels in ONE launch - a wave publishes
+// its pair, takes a ticket of its 64-wave group, and the group's last wave goes on as the next level's: correct, and 23 %
+// slower in the pipeline together with the same pattern in k_part_count, because every __threadfence() at agent scope is an
+// L2 write-back + invalidate on a chip whose eight XCDs have an L2 each (profiles/r04_f_fold_ab.txt).  Cross-workgroup
+// hand-offs inside a kernel are not free on MI355X; a kernel boundary does the same flush once.)
 template <class F29T>
-__global__ void __launch_bounds__(64) k_combine_wave(const uint32_t* __restrict__ in_keys, const uint32_t* __restrict__ in_pts,
-                                                     const uint32_t* __restrict__ plan, int level, uint32_t T_fixed,
-                                                     uint32_t* __restrict__ bucket_sums,
-                                                     uint32_t* __restrict__ out_keys, uint32_t* __restrict__ out_pts) {
+__global__ void __launch_bounds__(64) k_combine_wave(const uint32_t* __restrict__ keys_a, const uint32_t* __restrict__ pts_a,
+                                                       const uint32_t* __restrict__ plan, uint32_t* bucket_sums,
+                                                       uint32_t* keys_b, uint32_t* pts_b, int level) {
     constexpr int ACC = Words29<F29T>::ACC;
-    uint32_t T = T_fixed;
-    if (plan) {
-        T = plan[PLAN_T];
-        for (int k = 0; k < level; ++k) T = (T + 63u) >> 6;
+    uint32_t T = plan[PLAN_T];
+    if (T <= 1) return;                            // nothing to combine: the accumulation wrote the buckets itself
+    const uint32_t lane = threadIdx.x;
+    const uint32_t wv = blockIdx.x;
+    const uint32_t* in_keys = keys_a;
+    const uint32_t* in_pts = pts_a;
+    uint32_t out_rec = 0;                          // first record of this level's output region
+    for (int k = 0; k < level; ++k) {
+        if (T <= 64) return;
+        const uint32_t W = (T + 63u) >> 6;
+        in_keys = keys_b + out_rec;
+        in_pts = pts_b + (size_t)out_rec * ACC;
+        out_rec += 2u * W;
+        T = W;
     }
-    if (T <= 1) return;                            // nothing left to combine: the level below wrote the buckets itself
-    const uint32_t lane = threadIdx.x, wv = blockIdx.x, t = wv * 64u + lane;
     if (wv * 64u >= T) return;
-    const bool final_level = T <= 64;
-    uint32_t kF = NO_KEY, kL = NO_KEY;
-    XYZZ29<F29T> A, B;
-    bool Ainf = true, Binf = true;
-    if (t < T) {
-        kF = in_keys[2 * t];
-        kL = in_keys[2 * t + 1];
-        Ainf = load_acc(in_pts + (size_t)(2 * t) * ACC, A);
-        Binf = load_acc(in_pts + (size_t)(2 * t + 1) * ACC, B);
-    }
-    const bool single = kF == kL;                 // one run covers the segment: F carries it, L is empty
-    // C = the run still open at the right end of this segment
-    XYZZ29<F29T> Cv = single ? A : B;
-    bool Cinf = single ? Ainf : Binf;
-    if (single && !Binf) add29(Cv, Cinf, B, Binf);
-    const uint32_t kPrev = (uint32_t)__shfl_up((int)kL, 1, 64);
-    const bool joinL = lane > 0 && kPrev == kF;   // the run open at the end of the lane to the left continues here
-    bool f = single && joinL;                     // ... and runs on through this whole segment
-    if (__ballot(f)) {
-        for (unsigned d = 1; d < 64; d <<= 1) {   // segmented inclusive scan of C; f true at step d implies lane >= d
-            XYZZ29<F29T> Cu = shfl_up_acc(Cv, d);
-            const bool Cuinf = __shfl_up((int)Cinf, d, 64) != 0;
-            const bool fu = __shfl_up((int)f, d, 64) != 0;
-            if (f) add29(Cv, Cinf, Cu, Cuinf);
-            f = f && fu;
+    {
+        const uint32_t t = wv * 64u + lane;
+        const bool final_level = T <= 64;
+        uint32_t* out_keys = keys_b + out_rec;
+        uint32_t* out_pts = pts_b + (size_t)out_rec * ACC;
+        uint32_t kF = NO_KEY, kL = NO_KEY;
+        XYZZ29<F29T> A, B;
+        bool Ainf = true, Binf = true;
+        if (t < T) {
+            kF = in_keys[2 * t];
+            kL = in_keys[2 * t + 1];
+            Ainf = load_acc(in_pts + (size_t)(2 * t) * ACC, A);
+            Binf = load_acc(in_pts + (size_t)(2 * t + 1) * ACC, B);
         }
-    }
-    XYZZ29<F29T> Pv = shfl_up_acc(Cv, 1);         // the open run of the lane to the left, after the scan
-    const bool Pinf = __shfl_up((int)Cinf, 1, 64) != 0;
-    // lanes 0..j all single and chained <=> the run open at the end of lane j started at or before the wave's left edge
-    const unsigned long long chain = __ballot(single && (lane == 0 || joinL));
-    auto open_left = [&](unsigned j) { return (~chain & (j >= 63 ? ~0ull : ((2ull << j) - 1ull))) == 0ull; };
-    auto emit = [&](uint32_t key, const XYZZ29<F29T>& v, bool vinf, bool touches_left) {
-        if (key == NO_KEY) return;
-        if (touches_left && !final_level) {
-            out_keys[2 * wv] = key;
-            store_acc(out_pts + (size_t)(2 * wv) * ACC, v, vinf);
-        } else {
-            store_acc(bucket_sums + (size_t)key * ACC, v, vinf);
+        const bool single = kF == kL;                 // one run covers the segment: F carries it, L is empty
+        // C = the run still open at the right end of this segment
+        XYZZ29<F29T> Cv = single ? A : B;
+        bool Cinf = single ? Ainf : Binf;
+        if (single && !Binf) add29(Cv, Cinf, B, Binf);
+        const uint32_t kPrev = (uint32_t)__shfl_up((int)kL, 1, 64);
+        const bool joinL = lane > 0 && kPrev == kF;   // the run open at the end of the lane to the left continues here
+        bool f = single && joinL;                     // ... and runs on through this whole segment
+        if (__ballot(f)) {
+            for (unsigned d = 1; d < 64; d <<= 1) {   // segmented inclusive scan of C; f true at step d implies lane >= d
+                XYZZ29<F29T> Cu = shfl_up_acc(Cv, d);
+                const bool Cuinf = __shfl_up((int)Cinf, d, 64) != 0;
+                const bool fu = __shfl_up((int)f, d, 64) != 0;
+                if (f) add29(Cv, Cinf, Cu, Cuinf);
+                f = f && fu;
+            }
         }
-    };
-    if (lane > 0 && !joinL) emit(kPrev, Pv, Pinf, open_left(lane - 1));      // the left neighbour's open run ends at the boundary
-    if (!single) {                                                           // this segment's first run ends inside it
-        XYZZ29<F29T> H = A;
-        bool Hinf = Ainf, left = lane == 0;
-        if (joinL) { add29(H, Hinf, Pv, Pinf); left = open_left(lane - 1); }
-        emit(kF, H, Hinf, left);
-    }
-    if (lane == 63) {                                                        // the run open at the wave's right edge
-        if (final_level) {
-            emit(kL, Cv, Cinf, false);
-        } else if (open_left(63)) {                                          // the whole wave is one run
-            emit(kL, Cv, Cinf, true);
-            out_keys[2 * wv + 1] = kL;
-            store_acc(out_pts + (size_t)(2 * wv + 1) * ACC, Cv, true);
-        } else {
-            out_keys[2 * wv + 1] = kL;
-            store_acc(out_pts + (size_t)(2 * wv + 1) * ACC, Cv, Cinf);
+        XYZZ29<F29T> Pv = shfl_up_acc(Cv, 1);         // the open run of the lane to the left, after the scan
+        const bool Pinf = __shfl_up((int)Cinf, 1, 64) != 0;
+        // lanes 0..j all single and chained <=> the run open at the end of lane j started at or before the wave's left edge
+        const unsigned long long chain = __ballot(single && (lane == 0 || joinL));
+        auto open_left = [&](unsigned j) { return (~chain & (j >= 63 ? ~0ull : ((2ull << j) - 1ull))) == 0ull; };
+        auto emit = [&](uint32_t key, const XYZZ29<F29T>& v, bool vinf, bool touches_left) {
+            if (key == NO_KEY) return;
+            if (touches_left && !final_level) {
+                out_keys[2 * wv] = key;
+                store_acc(out_pts + (size_t)(2 * wv) * ACC, v, vinf);
+            } else {
+                store_acc(bucket_sums + (size_t)key * ACC, v, vinf);
+            }
+        };
+        if (lane > 0 && !joinL) emit(kPrev, Pv, Pinf, open_left(lane - 1));      // the left neighbour's open run ends at the boundary
+        if (!single) {                                                           // this segment's first run ends inside it
+            XYZZ29<F29T> H = A;
+            bool Hinf = Ainf, left = lane == 0;
+            if (joinL) { add29(H, Hinf, Pv, Pinf); left = open_left(lane - 1); }
+            emit(kF, H, Hinf, left);
+        }
+        if (lane == 63) {                                                        // the run open at the wave's right edge
+            if (final_level) {
+                emit(kL, Cv, Cinf, false);
+            } else if (open_left(63)) {                                          // the whole wave is one run
+                emit(kL, Cv, Cinf, true);
+                out_keys[2 * wv + 1] = kL;
+                store_acc(out_pts + (size_t)(2 * wv + 1) * ACC, Cv, true);
+            } else {
+                out_keys[2 * wv + 1] = kL;
+                store_acc(out_pts + (size_t)(2 * wv + 1) * ACC, Cv, Cinf);
+            }
         }
     }
 }
@@ -1146,38 +1194,48 @@ __global__ void __launch_bounds__(256) k_bucket_rows_cols(const uint32_t* __rest
 // tree levels (1.6 - 2.1 wave-additions per 64 buckets against 1.03 here).  Column lanes of a wave read adjacent
 // buckets; row lanes read RED_CHUNK buckets apart (the kernel is bound by the 3000-instruction additions, not by HBM).
 static constexpr uint32_t RED_CHUNK = 32;
+// One WAVE per RED_CHUNK x RED_CHUNK tile of the bucket matrix: lanes 0..31 add up the tile's rows (-> rowp[r][tile column]),
+// lanes 32..63 its columns (-> colp[tile row][col]).  Both halves have read the whole tile when the loop ends, and nobody
+// else reads it, so the wave then ZEROES the tile (zero_after): the bucket array is left empty for the next MSM and the
+// fill launch that opened every accumulation is gone.
 template <class F29T>
-__global__ void __launch_bounds__(64) k_bucket_chunks(const uint32_t* __restrict__ buckets, uint32_t R, uint32_t C,
-                                                      uint32_t* __restrict__ rowp, uint32_t* __restrict__ colp) {
+__global__ void __launch_bounds__(64) k_bucket_chunks(uint32_t* __restrict__ buckets, uint32_t R, uint32_t C,
+                                                      uint32_t* __restrict__ rowp, uint32_t* __restrict__ colp, int zero_after) {
     constexpr int ACC = Words29<F29T>::ACC;
     const uint32_t w = blockIdx.y;
     const uint32_t KC = (C + RED_CHUNK - 1) / RED_CHUNK, KR = (R + RED_CHUNK - 1) / RED_CHUNK;
-    const uint32_t n_row = (R * KC + 63u) & ~63u;                 // a wave holds row lanes or column lanes, not both
-    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
-    const uint32_t* src = buckets + (size_t)w * R * C * ACC;
+    const uint32_t tile = blockIdx.x;
+    if (tile >= KR * KC) return;
+    const uint32_t tr = tile / KC, tc = tile - tr * KC;
+    const uint32_t lane = threadIdx.x, i = lane & 31u;
+    const bool row_lane = lane < 32u;
+    uint32_t* src = buckets + (size_t)w * R * C * ACC;
+    const uint32_t r0 = tr * RED_CHUNK, c0 = tc * RED_CHUNK;
+    const uint32_t nr = R - r0 < RED_CHUNK ? R - r0 : RED_CHUNK, nc = C - c0 < RED_CHUNK ? C - c0 : RED_CHUNK;
     XYZZ29<F29T> acc;
     bool inf = true;
-    if (t < n_row) {
-        if (t >= R * KC) return;
-        const uint32_t r = t / KC, k = t - r * KC;
-        const uint32_t c0 = k * RED_CHUNK, c1 = c0 + RED_CHUNK < C ? c0 + RED_CHUNK : C;
-        for (uint32_t col = c0; col < c1; ++col) {
+    const bool live = row_lane ? i < nr : i < nc;
+    const uint32_t steps = row_lane ? nc : nr;
+    for (uint32_t s = 0; s < RED_CHUNK; ++s) {
+        if (live && s < steps) {
+            const uint32_t r = row_lane ? r0 + i : r0 + s, col = row_lane ? c0 + s : c0 + i;
             XYZZ29<F29T> q;
             bool qinf = load_acc(src + ((size_t)r * C + col) * ACC, q);
             add29(acc, inf, q, qinf);
         }
-        store_acc(rowp + ((size_t)w * R * KC + t) * ACC, acc, inf);
-    } else {
-        const uint32_t u = t - n_row;
-        if (u >= KR * C) return;
-        const uint32_t k = u / C, col = u - k * C;
-        const uint32_t r0 = k * RED_CHUNK, r1 = r0 + RED_CHUNK < R ? r0 + RED_CHUNK : R;
-        for (uint32_t r = r0; r < r1; ++r) {
-            XYZZ29<F29T> q;
-            bool qinf = load_acc(src + ((size_t)r * C + col) * ACC, q);
-            add29(acc, inf, q, qinf);
+    }
+    if (live) {
+        if (row_lane) store_acc(rowp + ((size_t)w * R * KC + (size_t)(r0 + i) * KC + tc) * ACC, acc, inf);
+        else store_acc(colp + ((size_t)w * KR * C + (size_t)tr * C + (c0 + i)) * ACC, acc, inf);
+    }
+    if (zero_after) {
+        // every load of the tile above has returned (its value fed an addition); rows of the tile are nc * ACC contiguous words
+        static_assert(ACC % 4 == 0, "accumulator records are whole uint4s");
+        const uint32_t row_vecs = nc * (ACC / 4);
+        for (uint32_t r = 0; r < nr; ++r) {
+            uint4* dst = reinterpret_cast<uint4*>(src + ((size_t)(r0 + r) * C + c0) * ACC);
+            for (uint32_t k = lane; k < row_vecs; k += 64u) dst[k] = make_uint4(0u, 0u, 0u, 0u);
         }
-        store_acc(colp + ((size_t)w * KR * C + u) * ACC, acc, inf);
     }
 }
 // Row_r = Σ_k rowp[r][k] (KC chunks), Col_col = Σ_k colp[k][col] (KR chunks): one lane each
@@ -1216,14 +1274,24 @@ __global__ void __launch_bounds__(64) k_bucket_chunk_sums(const uint32_t* __rest
 // block b < rbits: Σ_{r: bit b of r} Row_r;  block rbits + k: Σ_{col: bit k of (col + 1)} Col_col;  blockIdx.y = window
 // `out` and `plan_out` are HOST memory (PinnedBuf::dev): the MSM's last kernel hands its few KB of per-bit sums and the
 // plan's statistics straight to the host.
+// zero_words != 0 (engines whose MSMs follow each other on one stream): this being the MSM's last kernel, it also leaves the
+// partition counters (`plan`, zero_words words: plan | histograms | cursors) zeroed for the next MSM - the fill launch that
+// opened every MSM before.
 template <class F29T>
 __global__ void __launch_bounds__(256) k_bit_sums(const uint32_t* __restrict__ rows, uint32_t R, uint32_t rbits,
                                                   const uint32_t* __restrict__ cols, uint32_t C, uint32_t* __restrict__ out,
-                                                  const uint32_t* __restrict__ plan, uint32_t* __restrict__ plan_out) {
+                                                  uint32_t* plan, uint32_t* __restrict__ plan_out, uint32_t zero_words) {
     constexpr int ACC = Words29<F29T>::ACC;
     extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
     const uint32_t w = blockIdx.y, b = blockIdx.x;
-    if (w == 0 && b == 0 && threadIdx.x < PLAN_WORDS) plan_out[threadIdx.x] = plan[threadIdx.x];
+    if (w == 0 && b == 0 && threadIdx.x < PLAN_WORDS) {
+        plan_out[threadIdx.x] = plan[threadIdx.x];
+        if (zero_words) plan[threadIdx.x] = 0;
+    }
+    if (zero_words) {
+        const uint32_t nthr = gridDim.x * gridDim.y * blockDim.x, me = (w * gridDim.x + b) * blockDim.x + threadIdx.x;
+        for (uint32_t k = PLAN_WORDS + me; k < zero_words; k += nthr) plan[k] = 0;
+    }
     const bool is_row = b < rbits;
     const uint32_t bit = is_row ? b : b - rbits, n = is_row ? R : C, offset = is_row ? 0u : 1u;
     const uint32_t* src = is_row ? rows + (size_t)w * R * ACC : cols + (size_t)w * C * ACC;
@@ -1253,8 +1321,12 @@ static constexpr uint32_t ACC_TARGET_THREADS = 256u * 4u * 4u * 64u;  // CUs x S
 static constexpr uint32_t ACC_TARGET_PAIRS = 256u * 4u * CG_G2PAIR_RESIDENT_WAVES * 64u / 2u;
 // segments of one fully resident round of the engine's accumulation kernel
 template <class F29T> static uint32_t acc_target_segments(bool latency_mode) {
-    if (Words29<F29T>::NF != 2) return ACC_TARGET_THREADS;
-    return g2_pair_kernel(latency_mode) ? ACC_TARGET_PAIRS : ACC_TARGET_THREADS;
+    // CG_ACC_QUARTERS (tuning aid, throughput contexts): lanes of the largest accumulation launch in quarters of a resident
+    // round - 3 leaves one wave slot per SIMD to whatever else is in flight, 8 is two rounds
+    static const uint32_t quarters = [] { const char* e = getenv("CG_ACC_QUARTERS"); const int v = e ? atoi(e) : 4; return (uint32_t)(v >= 1 && v <= 16 ? v : 4); }();
+    const uint32_t full = latency_mode ? ACC_TARGET_THREADS : ACC_TARGET_THREADS / 4u * quarters;
+    if (Words29<F29T>::NF != 2) return full;
+    return g2_pair_kernel(latency_mode) ? ACC_TARGET_PAIRS : full;
 }
 // shortest segment.  Throughput: 64 - fewer, longer lanes for the small MSMs, whose pieces cost a wave-wide addition
 // each to combine (they run beside the h MSM, which fills the chip).  Latency (a shard of one proof): 16.
@@ -1302,7 +1374,9 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
     uint64_t t1 = (cap_entries + min_L - 1) / min_L;
     if (t1 > acc_target_segments<F29T>(latency_mode)) t1 = acc_target_segments<F29T>(latency_mode);
     max_segments = (uint32_t)t1;
-    const uint64_t pa = 2 * t1, pb = 2 * ceil_div(t1, 64);   // two pieces per segment, then two per wave of 64 segments
+    // two pieces per segment; then two per wave of every combine level, the levels' regions one after another
+    uint64_t pa = 2 * t1, pb = 0;
+    for (uint64_t w = ceil_div(t1, 64); ; w = ceil_div(w, 64)) { pb += 2 * w; if (w <= 1) break; }
     mem().reserve(cap_entries, bits2 ? cap_entries : 1, pa, pa * ACC, pb, pb * ACC);
     const uint32_t wins = b->precomputed ? 1u : (uint32_t)W;
     {
@@ -1347,6 +1421,11 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
         ba_plan.alloc((size_t)(ba_rounds + 1) * BAP_WORDS + PLAN_WORDS);
     }
 #endif
+    // both start out zeroed (load time: a synchronous memset); per MSM they are either re-zeroed by the MSM's own last
+    // kernels (zero_at_end) or filled at its start
+    CG_HIP(hipMemset(counters.p, 0, counters.bytes()));
+    CG_HIP(hipMemset(bucket_sums.p, 0, bucket_sums.bytes()));
+    counters_clean = buckets_clean = true;
     h_plan.alloc(PLAN_WORDS);
     for (int k = 0; k < PLAN_WORDS; ++k) h_plan.p[k] = 0;
     h_result.alloc((size_t)wins * (red_rbits + red_cbits1) * ACC);   // per window: the per-bit sums of rows, then of columns
@@ -1389,7 +1468,8 @@ void MsmEngine<F>::digits(const Fr* scalars_dev, uint64_t n, hipStream_t st) {
     for (int k = 0; k < PLAN_WORDS; ++k) h_plan.p[k] = 0;
     CG_HIP(hipEventRecord(ev_t[0], st));
     if (!n) {   // the reduction's last kernel copies the device plan to the host: leave it a zeroed one
-        fill_zero(counters.p, PLAN_WORDS * 4, st);
+        if (!counters_clean) fill_zero(counters.p, (counters.bytes() + 15) & ~(size_t)15, st);
+        counters_clean = zero_at_end;     // what accumulate()'s last kernel leaves behind
         return;
     }
     const uint32_t B1 = 1u << bits1;
@@ -1407,10 +1487,23 @@ void MsmEngine<F>::digits(const Fr* scalars_dev, uint64_t n, hipStream_t st) {
     sh.staged = latency_mode ? 1 : 0;
     const uint32_t tiles = ceil_div(n, PART_TILE);
     CG_HIP(hipEventRecord(ev_t[1], st));
-    fill_zero(counters.p, (counters.bytes() + 15) & ~(size_t)15, st);
-    launch_part_level1(true, sh, tiles, (size_t)B1 * 4, st, scalars_dev, bases->valid.p, blk_hist.p, hist1, plan, nullptr, nullptr, nullptr);
-    CG_KERNEL_CHECK();
-    k_part_plan<<<1, 1024, (size_t)B1 * 4, st>>>(bits1, bits2 ? 1 : 0, hist1, start1, chunk0, plan, acc_target_segments<F29T>(latency_mode), min_L);
+    // the partition counters are zero when the MSM starts: left so by the last kernel of this engine's previous MSM
+    // (one-stream engines, zero_at_end) or filled here
+    if (!counters_clean) fill_zero(counters.p, (counters.bytes() + 15) & ~(size_t)15, st);
+    counters_clean = false;
+    PlanArgs pa;
+    pa.start1 = start1; pa.chunk0 = chunk0; pa.target_threads = acc_target_segments<F29T>(latency_mode); pa.min_L = min_L;
+    pa.two_level = bits2 ? 1 : 0;
+    static const bool plan_launch = getenv("CG_PLAN_LAUNCH") != nullptr && getenv("CG_PLAN_LAUNCH")[0] == '1';
+    if (plan_launch) {
+        PlanArgs none = pa;
+        none.start1 = nullptr;
+        launch_part_level1(true, sh, tiles, (size_t)B1 * 4, st, scalars_dev, bases->valid.p, blk_hist.p, hist1, plan, nullptr, nullptr, nullptr, none);
+        CG_KERNEL_CHECK();
+        k_part_plan<<<1, 1024, (size_t)B1 * 4, st>>>(bits1, pa, hist1, plan);
+    } else {
+        launch_part_level1(true, sh, tiles, (size_t)B1 * 4, st, scalars_dev, bases->valid.p, blk_hist.p, hist1, plan, nullptr, nullptr, nullptr, pa);
+    }
     CG_KERNEL_CHECK();
     launch_part_level1(false, sh, tiles, (size_t)B1 * 4, st, scalars_dev, bases->valid.p, blk_hist.p, nullptr, nullptr, start1, cur1, mem().ent_a.p);
     CG_KERNEL_CHECK();
@@ -1433,8 +1526,8 @@ void MsmEngine<F>::adopt(const uint64_t* grouped_entries, const uint32_t* plan_d
     CG_HIP(hipEventRecord(ev_t[1], st));
     // the plan (entry count, segment geometry, statistics) travels with the entries; everything downstream reads it from
     // this engine's own counters as usual
-    CG_HIP(hipMemcpyAsync(counters.p, plan_dev, PLAN_WORDS * 4, hipMemcpyDeviceToDevice, st));
-    k_replan<<<1, 1, 0, st>>>(counters.p, acc_target_segments<F29T>(latency_mode), min_L);
+    k_replan<<<1, 1, 0, st>>>(counters.p, plan_dev, acc_target_segments<F29T>(latency_mode), min_L);
+    counters_clean = false;
     CG_KERNEL_CHECK();
     CG_HIP(hipEventRecord(ev_t[2], st));
     adopted = n ? grouped_entries : nullptr;
@@ -1444,7 +1537,10 @@ void MsmEngine<F>::adopt(const uint64_t* grouped_entries, const uint32_t* plan_d
 // and the plan (entry count, statistics) are copied to pinned memory.  Nothing here waits for the host.
 template <class F>
 void MsmEngine<F>::accumulate(hipStream_t st) {
-    fill_zero(bucket_sums.p, bucket_sums.bytes(), st);
+    // the bucket array is empty when the accumulation starts: left so by the reduction of this engine's previous MSM
+    // (k_bucket_chunks, zero_at_end) or filled here
+    if (!buckets_clean) fill_zero(bucket_sums.p, bucket_sums.bytes(), st);
+    buckets_clean = false;
     if (n_scalars) {
         const uint32_t* plan = counters.p;
         const uint64_t* grouped = adopted ? adopted : this->grouped();
@@ -1489,19 +1585,15 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
         CG_HIP(hipEventRecord(ev_t[4], st));
         // combine the segments' pieces wave by wave until one wave covers them all (k_combine_wave); the grids cover the
         // largest plan this engine can see, waves beyond the actual one return at once
-        bool from_a = true;
-        uint32_t segs = max_segments;
-        for (int level = 0; segs > 1; ++level) {
-            const uint32_t waves = ceil_div(segs, 64u);
+        if (max_segments > 1) {
             MsmScratch& S = mem();
-            const uint32_t* ik = from_a ? S.part_keys_a.p : S.part_keys_b.p;
-            const uint32_t* ip = from_a ? S.part_pts_a.p : S.part_pts_b.p;
-            uint32_t* ok = from_a ? S.part_keys_b.p : S.part_keys_a.p;
-            uint32_t* op = from_a ? S.part_pts_b.p : S.part_pts_a.p;
-            k_combine_wave<F29T><<<waves, 64, 0, st>>>(ik, ip, plan, level, 0u, bucket_sums.p, ok, op);
-            CG_KERNEL_CHECK();
-            segs = waves;
-            from_a = !from_a;
+            uint32_t segs = max_segments;
+            for (int level = 0; segs > 1; ++level) {
+                const uint32_t waves = ceil_div(segs, 64u);
+                k_combine_wave<F29T><<<waves, 64, 0, st>>>(S.part_keys_a.p, S.part_pts_a.p, plan, bucket_sums.p, S.part_keys_b.p, S.part_pts_b.p, level);
+                CG_KERNEL_CHECK();
+                segs = waves;
+            }
         }
     }
     // bucket reduction (see the comment above block_tree_sum): two launches, the second writing the per-bit sums to host memory, of a fixed
@@ -1528,16 +1620,18 @@ void MsmEngine<F>::enqueue_reduction(hipStream_t st) {
         CG_KERNEL_CHECK();
     } else {                     // a lane per chunk of 32 buckets, then a lane per row / column: fewest additions
         const uint32_t KC = ceil_div(C, RED_CHUNK), KR = ceil_div(R, RED_CHUNK);
-        const uint32_t lanes_a = ((R * KC + 63u) & ~63u) + KR * C, lanes_b = ((R + 63u) & ~63u) + C;
-        k_bucket_chunks<F29T><<<dim3(ceil_div(lanes_a, 64), wins), 64, 0, st>>>(bucket_sums.p, R, C, rowp_buf.p, colp_buf.p);
+        const uint32_t lanes_b = ((R + 63u) & ~63u) + C;
+        k_bucket_chunks<F29T><<<dim3(KR * KC, wins), 64, 0, st>>>(bucket_sums.p, R, C, rowp_buf.p, colp_buf.p, zero_at_end ? 1 : 0);
         CG_KERNEL_CHECK();
+        buckets_clean = zero_at_end;
         k_bucket_chunk_sums<F29T><<<dim3(ceil_div(lanes_b, 64), wins), 64, 0, st>>>(rowp_buf.p, colp_buf.p, R, C, rows_buf.p, cols_buf.p);
         CG_KERNEL_CHECK();
     }
     const uint32_t nbits = (uint32_t)(red_rbits + red_cbits1);
     k_bit_sums<F29T><<<dim3(nbits, wins), 256, lds, st>>>(rows_buf.p, R, (uint32_t)red_rbits, cols_buf.p, C, h_result.dev(), counters.p,
-                                                          h_plan.dev());
+                                                          h_plan.dev(), zero_at_end ? (uint32_t)counters.n : 0u);
     CG_KERNEL_CHECK();
+    counters_clean = zero_at_end;
 }
 
 // ---- host: lazy 29-bit accumulator -> saturated Montgomery(2^256) XYZZ ---------------------------------

@@ -91,6 +91,13 @@ struct MsmEngine {
     PinnedBuf<uint32_t> h_plan;       // the device plan of the last MSM: [0] entries, [3] scalars with a non-zero digit
     PinnedBuf<uint32_t> h_result;     // per window: red_rbits + red_cbits1 per-bit sums of the rows / the columns
     uint64_t n_scalars = 0;
+    // set before init() for engines whose MSMs follow each other on ONE stream: the MSM's last kernels leave the partition
+    // counters and the bucket array zeroed for the next MSM, and the two fill launches that opened an MSM are skipped.
+    // (With an MSM spread over several streams another engine may still be reading this one's plan - MsmEngine::adopt - when
+    // its last kernel runs, so those engines fill at the start.)  The *_clean flags say whether the invariant holds: an MSM
+    // that was abandoned half-way (a failed call) leaves them false and the next MSM fills.
+    bool zero_at_end = false;
+    bool counters_clean = false, buckets_clean = false;
     bool latency_mode = false;        // set before init(): short segments (one proof at a time matters more than proofs per second)
 #ifdef CG_WITH_BATCH_AFFINE
     // batch-affine pair rounds in front of the accumulation (batchaff.hpp; G1 only; 0 = off)

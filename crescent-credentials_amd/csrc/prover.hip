@@ -514,7 +514,11 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
 #ifdef CG_WITH_BATCH_AFFINE
             if (getenv("CG_BA_H_ONLY")) sl->el.ba_allowed = sl->ea.ba_allowed = sl->eb1.ba_allowed = false;   // experiment switch
 #endif
-            if (serial) sl->eh.shared_mem = sl->el.shared_mem = sl->ea.shared_mem = sl->eb1.shared_mem = sl->eb2.shared_mem = &sl->scratch;
+            if (serial) {
+                sl->eh.shared_mem = sl->el.shared_mem = sl->ea.shared_mem = sl->eb1.shared_mem = sl->eb2.shared_mem = &sl->scratch;
+                const bool zero_at_end = !(getenv("CG_NO_ZERO_AT_END") && getenv("CG_NO_ZERO_AT_END")[0] == '1');     // A/B aid
+                sl->eh.zero_at_end = sl->el.zero_at_end = sl->ea.zero_at_end = sl->eb1.zero_at_end = sl->eb2.zero_at_end = zero_at_end;
+            }
             sl->eh.init(&c->bh); sl->el.init(&c->bl); sl->ea.init(&c->ba); sl->eb1.init(&c->bb1); sl->eb2.init(&c->bb2);
             sl->h_canon.alloc(D);
             sl->wm.alloc(M, D, std::max(c->A.sell_scratch, std::max(c->B.sell_scratch, c->C.sell_scratch)));

@@ -180,8 +180,10 @@ __device__ __forceinline__ bool fr_lt_modulus(const Fr& x) {
 }
 
 // ---- witness -> R' form; sparse products --------------------------------------------------------------------
+// Also places the instance wires behind A's rows (a[m + i] = w_i, r1cs_to_qap.rs:173-177) at the bit-reversed index the
+// first transform wants: `va` must have been zeroed before this kernel and is written below row m + l by nothing else.
 __global__ void __launch_bounds__(256) k_w_to29(const Fr* __restrict__ w, uint32_t* __restrict__ out, uint64_t n,
-                                                uint32_t* __restrict__ bad_input) {
+                                                uint32_t* __restrict__ bad_input, uint32_t* __restrict__ va, uint64_t m, uint64_t l, int logn) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fr x = w[i];
@@ -189,8 +191,11 @@ __global__ void __launch_bounds__(256) k_w_to29(const Fr* __restrict__ w, uint32
     if (!fr_lt_modulus(x)) *bad_input = 1u;
     // x·R' as the product leaves it: normalised and below 2N (x < 2^256, R'^2 mod N < N), which is all the packed form
     // and the sparse product's lazy sums ask for; the canonical representative would cost a second product
-    store_packed29(out, i, mul(unpack29<Fr29P>(x.l), Fr29::from_limbs(Fr29P::R2)));
+    const Fr29 v = mul(unpack29<Fr29P>(x.l), Fr29::from_limbs(Fr29P::R2));
+    store_packed29(out, i, v);
+    if (i < l) store_packed29(va, brev((uint32_t)(m + i), logn), v);
 }
+
 
 // out[rev(i)] = <M_i, w>, i < rows  (evaluate_constraint, r1cs_to_qap.rs:16-45); the output vector is the
 // bit-reversed input the first transform wants.
@@ -218,15 +223,6 @@ __global__ void __launch_bounds__(256) k_sell29(const uint32_t* __restrict__ sli
     const Fr29 r = weak_reduce(normalize(acc));     // below 3N: fits the packed form; nothing downstream needs the canonical value
     if (d & SELL_FINAL) store_packed29(out, brev(d & ~SELL_FINAL, logn), r);
     else store_packed29(scratch, d, r);
-}
-// rows m .. m+l of `a` hold the instance assignment (r1cs_to_qap.rs:173-177)
-__global__ void k_place_inputs29(const uint32_t* __restrict__ w29, uint32_t* __restrict__ out, uint64_t m, uint64_t l, int logn) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= l) return;
-    const uint4* s = reinterpret_cast<const uint4*>(w29 + i * 8);
-    uint4* d = reinterpret_cast<uint4*>(out + (uint64_t)brev((uint32_t)(m + i), logn) * 8);
-    d[0] = s[0];
-    d[1] = s[1];
 }
 
 // ---- LDS pass ---------------------------------------------------------------------------------------------------
@@ -432,14 +428,15 @@ void wm29_run(const Wm29Domain& dom, const DevCsr& A, const DevCsr& B, const Dev
     const int logn = dom.logn;
     // the flag is HOST memory the kernel writes only when it meets a non-canonical element: no memset, no copy back
     buf.h_bad_input.p[0] = 0;
-    k_w_to29<<<ceil_div(M, 256), 256, 0, st>>>(w_canon, buf.w29.p, M, buf.h_bad_input.dev());
-    CG_KERNEL_CHECK();
     uint32_t* v[3] = {buf.va.p, buf.vb.p, buf.vc.p};
+    fill_zero(v[0], D * 32, st);
+    k_w_to29<<<ceil_div(M, 256), 256, 0, st>>>(w_canon, buf.w29.p, M, buf.h_bad_input.dev(), buf.va.p, m, l, logn);
+    CG_KERNEL_CHECK();
     const DevCsr* mats[3] = {&A, &B, &C};
     const Csr29* dicts[3] = {&dA, &dB, &dC};
     const int nvec = coset_values ? 2 : 3;       // c's share of the quotient lives in the folded l query
     for (int k = 0; k < nvec; ++k) {
-        fill_zero(v[k], D * 32, st);
+        if (k) fill_zero(v[k], D * 32, st);
         const uint32_t* src = buf.w29.p;
         for (int lv = 0; lv < mats[k]->n_sell; ++lv) {
             const SellLevel& L = mats[k]->sell[lv];
@@ -453,8 +450,6 @@ void wm29_run(const Wm29Domain& dom, const DevCsr& A, const DevCsr& B, const Dev
             src = scratch;
         }
     }
-    k_place_inputs29<<<ceil_div(l, 256), 256, 0, st>>>(buf.w29.p, buf.va.p, m, l, logn);
-    CG_KERNEL_CHECK();
     if (coset_values && strided) {
         // a shard's own coset points only (Wm29Strided): two transforms of size D, two of size d
         const Wm29Strided& S = *strided;
