@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 export CG_SERIAL_STREAMS=1
 export CG_LATENCY_MODE=0   # the segment length of the pipelined run (a one-slot context would pick the latency setting)
 cd /tmp
-FLAGS="--steps 6 --warmup 2 --blocks 1 --no-sweep --no-cpu-baseline --no-host-witness --no-clock-probe --inflight 1 $*"
+FLAGS="--steps 6 --warmup 2 --blocks 1 --no-sweep --no-cpu-baseline --no-host-witness --no-check --no-clock-probe --inflight 1 $*"
 for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
   rocprofv3 --pmc $C -d "$OUT/$C" -o p -- python3 "$ROOT/bench.py" $FLAGS > "$OUT/$C.line.json" 2> "$OUT/$C.log"
 done

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 export CG_SERIAL_STREAMS=1
 export CG_LATENCY_MODE=0
 cd /tmp
-FLAGS="--steps 4 --warmup 2 --blocks 1 --no-sweep --no-cpu-baseline --no-host-witness --no-clock-probe --inflight 1 $*"
+FLAGS="--steps 4 --warmup 2 --blocks 1 --no-sweep --no-cpu-baseline --no-host-witness --no-check --no-clock-probe --inflight 1 $*"
 i=0
 : > "$OUT/sq_counters.md"
 echo "SQ counters per launch (steady state), serial streams, one proof in flight: \`CG_SERIAL_STREAMS=1 CG_LATENCY_MODE=0 rocprofv3 --pmc <set> -- python3 bench.py $FLAGS\` (one pass per set), summarised by tools/rocpd_counters.py" >> "$OUT/sq_counters.md"
