@@ -78,7 +78,9 @@ def parse():
     ap.add_argument("--no-host-witness", action="store_true", help="skip the host-witness (cg_prove) sub-record")
     ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the sharded-proof sub-record")
     ap.add_argument("--sharded-steps", type=int, default=20, help="N > 1: sharded proofs timed one at a time (latency)")
-    ap.add_argument("--sharded-inflight", type=int, default=4, help="N > 1: sharded proofs kept in flight per rank in the pipelined leg")
+    ap.add_argument("--sharded-inflight", type=int, default=8,
+                    help="N > 1: sharded proofs kept in flight per rank in the pipelined leg (two ranks on one GPU: 142.5 proofs/s with "
+                         "4, 159.0 with 8, against 116.5 one at a time and 196 for replicas: profiles/r04_h_*, r04_i_sharded_inflight8.txt)")
     ap.add_argument("--sharded-stream", type=int, default=160, help="N > 1: sharded proofs of the pipelined leg")
     ap.add_argument("--rccl-deadline", type=float, default=90.0,
                     help="N > 1: seconds the RCCL data group may take to come up (creation + first all_gather) before the sharded leg "

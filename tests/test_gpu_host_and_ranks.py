@@ -409,7 +409,7 @@ def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
     assert sh["all_gathers"] == sh["proofs"] == 6 and set(sh["ms_breakdown_rank0"]) == {"partial", "gather", "assemble"}
     assert "error" not in sh and "backend_fallback" not in sh
     fl = sh["in_flight"]
-    assert fl["proofs_in_flight"] == 4 and fl["all_gathers"] == fl["proofs"] and fl["bytes_identical_to_unsharded"] is True
+    assert fl["proofs_in_flight"] == 8 and fl["all_gathers"] == fl["proofs"] and fl["bytes_identical_to_unsharded"] is True
     assert fl["proofs_per_s"] > 0
     assert len(d["value_per_rank"]) == 2 and abs(sum(d["value_per_rank"]) - d["value"]) < 0.35 * d["value"]
     assert d["proof_verifies"] is True and d["key_check"]["ok"] is True and d["key_check"]["proof_equals_trapdoor_closed_form"] is True
