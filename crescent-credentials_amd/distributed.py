@@ -99,7 +99,14 @@ def open_data_group(device, backend: str = "nccl", deadline_s: float = 90.0):
     def attempt():
         try:
             torch.cuda.set_device(device)        # a new thread starts on device 0, whatever the main thread chose
-            g = dist.new_group(backend=backend, device_id=device) if backend == "nccl" else dist.new_group(backend=backend)
+            g = None
+            if backend == "nccl":
+                try:        # bound to this rank's device: the communicator is made here, not at the first collective
+                    g = dist.new_group(backend=backend, device_id=device)
+                except (TypeError, ValueError):
+                    g = None
+            if g is None:   # (a torch whose new_group takes no device_id, or refuses one under a gloo default group)
+                g = dist.new_group(backend=backend)
             mine = torch.full((8,), float(dist.get_rank()), device=device)
             allv = torch.empty(8 * world, device=device)
             dist.all_gather_into_tensor(allv, mine, group=g)

@@ -108,6 +108,16 @@ def _worker(rank, world, port, q):
         ok = ok and control_group() is dist.group.WORLD          # gloo default group IS the control plane
         ok = ok and gather_over_ranks(float(10 + rank), world) == [10.0, 11.0]
         ok = ok and min_over_ranks(float(rank + 1), world) == 1.0
+        # the data plane: RCCL cannot come up here (no GPU), which every rank finds out within the deadline, agrees on over
+        # the control plane, and answers by handing back the gloo group with the reason; "gloo" asked for is gloo, no error
+        from crescent_credentials_amd.distributed import open_data_group
+        grp, used, err = open_data_group(torch.device("cuda", 0), "nccl", deadline_s=60.0)
+        ok = ok and grp is control_group() and used == "gloo" and isinstance(err, str) and len(err) > 0
+        grp2, used2, err2 = open_data_group(torch.device("cpu"), "gloo")
+        ok = ok and grp2 is control_group() and used2 == "gloo" and err2 is None
+        sp2 = ShardedProver(shard, torch.device("cpu"), group=grp)
+        c0 = g["proofs"][0]
+        ok = ok and sp2.prove(w, int(c0["r"], 16), int(c0["s"], 16)).hex() == c0["proof"]
         barrier_sync(world)
         mx = max_over_ranks(float(rank + 1), world, torch.device("cpu"))
         q.put((rank, ok, mx))
