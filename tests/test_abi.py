@@ -209,6 +209,99 @@ def _c_struct_fields(name):
     return out
 
 
+_RUST_OF_C = {"uint64_t": "u64", "uint32_t": "u32", "int32_t": "i32", "int64_t": "i64", "uint8_t": "u8", "float": "f32", "double": "f64",
+              "int": "c_int", "char": "c_char", "void": "c_void"}
+
+
+def _rust_type_of(ctype: str, array: str) -> str:
+    """the Rust spelling of a C declaration's type as sys.rs writes it"""
+    t = " ".join(ctype.split())
+    const = t.startswith("const ")
+    t = t[6:] if const else t
+    stars = t.count("*")
+    base = _RUST_OF_C[t.replace("*", "").strip()]
+    for _ in range(stars):
+        base = ("*const " if const else "*mut ") + base
+    return "[%s; %s]" % (base, array) if array else base
+
+
+def _c_struct_field_types(name):
+    src = open(os.path.join(ROOT, "include", "crescent_gpu.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), src, flags=re.S).group(1)
+    out = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        if not decl:
+            continue
+        ctype, rest = re.match(r"(.*?[\s\*])(\w+(?:\s*\[\d+\])?(?:\s*,\s*\*?\s*\w+)*)$", decl).groups()
+        for item in rest.split(","):             # `const uint8_t *a, *b;` declares several fields of one type
+            item = item.strip()
+            ptr = item.startswith("*")
+            m = re.match(r"\*?\s*(\w+)\s*(?:\[(\d+)\])?$", item)
+            out.append((m.group(1), _rust_type_of(ctype + ("*" if ptr else ""), m.group(2))))
+    return out
+
+
+def test_rust_shim_struct_field_types_match_header():
+    """the repr(C) structs of sys.rs carry the header's field TYPES, not only its names and order (the crate has
+    never met rustc, so the layout is checked here): u64 / i32 / f32 widths, pointer constness, array lengths"""
+    rs = open(os.path.join(ROOT, "integration", "rust", "crescent-gpu", "src", "sys.rs")).read()
+    for name in ("cg_proving_key", "cg_csr", "cg_options", "cg_timings", "cg_ctx_info"):
+        body = re.search(r"pub struct %s \{(.*?)\n\}" % name, rs, flags=re.S).group(1)
+        rust = [(f, " ".join(t.split())) for f, t in re.findall(r"pub (\w+):\s*([^,\n]+),", body)]
+        assert rust == _c_struct_field_types(name), name
+    # and the ctypes mirror's widths
+    from crescent_credentials_amd import api
+    width = {"u64": 8, "u32": 4, "i32": 4, "f32": 4}
+    for cls, name in ((api._CgOptions, "cg_options"), (api.CgTimings, "cg_timings"), (api.CgCtxInfo, "cg_ctx_info"), (api._CgProvingKey, "cg_proving_key")):
+        for (fname, ctype), (hname, rtype) in zip(cls._fields_, _c_struct_field_types(name)):
+            assert fname == hname
+            m = re.match(r"\[(\w+); (\d+)\]", rtype)
+            want = width[m.group(1)] * int(m.group(2)) if m else (8 if rtype.startswith("*") else width[rtype])
+            assert ctypes.sizeof(ctype) == want, (name, fname, rtype)
+
+
+def test_rust_shim_function_signatures_match_header():
+    """every extern fn of sys.rs takes the header's arguments: the same count, and per argument the same shape (scalar
+    width, pointer or not, pointer constness)"""
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "crescent_gpu.h")).read(), flags=re.S)
+    rs = open(os.path.join(ROOT, "integration", "rust", "crescent-gpu", "src", "sys.rs")).read()
+
+    def c_shape(arg):
+        arg = " ".join(re.sub(r"\[\d+\]", "*", arg).split())               # an array parameter is a pointer
+        if arg in ("void", ""):
+            return None
+        ptr = arg.count("*")
+        const = arg.startswith("const ")
+        base = re.sub(r"^const ", "", arg).replace("*", " ").split()[0]
+        if base == "struct":
+            base = re.sub(r"^const ", "", arg).replace("*", " ").split()[1]
+        return (ptr, const if ptr else False, _RUST_OF_C.get(base, base))
+
+    def rust_shape(arg):
+        t = " ".join(arg.split(":", 1)[1].split())
+        ptr = t.count("*const ") + t.count("*mut ")
+        const = t.startswith("*const ")
+        base = t.replace("*const ", "").replace("*mut ", "")
+        return (ptr, const if ptr else False, base)
+
+    checked = 0
+    for name, args in re.findall(r"pub fn (cg_[a-z0-9_]+)\s*\((.*?)\)", rs, flags=re.S):
+        m = re.search(r"\b%s\s*\((.*?)\)\s*;" % name, hdr, flags=re.S)
+        assert m, name
+        c_args = [c_shape(a) for a in m.group(1).split(",")]
+        c_args = [a for a in c_args if a is not None]
+        r_args = [rust_shape(a) for a in args.split(",") if a.strip()]
+        assert len(c_args) == len(r_args), (name, c_args, r_args)
+        for ca, ra in zip(c_args, r_args):
+            assert ca[0] == ra[0] and ca[1] == ra[1], (name, ca, ra)            # pointer depth and constness
+            if ca[2] in _RUST_OF_C.values():                                       # scalar / byte pointers: the same width
+                assert ca[2] == ra[2] or {ca[2], ra[2]} <= {"c_int", "i32"} or {ca[2], ra[2]} <= {"c_void", "u8"}, (name, ca, ra)
+        checked += 1
+    assert checked >= 8
+
+
 def test_header_is_strict_c_and_the_c_caller_links():
     """include/crescent_gpu.h compiles as C11 with -pedantic -Werror (a C or cgo/bindgen consumer sees no C++), and
     integration/c/crescent_prove - the reference's create_client_state as a plain C program - is built by build() and
