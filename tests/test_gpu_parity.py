@@ -179,6 +179,33 @@ def test_external_vectors_on_the_gpu(cc, oracle):
             assert int.from_bytes(outc[32 * k:32 * k + 32], "little") == 5 * pow(w, k, oracle.R) % oracle.R, (logn, k)
 
 
+def test_points_held_by_the_reference_tree_on_the_gpu(cc, oracle):
+    """the G1 / G2 points of forks/halo2curves/src/bn256/curve.rs:307-420 through the HIP MSM: [r - 1]·P = -P for each
+    (an identity of the group, no oracle value involved), with the default window and with small and wide ones, canonical and
+    Montgomery-form bases; and a sum over all five against the oracle's serial sum"""
+    from test_oracle_kats import h2c_points
+    g1, g2 = h2c_points(oracle)
+    rm1 = _scalars([oracle.R - 1])
+    mont = lambda b, n: b"".join((int.from_bytes(b[32 * i:32 * i + 32], "little") * (1 << 256) % oracle.Q).to_bytes(32, "little") for i in range(n))
+    for P in g1:
+        b = oracle.g1_packed(P)
+        want = oracle.g1_packed(oracle.G1.neg_affine(P))
+        for wb in (0, 3, 13, 20):
+            assert cc.msm_bigint_g1(b, rm1, window_bits=wb) == want, wb
+        assert cc.msm_bigint_g1(mont(b, 2), rm1, coord_form=cc.api.CG_FORM_MONTGOMERY) == want
+    for P in g2:
+        b = oracle.g2_packed(P)
+        want = oracle.g2_packed(oracle.G2.neg_affine(P))
+        for wb in (0, 3, 13, 20):
+            assert cc.msm_bigint_g2(b, rm1, window_bits=wb) == want, wb
+        assert cc.msm_bigint_g2(mont(b, 4), rm1, coord_form=cc.api.CG_FORM_MONTGOMERY) == want
+    ks = [oracle.R - 2, 1, 2, 0x1234567890ABCDEF << 100, 3]
+    assert cc.msm_bigint_g1(b"".join(oracle.g1_packed(P) for P in g1), _scalars(ks)) == \
+        oracle.g1_packed(oracle.G1.to_affine(oracle.G1.msm_naive(g1, ks)))
+    assert cc.msm_bigint_g2(b"".join(oracle.g2_packed(P) for P in g2), _scalars(ks)) == \
+        oracle.g2_packed(oracle.G2.to_affine(oracle.G2.msm_naive(g2, ks)))
+
+
 def test_msm_empty_and_all_zero(cc, oracle):
     assert cc.msm_bigint_g1(b"", b"") == bytes(64)
     g = oracle.g1_packed(oracle.G1_GEN)

@@ -162,3 +162,36 @@ def test_msm_matches_serial_sum(oracle):
     pts = [oracle.G1.to_affine(oracle.G1.mul_affine(oracle.G1_GEN, rng.randrange(1, oracle.R))) for _ in range(20)] + [None]
     sc = [rng.randrange(oracle.R) for _ in range(19)] + [0, 1]
     assert oracle.G1.to_affine(oracle.G1.msm(pts, sc)) == oracle.G1.to_affine(oracle.G1.msm_naive(pts, sc))
+
+
+def h2c_points(oracle):
+    """the BN254 points the reference's tree holds (forks/halo2curves/src/bn256/curve.rs:307-420)"""
+    k = K["halo2curves_bn256_hash_to_curve_points"]
+    g1 = [(int(x, 16), int(y, 16)) for x, y in k["g1"]]
+    g2 = [((int(x0, 16), int(x1, 16)), (int(y0, 16), int(y1, 16))) for x0, x1, y0, y1 in k["g2"]]
+    return g1, g2
+
+
+def test_points_held_by_the_reference_tree(oracle):
+    """Five G1 and five G2 points of BN254 from the reference's own tests (the in-tree halo2curves fork, taken by it from
+    gnark-crypto): each is on the oracle's curve - y² = x³ + 3 and the twist y² = x³ + 3/(9 + u) with Fq2 = (c0, c1) in the
+    order the prover's encodings use - and [r - 1]·P = -P by the oracle's group law (doublings and additions along 254 bits
+    of an independent point, over Fq and over Fq2: a wrong formula does not land on -P), and through the C restatement's
+    MSM; sums of several of them agree between the two."""
+    import cpu_ref
+    g1, g2 = h2c_points(oracle)
+    rm1 = (oracle.R - 1).to_bytes(32, "little")
+    for P in g1:
+        assert oracle.G1.is_on_curve(P)
+        assert oracle.G1.to_affine(oracle.G1.mul_affine(P, oracle.R - 1)) == oracle.G1.neg_affine(P)
+        assert cpu_ref.msm_g1(oracle.g1_packed(P), rm1) == oracle.g1_packed(oracle.G1.neg_affine(P))
+    for P in g2:
+        assert oracle.G2.is_on_curve(P)
+        assert oracle.G2.to_affine(oracle.G2.mul_affine(P, oracle.R - 1)) == oracle.G2.neg_affine(P)
+        assert cpu_ref.msm_g2(oracle.g2_packed(P), rm1) == oracle.g2_packed(oracle.G2.neg_affine(P))
+    ks = [oracle.R - 2, 1, 2, 0x1234567890ABCDEF << 100, 3]
+    sc = b"".join(k.to_bytes(32, "little") for k in ks)
+    want1 = oracle.g1_packed(oracle.G1.to_affine(oracle.G1.msm_naive(g1, ks)))
+    want2 = oracle.g2_packed(oracle.G2.to_affine(oracle.G2.msm_naive(g2, ks)))
+    assert cpu_ref.msm_g1(b"".join(oracle.g1_packed(P) for P in g1), sc) == want1
+    assert cpu_ref.msm_g2(b"".join(oracle.g2_packed(P) for P in g2), sc) == want2
