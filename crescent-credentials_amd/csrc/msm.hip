@@ -1423,8 +1423,19 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
 #endif
     // both start out zeroed (load time: a synchronous memset); per MSM they are either re-zeroed by the MSM's own last
     // kernels (zero_at_end) or filled at its start
-    CG_HIP(hipMemset(counters.p, 0, counters.bytes()));
-    CG_HIP(hipMemset(bucket_sums.p, 0, bucket_sums.bytes()));
+    // (On a stream of its own and WAITED for: hipMemset on device memory returns before the fill has run, and the legacy
+    // default stream it runs on does not order itself against this library's non-blocking streams - the first MSM of a
+    // freshly loaded context could start before the fill and have its counters zeroed under it.  Seen as wrong proofs and
+    // memory faults in test_contexts_come_and_go_while_others_prove, 10 runs in 12.)
+    {
+        hipStream_t zs = nullptr;
+        CG_HIP(hipStreamCreateWithFlags(&zs, hipStreamNonBlocking));
+        hipError_t e1 = hipMemsetAsync(counters.p, 0, counters.bytes(), zs);
+        hipError_t e2 = hipMemsetAsync(bucket_sums.p, 0, bucket_sums.bytes(), zs);
+        hipError_t e3 = hipStreamSynchronize(zs);
+        (void)hipStreamDestroy(zs);
+        CG_HIP(e1); CG_HIP(e2); CG_HIP(e3);
+    }
     counters_clean = buckets_clean = true;
     h_plan.alloc(PLAN_WORDS);
     for (int k = 0; k < PLAN_WORDS; ++k) h_plan.p[k] = 0;
