@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """k_accum_affine launch by launch: stand-alone duration (kernel trace taken with CG_SERIAL_STREAMS=1 --inflight 1) against
 the launch's own VALU instruction floor (SQ_INSTS_VALU of the same launch from a --pmc pass of the same command / 578 G
-wave-instructions per second), for the launches of a steady-state proof in the order the prover enqueues them
-(l, a, b1, b2 [G2], h).  Shows how much of the kernel's blended "efficiency" is the chip-filling h launch and how much the
+wave-instructions per second), for the accumulation launches between one k_w_to29 and the next: the witness map sits
+between a proof's assignment-driven MSMs and its h MSM (one-stream order l, a, b1, b2 [G2], witness map, h), so such a
+window holds h of one proof and then l, a, b1, b2 of the next.  Shows how much of the kernel's blended "efficiency" is the chip-filling h launch and how much the
 small MSMs, whose launches leave most of the chip empty when they run alone.
 usage: rocpd_accum_launches.py trace.db pmc.db [out.md]"""
 import re, sqlite3, sys
@@ -37,7 +38,7 @@ def per_proof(rows, firsts, val):
 ft, fp = steady(tr, 0, 1), steady(pm, 0, 1)
 dur = per_proof(tr, ft, lambda r: (r[2] - r[1]) / 1e3)
 ins = per_proof(pm, fp, lambda r: r[2])
-names = {0: "l", 1: "a", 2: "b1", 3: "b2", 4: "h"}
+names = {0: "h", 1: "l", 2: "a", 3: "b1", 4: "b2"}
 lines = ["k_accum_affine launch by launch (%d traced proofs, %d counted proofs; stand-alone, one proof at a time)" % (len(ft), len(fp)), "",
          "| launch | field | us stand-alone | VALU M wave-instr | floor us | efficiency |", "|---|---|---|---|---|---|"]
 tot_d = tot_f = 0.0
