@@ -16,4 +16,7 @@ done
 F=$(find "$OUT/FETCH_SIZE" -name '*.db' | head -1); W=$(find "$OUT/WRITE_SIZE" -name '*.db' | head -1); V=$(find "$OUT/SQ_INSTS_VALU" -name '*.db' | head -1)
 python3 "$ROOT/tools/make_pmc_json.py" "$KEY" "$F" "$W" "$V" "CG_SERIAL_STREAMS=1 rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU> -- python3 bench.py $FLAGS" "$OUT/pmc_counters.json"
 python3 "$ROOT/tools/rocpd_pmc.py" "$V" SQ_INSTS_VALU "$OUT/valu_per_proof.md" > /dev/null
+# where the HBM traffic of a proof goes, kernel by kernel (KB per proof, raw counters)
+python3 "$ROOT/tools/rocpd_pmc.py" "$F" FETCH_SIZE "$OUT/fetch_kb_per_proof.md" > /dev/null
+python3 "$ROOT/tools/rocpd_pmc.py" "$W" WRITE_SIZE "$OUT/write_kb_per_proof.md" > /dev/null
 rm -rf "$OUT/FETCH_SIZE" "$OUT/WRITE_SIZE" "$OUT/SQ_INSTS_VALU"

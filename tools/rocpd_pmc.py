@@ -18,12 +18,14 @@ for n, c, v, s, d in rows:
     a[0] += 1; a[1] += v
 tot = sum(a[1] for a in agg.values())
 lines = ["%s per proof (%d steady-state proofs, after the one-time window re-tune)" % (ctr, nproofs), "",
-         "| kernel | launches/proof | %s per proof (M) | %% |" % ctr, "|---|---|---|---|"]
+         "| kernel | launches/proof | %s per proof (%s) | %% |" % (ctr, "MB: the counter is in KB" if ctr.endswith("_SIZE") else "M"),
+         "|---|---|---|---|"]
+unit = 1e3 if ctr.endswith("_SIZE") else 1e6
 for n, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     if a[1] / tot < 0.0005:
         continue
-    lines.append("| %s | %.1f | %.1f | %.1f |" % (n, a[0] / nproofs, a[1] / nproofs / 1e6, 100 * a[1] / tot))
-lines += ["", "total: %.1f M per proof" % (tot / nproofs / 1e6)]
+    lines.append("| %s | %.1f | %.1f | %.1f |" % (n, a[0] / nproofs, a[1] / nproofs / unit, 100 * a[1] / tot))
+lines += ["", "total: %.1f %s per proof" % (tot / nproofs / unit, "MB" if ctr.endswith("_SIZE") else "M")]
 if ctr == "SQ_INSTS_VALU":
     lines.append("at the measured issue ceiling of 578 G wave-instructions/s (tools/ubench: 168 G Fq products/s x 220 instr / 64 lanes): %.2f ms per proof" % (tot / nproofs / 578e9 * 1e3))
 out = "\n".join(lines)
