@@ -17,7 +17,7 @@ assignments of the same value distribution, so that no step repeats the previous
 
 Timed region.  Several proofs are in flight per GPU (that is how the latency-bound tails of one proof hide under the bulk
 kernels of another), so a region of K proofs that starts and ends with an empty GPU contains a ramp-up and a drain that
-weigh more the smaller K is (K = 20 with 16 in flight is 1.25 pipeline fills).  The headline is therefore measured in
+weigh more the smaller K is (K = 20 with 12 in flight is 1.7 pipeline fills).  The headline is therefore measured in
 steady state: after W warm-up proofs the stream of proofs keeps running and B consecutive blocks of EXACTLY K
 completions each are timed (B chosen so that B·K >= 1500 whatever K is).  `value` = B·K proofs ÷ the time from the last
 warm-up completion to the last timed completion - proofs ÷ elapsed over the WHOLE steady window, no block dropped
@@ -104,9 +104,11 @@ def parse():
                          "the control plane is always gloo")
     ap.add_argument("--allow-shared-gpu", action="store_true",
                     help="N > visible GPUs: let several ranks share a GPU (implied by --backend gloo; RCCL needs a GPU per rank)")
-    ap.add_argument("--inflight", type=int, default=16,
-                    help="proofs in flight per GPU: host threads x context proof_slots, one stream each (8: 185, 12: 194, 16: 197, "
-                         "20: 195 proofs/s on one box, profiles/r03_b_inflight_and_segments.txt)")
+    ap.add_argument("--inflight", type=int, default=12,
+                    help="proofs in flight per GPU: host threads x context proof_slots, one stream each.  Round 4 (70 launches per proof): "
+                         "6: 177.5, 8: 188.7, 10: 191.6, 12: 196.8, 16: 196.8 proofs/s on one box (profiles/r04_m_inflight_low.txt) - twelve "
+                         "give the rate of sixteen with a quarter less memory and time in the pipeline per proof; round 3 (84 launches) "
+                         "needed sixteen (8: 185, 12: 194, 16: 197)")
     ap.add_argument("--assignments", type=int, default=4, help="device-resident assignments the timed proofs rotate over")
     ap.add_argument("--no-clock-probe", action="store_true",
                     help="do not sample the shader clock during the timed proofs (profiling runs: under rocprofv3 --pmc kernels "
