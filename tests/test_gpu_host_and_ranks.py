@@ -229,6 +229,46 @@ def test_contexts_come_and_go_while_others_prove(cc, oracle, medium):
         resident.close()
 
 
+def test_free_waits_for_the_calls_still_inside_the_context(cc, oracle, medium):
+    """a proof lets go of the context's lock before its re-tune check and its host finish, both of which read the
+    context, so cg_circuit_free racing with the TAIL of a call was a use-after-free for C and Rust callers (the Python cache's
+    leases hid it).  cg_circuit_free now also waits for a count of calls inside.  Raw handle: one thread is inside
+    cg_prove - the context's FIRST proof, the one followed by the window re-tune - while another frees the context; every
+    such proof must come back right, nothing may crash."""
+    import ctypes as C
+    import threading
+    import cpu_ref
+    from crescent_credentials_amd.api import fr_to_bytes
+    (l, m, M), cm, w, pk = medium
+    r, s = 21, 34
+    want = cpu_ref.prove(pk, (cm.a, cm.b, cm.c), l, m, M, w, r, s, nthreads=8)
+    L = cc.lib()
+    rb = np.frombuffer(fr_to_bytes(r), np.uint8).copy()
+    sb = np.frombuffer(fr_to_bytes(s), np.uint8).copy()
+    wv = np.ascontiguousarray(w, np.uint8)
+    for delay_us in (50, 200, 500, 1000, 2000, 4000, 8000, 100, 300, 3000):
+        p = cc.Prover(pk, cm, proof_slots=2)
+        h = p._h
+        p._h = None                                  # this test owns the handle from here
+        out = np.zeros(256, np.uint8)
+        rc = []
+        inside = threading.Event()
+
+        def prove():
+            inside.set()
+            rc.append(L.cg_prove(h, wv.ctypes.data_as(C.c_void_p), rb.ctypes.data_as(C.c_void_p), sb.ctypes.data_as(C.c_void_p),
+                                 out.ctypes.data_as(C.c_void_p), None))
+        t = threading.Thread(target=prove)
+        t.start()
+        inside.wait()
+        time.sleep(delay_us * 1e-6)
+        L.cg_circuit_free(h)                         # the call above has started: free must wait for ALL of it
+        t.join()
+        # (a free that won the race to the context before cg_prove entered it is the caller's bug, not covered; with the
+        # Event the call has at least been made - the delays sweep where in the call the free arrives)
+        assert rc == [0] and out.tobytes() == want, delay_us
+
+
 def test_set_device(cc, oracle):
     """cg_set_device: range-checked, and the device-less entry points still answer afterwards"""
     cc.set_device(0)
