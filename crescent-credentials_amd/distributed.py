@@ -26,6 +26,7 @@ import torch
 import torch.distributed as dist
 
 PARTIAL_BYTES = 384
+POISON = b"\xff" * PARTIAL_BYTES     # no partial-sum record looks like this: coordinates are canonical (< q < 2^254)
 
 _control = None
 
@@ -219,13 +220,18 @@ class ShardedProver:
     def prove_stream(self, jobs, in_flight: int, on_device: bool = True, done_times: Optional[list] = None):
         """jobs: list of (assignment, r, s) - the SAME list, in the same order, on every rank.  -> proofs in job order.
         `in_flight` sharded proofs are kept going on this rank.  done_times (optional list) receives perf_counter() of
-        every proof's completion, job order."""
+        every proof's completion, job order.
+
+        A shard that fails does not leave the other ranks waiting in a collective: the failing rank still takes part in
+        every all_gather, sending a poison record for the job it could not do; every rank sees the poison, skips that job's
+        host finish, and at the end of the stream the failing rank raises its own exception and the others a RuntimeError
+        naming the rank and the job.  The sequence of collectives is the same on every rank whatever fails."""
         n = len(jobs)
         if n == 0:
             return []
         in_flight = max(1, min(in_flight, n))
         parts = [None] * n           # this rank's 384-byte record of proof k
-        gathered = [None] * n        # all ranks' records of proof k
+        gathered = [None] * n        # all ranks' records of proof k (None: some rank failed on it)
         proofs = [None] * n
         if done_times is not None:
             done_times[:] = [0.0] * n
@@ -233,41 +239,40 @@ class ShardedProver:
         have_all = [threading.Event() for _ in range(n)]
         nxt = [0]
         lock = threading.Lock()
-        err = []
-
-        def fail(e):
-            err.append(e)
-            for ev in have_part + have_all:      # nobody stays blocked behind a failure
-                ev.set()
+        mine, theirs, fatal = [], [], []      # (job, exception) of this rank; (job, rank) poisoned by others; the gather itself
 
         def worker():
-            while not err:
+            while not fatal:
                 with lock:
                     k = nxt[0]
                     nxt[0] += 1
                 if k >= n:
                     return
+                a, r, s = jobs[k]
+                t0 = time.perf_counter()
                 try:
-                    a, r, s = jobs[k]
-                    t0 = time.perf_counter()
                     parts[k] = self.prover.prove_partial(a, r, on_device=on_device)
-                    t1 = time.perf_counter()
-                    have_part[k].set()
-                    have_all[k].wait()
-                    if err:
-                        return
+                except BaseException as e:   # noqa: BLE001 - surfaces below, after the stream
+                    mine.append((k, e))
+                    parts[k] = POISON
+                t1 = time.perf_counter()
+                have_part[k].set()
+                have_all[k].wait()
+                if fatal or gathered[k] is None:
+                    continue
+                try:
                     t2 = time.perf_counter()
                     proofs[k] = self.prover.assemble(gathered[k], self.world, r, s)
                     t3 = time.perf_counter()
-                    if done_times is not None:
-                        done_times[k] = t3
-                    with lock:
-                        self.seconds["partial"] += t1 - t0
-                        self.seconds["assemble"] += t3 - t2
-                        self.proofs += 1
-                except BaseException as e:   # noqa: BLE001 - surfaces below
-                    fail(e)
-                    return
+                except BaseException as e:   # noqa: BLE001
+                    mine.append((k, e))
+                    continue
+                if done_times is not None:
+                    done_times[k] = t3
+                with lock:
+                    self.seconds["partial"] += t1 - t0
+                    self.seconds["assemble"] += t3 - t2
+                    self.proofs += 1
 
         def gatherer():
             try:
@@ -275,26 +280,35 @@ class ShardedProver:
                     torch.cuda.set_device(self.device)   # a new thread starts on device 0
                 for k in range(n):
                     have_part[k].wait()
-                    if err:
-                        return
                     t0 = time.perf_counter()
                     if self.world > 1:
-                        gathered[k] = self._gather(parts[k])
+                        allp = self._gather(parts[k])
                         self.all_gathers += 1
                     else:
-                        gathered[k] = parts[k]
+                        allp = parts[k]
+                    bad = [q for q in range(self.world) if allp[PARTIAL_BYTES * q:PARTIAL_BYTES * (q + 1)] == POISON]
+                    if bad:
+                        theirs.extend((k, q) for q in bad)
+                    else:
+                        gathered[k] = allp
                     self.seconds["gather"] += time.perf_counter() - t0
                     have_all[k].set()
-            except BaseException as e:       # noqa: BLE001
-                fail(e)
+            except BaseException as e:       # noqa: BLE001 - the transport itself failed: nothing more can be exchanged
+                fatal.append(e)
+                for ev in have_all:
+                    ev.set()
 
         ts = [threading.Thread(target=worker) for _ in range(in_flight)] + [threading.Thread(target=gatherer)]
         for t in ts:
             t.start()
         for t in ts:
             t.join()
-        if err:
-            raise err[0]
+        if fatal:
+            raise fatal[0]
+        if mine:
+            raise mine[0][1]
+        if theirs:
+            raise RuntimeError("sharded proof stream: " + ", ".join("rank %d failed on job %d" % (q, k) for k, q in theirs[:8]))
         return proofs
 
     def breakdown_ms(self) -> dict:

@@ -104,6 +104,28 @@ def _worker(rank, world, port, q):
         ok = ok and [p.hex() for p in got] == [c["proof"] for c in cases]
         ok = ok and sp.all_gathers == len(g["proofs"]) + len(jobs) and len(times) == len(jobs) and all(t > 0 for t in times)
         ok = ok and sp.prove_stream([], in_flight=4) == []
+        # a shard that fails on ONE rank: no rank is left waiting in a collective, every collective is still issued in order,
+        # the failing rank raises its own exception and the other names the rank and the job
+        class Flaky:
+            def __init__(self, inner, fail_at):
+                self.inner, self.fail_at, self.calls = inner, fail_at, 0
+            def prove_partial(self, a, r, on_device=False):
+                self.calls += 1
+                if (a, r) == self.fail_at:
+                    raise ValueError("shard fault injected on rank %d" % rank)
+                return self.inner.prove_partial(a, r, on_device=on_device)
+            def assemble(self, *args):
+                return self.inner.assemble(*args)
+        jobs2 = [(w, 1000 + i, 7) for i in range(5)]
+        spf = ShardedProver(Flaky(shard, (w, 1002) if rank == 1 else None), torch.device("cpu"))
+        try:
+            spf.prove_stream(jobs2, in_flight=3, on_device=False)
+            ok = False
+        except ValueError as e:
+            ok = ok and rank == 1 and "injected" in str(e)
+        except RuntimeError as e:
+            ok = ok and rank == 0 and "rank 1 failed on job 2" in str(e)
+        ok = ok and spf.all_gathers == len(jobs2)
         from crescent_credentials_amd.distributed import control_group, gather_over_ranks, min_over_ranks
         ok = ok and control_group() is dist.group.WORLD          # gloo default group IS the control plane
         ok = ok and gather_over_ranks(float(10 + rank), world) == [10.0, 11.0]
