@@ -92,7 +92,9 @@ typedef struct cg_options {
     int32_t shard_count;   /* ... of shard_count; 0 or 1 = unsharded.  A shard with proof_slots > 1 keeps that many
                               sharded proofs in flight (cg_prove_partial from as many threads) */
     int32_t proof_slots;   /* proofs that may be in flight on this context at once (each has its own working
-                              set and streams; cg_prove* from different threads overlap on the GPU); 0 = 1 */
+                              set and streams; cg_prove* from different threads overlap on the GPU); 0 = 1, at
+                              most 16.  1 = a latency context (five streams per proof); more = a throughput
+                              context (one stream per proof; twelve reach the full rate at the rs256 size) */
     int32_t flags;         /* CG_FLAG_* */
     int32_t reserved[2];
 } cg_options;
