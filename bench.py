@@ -133,7 +133,10 @@ def visible_gpus_without_hip() -> int:
                         n += int(line.split()[1]) > 0
         except (OSError, ValueError):
             pass
-    return n
+    # a container that was given some of the host's GPUs has only their render nodes (the pool's one-GPU boxes: ten topology
+    # nodes, one of them readable, one /dev/dri/renderD*)
+    r = sum(1 for p in glob.glob("/dev/dri/renderD*") if os.access(p, os.R_OK | os.W_OK))
+    return min(n, r) if n and r else (n or r)
 
 
 def self_launch(a) -> int:
