@@ -8,7 +8,7 @@ accepted, with no code shared with `csrc/setup.hip`:
   verify        the reference's one acceptance criterion (forks/groth16/src/test.rs:70-71, creds/src/lib.rs:286-290,
                 verifier.rs:44-65) by the Python oracle's pairing; a flipped public input must be refused.
   key_scalars   a_i(tau), b_i(tau), c_i(tau), zt by oracle/cpu_ref.c `ref_qap_at` (r1cs_to_qap.rs:103-147 restated; pinned to
-                the Python oracle in tests/test_cpu_ref.py), then the scalars of the five queries as generator.rs:118-194
+                the Python oracle in tests/test_keycheck_cpu.py), then the scalars of the five queries as generator.rs:118-194
                 defines them.
   check_key     (1) every fixed point of the key and every gamma_abc entry == [scalar]·G by the Python oracle's
                 double-and-add; (2) a strided sample of each query the same way; (3) EVERY entry of each query through a
@@ -19,7 +19,6 @@ accepted, with no code shared with `csrc/setup.hip`:
                 C = [sum_aux w_i·l_i + (a(tau)·b(tau) - c(tau))/delta + s·A + r·B - r·s·delta]G, for a SATISFYING
                 assignment (then h(tau)·zt = a(tau)·b(tau) - c(tau) exactly; no transform, no MSM over the key).
 """
-import random
 
 import numpy as np
 
