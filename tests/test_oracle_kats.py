@@ -195,3 +195,30 @@ def test_points_held_by_the_reference_tree(oracle):
     want2 = oracle.g2_packed(oracle.G2.to_affine(oracle.G2.msm_naive(g2, ks)))
     assert cpu_ref.msm_g1(b"".join(oracle.g1_packed(P) for P in g1), sc) == want1
     assert cpu_ref.msm_g2(b"".join(oracle.g2_packed(P) for P in g2), sc) == want2
+
+
+def test_fq2_constants_held_by_the_reference_tree(oracle):
+    """The in-tree halo2curves fork spells out xi^((q^k - 1)/6), k = 1..3, and xi^((q - 1)/2) for xi = 9 + u as Montgomery limbs
+    (forks/halo2curves/src/bn256/fq12.rs:40-100, engine.rs:164-177).  The oracle's Fq2 multiplication and squaring - the
+    arithmetic under its G2 group law and its pairing - must reach them through 250 to 760 steps each."""
+    k = K["halo2curves_bn256_fq2_constants"]
+    Q, F = oracle.Q, oracle.Fq2Ops
+    rinv = pow(1 << 256, Q - 2, Q)
+    canon = lambda limbs: sum(int(x, 16) << (64 * i) for i, x in enumerate(limbs)) * rinv % Q
+    val = lambda name: (canon(k[name][0]), canon(k[name][1]))
+
+    def fpow(a, e):
+        r = (1, 0)
+        while e:
+            if e & 1:
+                r = F.mul(r, a)
+            a = F.sqr(a)
+            e >>= 1
+        return r
+    xi = (9, 1)
+    assert fpow(xi, (Q - 1) // 6) == val("xi_pow_q1_minus_1_over_6")
+    assert fpow(xi, (Q * Q - 1) // 6) == val("xi_pow_q2_minus_1_over_6")
+    assert fpow(xi, (Q ** 3 - 1) // 6) == val("xi_pow_q3_minus_1_over_6")
+    assert fpow(xi, (Q - 1) // 2) == val("xi_pow_q1_minus_1_over_2")
+    # and the twist the G2 points live on is y^2 = x^3 + 3/xi with this xi (forks/halo2curves/src/bn256/curve.rs: G2_B)
+    assert F.mul(oracle.G2.b, xi) == (3, 0)
