@@ -206,6 +206,32 @@ def test_points_held_by_the_reference_tree_on_the_gpu(cc, oracle):
         oracle.g2_packed(oracle.G2.to_affine(oracle.G2.msm_naive(g2, ks)))
 
 
+def test_endomorphism_known_answer_on_the_gpu(cc, oracle):
+    """[lambda]·(x, y) = (beta·x, y) (forks/halo2curves tests/curve.rs:413-427, constants fr.rs:12 / fq.rs:14): a full-width
+    scalar multiplication with an answer stated by the reference's tree, through the HIP MSM - one-shot entry point with
+    several windows, resident-table context, Montgomery-form bases, and with the point repeated 1000 times under scalars
+    that add up to lambda"""
+    from test_oracle_kats import endo_constants, h2c_points
+    lam, beta = endo_constants()
+    g1, _ = h2c_points(oracle)
+    for P in [oracle.G1_GEN] + g1:
+        want = oracle.g1_packed((beta * P[0] % oracle.Q, P[1]))
+        b = oracle.g1_packed(P)
+        for wb in (0, 2, 7, 16, 20):
+            assert cc.msm_bigint_g1(b, _scalars([lam]), window_bits=wb) == want, wb
+        for wb in (0, 22):                                   # resident window tables (the prover's arrangement)
+            ctx = cc.MsmContext(b, group=1, window_bits=wb)
+            try:
+                assert ctx.run(_scalars([lam])) == want, wb
+            finally:
+                ctx.close()
+    P = g1[0]
+    rng = random.Random(5)
+    parts = [rng.randrange(oracle.R) for _ in range(999)]
+    parts.append((lam - sum(parts)) % oracle.R)
+    assert cc.msm_bigint_g1(oracle.g1_packed(P) * 1000, _scalars(parts)) == oracle.g1_packed((beta * P[0] % oracle.Q, P[1]))
+
+
 def test_msm_empty_and_all_zero(cc, oracle):
     assert cc.msm_bigint_g1(b"", b"") == bytes(64)
     g = oracle.g1_packed(oracle.G1_GEN)

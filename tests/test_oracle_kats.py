@@ -222,3 +222,23 @@ def test_fq2_constants_held_by_the_reference_tree(oracle):
     assert fpow(xi, (Q - 1) // 2) == val("xi_pow_q1_minus_1_over_2")
     # and the twist the G2 points live on is y^2 = x^3 + 3/xi with this xi (forks/halo2curves/src/bn256/curve.rs: G2_B)
     assert F.mul(oracle.G2.b, xi) == (3, 0)
+
+
+def endo_constants():
+    k = K["halo2curves_bn256_endomorphism"]
+    return int(k["fr_zeta_lambda"], 16), int(k["fq_zeta_beta"], 16)
+
+
+def test_endomorphism_known_answer_from_the_reference_tree(oracle):
+    """forks/halo2curves tests/curve.rs:413-427 asserts g * Fr::ZETA == g.endo() = (x * Fq::ZETA, y): a 254-bit scalar
+    multiplication on BN254 G1 whose answer the reference's tree states.  Through the oracle's double-and-add, its Pippenger,
+    and the C restatement's MSM, for the generator and for the five G1 points the tree holds."""
+    import cpu_ref
+    lam, beta = endo_constants()
+    assert pow(lam, 3, oracle.R) == 1 and lam != 1 and pow(beta, 3, oracle.Q) == 1 and beta != 1
+    g1, _ = h2c_points(oracle)
+    for P in [oracle.G1_GEN] + g1:
+        want = (beta * P[0] % oracle.Q, P[1])
+        assert oracle.G1.to_affine(oracle.G1.mul_affine(P, lam)) == want
+        assert oracle.G1.to_affine(oracle.G1.msm([P], [lam])) == want
+        assert cpu_ref.msm_g1(oracle.g1_packed(P), lam.to_bytes(32, "little")) == oracle.g1_packed(want)
