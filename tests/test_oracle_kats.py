@@ -242,3 +242,17 @@ def test_endomorphism_known_answer_from_the_reference_tree(oracle):
         assert oracle.G1.to_affine(oracle.G1.mul_affine(P, lam)) == want
         assert oracle.G1.to_affine(oracle.G1.msm([P], [lam])) == want
         assert cpu_ref.msm_g1(oracle.g1_packed(P), lam.to_bytes(32, "little")) == oracle.g1_packed(want)
+
+
+def test_bn_parameter_and_miller_loop_digits_held_by_the_reference_tree(oracle):
+    """forks/halo2curves/src/bn256/mod.rs:17-24: u and the signed digits of 6u + 2.  Both moduli are polynomials in u, and the
+    digit string is the one oracle/ark_files.py walks when it prepares a G2 point (marked [ark-mem] there: now also pinned
+    to the tree)."""
+    import ark_files
+    k = K["halo2curves_bn256_parameter"]
+    u = int(k["bn_x"])
+    assert 36 * u ** 4 + 36 * u ** 3 + 24 * u ** 2 + 6 * u + 1 == oracle.Q
+    assert 36 * u ** 4 + 36 * u ** 3 + 18 * u ** 2 + 6 * u + 1 == oracle.R
+    assert sum(d << i for i, d in enumerate(k["six_u_plus_2_naf"])) == 6 * u + 2
+    assert ark_files.BN_X == u and list(ark_files.ATE_LOOP_COUNT) == k["six_u_plus_2_naf"]
+    assert len(k["six_u_plus_2_naf"]) == 65
