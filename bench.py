@@ -6,14 +6,17 @@ this process launches its own N ranks (python -m torch.distributed.run ..., befo
 rank 0's line and the exit code; launched under torch.distributed.run it is one of the ranks.  Rank 0 prints ONE JSON
 line.
 
-A "step" is one full Groth16 proof (assignment resident in HBM -> 256-byte proof): the witness map (2 sparse products
-+ 4 transforms with the folded key; 3 + 7 in the reference arrangement), four G1 MSMs, one G2 MSM and the host finish,
-with fresh (r, s).
+A "step" is one full Groth16 proof as SURVEY §8d defines the metric - witness in HOST memory -> 256-byte proof (cg_prove,
+what creds/src/lib.rs:274-283 hands over): the 32·M-byte upload of the assignment from pageable memory, the witness map
+(2 sparse products + 4 transforms with the folded key; 3 + 7 in the reference arrangement), four G1 MSMs, one G2 MSM and
+the host finish, with fresh (r, s).  The same loop from page-locked memory (cg_host_alloc) and with the assignments
+already resident in HBM (cg_prove_dev - rounds 1-4's headline) is measured beside it: `config.host_witness`,
+`timing.device_resident`, `host_witness`.
 Workload: the rs256-sd circuit's SHAPE (BASELINE.json metric; SURVEY.md §8d "S21": D = 2^21, m = 1 480 000,
 M = 1 500 000, ℓ = 26), synthetic + satisfiable, ≈11 terms per row (nnz ≈ 16.6 M: the circomlib gate mix of
 crescent-credentials_amd/synth/synth.cpp), with a proving key made by the GPU setup from a seeded trapdoor.  Real
-Crescent circuits cannot be built in this environment.  The timed proofs rotate over several device-resident
-assignments of the same value distribution, so that no step repeats the previous step's inputs.
+Crescent circuits cannot be built in this environment.  The timed proofs rotate over several assignments of the same
+value distribution, so that no step repeats the previous step's inputs.
 
 Timed region.  Several proofs are in flight per GPU (that is how the latency-bound tails of one proof hide under the bulk
 kernels of another), so a region of K proofs that starts and ends with an empty GPU contains a ramp-up and a drain that
@@ -75,7 +78,16 @@ def parse():
                          "booleanity + short product rows, ~3.4 terms per row (kept for A/B against round-1 numbers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the secondary witness_sweep measurements")
-    ap.add_argument("--no-host-witness", action="store_true", help="skip the host-witness (cg_prove) sub-record")
+    ap.add_argument("--no-host-witness", action="store_true",
+                    help="skip the secondary legs of the witness's origin (page-locked host memory, device-resident)")
+    ap.add_argument("--witness", default="host", choices=["host", "pinned", "device"],
+                    help="where the timed proofs' assignments come from: host = pageable host memory through cg_prove (the metric as "
+                         "SURVEY 8d writes it, the default), pinned = page-locked host memory, device = already in HBM (cg_prove_dev: "
+                         "profiling runs, A/B of kernels)")
+    ap.add_argument("--mode", default=None, choices=["latency", "throughput"],
+                    help="force the context's arrangement (CG_FLAG_LATENCY_MODE / CG_FLAG_THROUGHPUT_MODE); default: proof slots decide. "
+                         "`--inflight 1 --mode throughput` is the profiling arrangement: one proof at a time on one stream with the "
+                         "pipelined run's kernels")
     ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the sharded-proof sub-record")
     ap.add_argument("--sharded-steps", type=int, default=20, help="N > 1: sharded proofs timed one at a time (latency)")
     ap.add_argument("--sharded-inflight", type=int, default=8,
@@ -295,7 +307,9 @@ def main():
         import torch
         ndev = max(1, torch.cuda.device_count())
     ranks_per_gpu = max(1, math.ceil(int(os.environ.get("LOCAL_WORLD_SIZE", world)) / ndev))
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(16 if ranks_per_gpu == 1 else max(4, 16 // ranks_per_gpu)))
+    # (eight plumbing ranks on one GPU get two queues each: 8 x 4 = 32 user queues would be above the ~24 at which the hardware
+    # scheduler starts time-slicing)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(16 if ranks_per_gpu == 1 else max(2, 16 // ranks_per_gpu)))
     # the RCCL group of the sharded leg must never take the process down: no asynchronous tear-down on a failed or
     # timed-out collective, no heartbeat monitor (the leg has its own deadline and falls back to gloo)
     os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
@@ -381,14 +395,14 @@ def main():
             window = max_over_ranks(window, world)
         return window, rec, per_rank
 
-    def bracketed(prove_k, steps, sync_ranks):
+    def bracketed(prove_k, steps, sync_ranks, threads=None):
         """the classical region: empty GPU, K proofs, empty GPU"""
         if sync_ranks:
             barrier_sync(world)
         else:
             torch.cuda.synchronize()
         t0 = time.perf_counter()
-        steady_stream(prove_k, steps, inflight)
+        steady_stream(prove_k, steps, threads or inflight)
         torch.cuda.synchronize()
         if sync_ranks:
             barrier_sync(world)
@@ -408,29 +422,57 @@ def main():
     wires = wl.wire_stats(w_np)
     log("workload %s: l=%d m=%d M=%d nnz=%d wires=%s, key + circuit made in %.1fs" % (a.shape, l, m, M, nnz, wires, time.time() - t0))
     t0 = time.time()
-    prover = cc.Prover(pk, cm, device=local_rank, window_bits=a.window, proof_slots=inflight, h_coefficient_basis=a.h_coefficient_basis)
+    prover = cc.Prover(pk, cm, device=local_rank, window_bits=a.window, proof_slots=inflight, h_coefficient_basis=a.h_coefficient_basis,
+                       mode=a.mode)
     log("circuit loaded on GPU in %.1fs (D = %d)" % (time.time() - t0, prover.domain_size))
     ws_np = permuted_assignments(w_np, l, max(1, a.assignments), 7)
     ws_dev = [torch.from_numpy(x).to(dev) for x in ws_np]
     torch.cuda.synchronize()
 
     timed_sample = {}       # the latest proof the stream made on the SATISFYING assignment (the permuted ones satisfy nothing)
+    pinned = []             # page-locked copies of the assignments (cg_host_alloc), made on first use
 
-    def prove_dev_k(k):
-        j = k % len(ws_dev)
-        r_, s_ = fresh_rs()
-        p = prover.prove_dev(ws_dev[j].data_ptr(), r_, s_)
-        if j == 0:
-            timed_sample["proof"] = (k, r_, s_, p.data)
+    def pinned_buffers():
+        if not pinned:
+            for x in ws_np:
+                hb = cc.HostBuffer(x.size)
+                hb.array[:] = x
+                pinned.append(hb)
+        return pinned
+
+    def stream_of(origin, sample=None):
+        """prove_k(k) for assignments arriving from `origin`: 'host' = pageable host memory (numpy arrays) through cg_prove,
+        'pinned' = page-locked host memory through cg_prove, 'device' = already in HBM through cg_prove_dev"""
+        if origin == "pinned":
+            pinned_buffers()
+
+        def prove_k(k):
+            j = k % len(ws_np)
+            r_, s_ = fresh_rs()
+            if origin == "host":
+                p = prover.prove_host_ptr(ws_np[j].ctypes.data, r_, s_)
+            elif origin == "pinned":
+                p = prover.prove_host_ptr(pinned[j].ptr, r_, s_)
+            else:
+                p = prover.prove_dev(ws_dev[j].data_ptr(), r_, s_)
+            if sample is not None and j == 0:
+                sample["proof"] = (k, r_, s_, p.data)
+        return prove_k
+
+    # two more caller threads than proof slots when the witness arrives from the host: a context holds that many more upload
+    # buffers, so the next assignments arrive while every working set is busy
+    callers_of = lambda origin: inflight if origin == "device" else inflight + 2
+    prove_headline_k = stream_of(a.witness, timed_sample)
+    callers = callers_of(a.witness)
 
     blocks = n_blocks(a)
     n_timed = blocks * a.steps
-    prime(prove_dev_k)
+    prime(prove_headline_k)
     clock = ClockSampler(cc, local_rank) if rank == 0 and not a.no_clock_probe else None
-    dt, timing, per_rank = measure(prove_dev_k, a.steps, a.warmup, blocks, True, clock)
+    dt, timing, per_rank = measure(prove_headline_k, a.steps, a.warmup, blocks, True, clock, threads=callers)
     value = n_timed * world / dt
     checked_proof = timed_sample.get("proof")           # taken before any later leg overwrites it
-    dt_br = bracketed(prove_dev_k, a.steps, True)
+    dt_br = bracketed(prove_headline_k, a.steps, True, threads=callers)
     info = prover.info()
     log("steady state %.2f proofs/s (%d proofs in %.2f s; median block %.2f, spread %.1f %%); bracketed %.2f; shader clock %s GHz" %
         (value, n_timed, dt, timing["median_block"]["value_this_rank"] * world, timing["median_block"]["spread_pct"],
@@ -488,7 +530,13 @@ def main():
                    "wires": wires, "mode": "throughput (one full key replica per GPU)",
                    "h_query_basis": "coefficient" if a.h_coefficient_basis else "coset evaluation (transformed at load)",
                    "proofs_per_rank": n_timed, "proofs_in_flight_per_gpu": inflight,
-                   "inputs": "%d assignments resident in HBM, taken in rotation; (r,s) fresh per proof" % len(ws_dev),
+                   "inputs": {"host": "witness in HOST memory (pageable) -> proof through cg_prove, the metric as SURVEY 8d writes it: every "
+                                      "proof uploads its %d-byte assignment first; %d assignments taken in rotation; (r,s) fresh per proof",
+                              "pinned": "witness in page-locked HOST memory (cg_host_alloc) -> proof through cg_prove: every proof uploads "
+                                        "its %d-byte assignment first; %d assignments taken in rotation; (r,s) fresh per proof",
+                              "device": "NOT the metric as written: %d-byte assignments already resident in HBM (cg_prove_dev, --witness "
+                                        "device); %d taken in rotation; (r,s) fresh per proof"}[a.witness] % (int(ws_np[0].size), len(ws_np)),
+                   "witness_origin": a.witness, "caller_threads": callers,
                    "context": {"resident_GB": round(info["total_bytes"] / 1e9, 2), "tables_GB": round(info["table_bytes"] / 1e9, 2),
                                "per_slot_GB": round(info["slot_bytes"] / 1e9, 3),
                                "per_slot_GB_by_kind": {k[5:-6]: round(info[k] / 1e9, 3) for k in
@@ -546,50 +594,52 @@ def main():
         watchdog.daemon = True
         watchdog.start()
 
-    # ---- SURVEY §8d's metric as written: witness in HOST memory -> proof (cg_prove), pageable and page-locked ------------
+    # ---- the witness's origin, the other two ways: page-locked host memory, and already resident in HBM ------------------
+    # (`value` above is the --witness origin, pageable host memory by default = SURVEY §8d's metric as written)
+    rates = {a.witness: value}
     if not a.no_host_witness:
-        hw = {"note": "the same steady-state measurement through cg_prove: every proof uploads its 32·M-byte assignment from "
-                      "host memory first (the reference's caller has the witness on the host, creds/src/lib.rs:274-283); "
-                      "uploads overlap the other proofs in flight (proof_slots + 2 caller threads)"}
+        hw = {"note": "the same steady-state measurement with the assignments arriving from the other origins: `value` is the "
+                      "'%s' one.  From host memory every proof uploads its 32·M-byte assignment first (the reference's caller has "
+                      "the witness on the host, creds/src/lib.rs:274-283); uploads overlap the other proofs in flight (proof_slots + 2 "
+                      "caller threads)" % a.witness}
         hblocks = max(3, blocks // 2)
         hn = hblocks * a.steps
         try:
-            def prove_pageable_k(k):
-                x = ws_np[k % len(ws_np)]
-                prover.prove_host_ptr(x.ctypes.data, *fresh_rs())
-            prime_n = inflight
-            # two more caller threads than proof slots: a context holds that many more upload buffers, so the next
-            # assignments arrive while every working set is busy
-            callers = inflight + 2
-            steady_stream(prove_pageable_k, prime_n, callers)
-            d_p, rec_p, _ = measure(prove_pageable_k, a.steps, min(a.warmup, inflight), hblocks, True, threads=callers)
-            hw["pageable"] = dict(rec_p, proofs_per_s=round(hn * world / d_p, 3), ms_per_step=round(d_p / hn * 1e3, 4))
-            pinned = [cc.HostBuffer(x.size) for x in ws_np]
-            for hb, x in zip(pinned, ws_np):
-                hb.array[:] = x
-
-            def prove_pinned_k(k):
-                prover.prove_host_ptr(pinned[k % len(pinned)].ptr, *fresh_rs())
-            steady_stream(prove_pinned_k, prime_n, callers)
-            d_l, rec_l, _ = measure(prove_pinned_k, a.steps, min(a.warmup, inflight), hblocks, True, threads=callers)
-            hw["pinned"] = dict(rec_l, proofs_per_s=round(hn * world / d_l, 3), ms_per_step=round(d_l / hn * 1e3, 4))
-            hw["pinned_over_device_resident"] = round((hn * world / d_l) / value, 4)
-            hw["pageable_over_device_resident"] = round((hn * world / d_p) / value, 4)
-            _, tmu = prover.prove_host_ptr(pinned[0].ptr, *fresh_rs(), timings=True)
+            for origin in ("host", "pinned", "device"):
+                if origin == a.witness:
+                    continue
+                pk_ = stream_of(origin)
+                thr = callers_of(origin)
+                steady_stream(pk_, inflight, thr)
+                d_o, rec_o, _ = measure(pk_, a.steps, min(a.warmup, inflight), hblocks, True, threads=thr)
+                rates[origin] = hn * world / d_o
+                rec = dict(rec_o, proofs_per_s=round(rates[origin], 3), ms_per_step=round(d_o / hn * 1e3, 4), over_value=round(rates[origin] / value, 4))
+                if origin == "device":
+                    out["timing"]["device_resident"] = dict(rec, note="assignments already in HBM (cg_prove_dev): rounds 1-4's headline")
+                else:
+                    hw["pageable" if origin == "host" else "pinned"] = rec
+            _, tmu = prover.prove_host_ptr(pinned_buffers()[0].ptr, *fresh_rs(), timings=True)
             hw["upload_ms_one_proof_alone"] = round(tmu["upload_ms"], 3)
             hw["upload_bytes"] = int(ws_np[0].size)
             # the bytes do not depend on where the witness came from
             r_, s_ = fresh_rs()
-            same = prover.prove_host_ptr(pinned[0].ptr, r_, s_).data == prover.prove_dev(ws_dev[0].data_ptr(), r_, s_).data
+            want_ = prover.prove_dev(ws_dev[0].data_ptr(), r_, s_).data
+            same = prover.prove_host_ptr(pinned[0].ptr, r_, s_).data == want_ and prover.prove_host_ptr(ws_np[0].ctypes.data, r_, s_).data == want_
             hw["bytes_identical_to_device_resident"] = bool(same)
             assert same, "host-witness and device-resident proofs differ"
-            for hb in pinned:
-                hb.close()
         except AssertionError:
             raise
         except Exception as e:
             hw["error"] = repr(e)
         out["host_witness"] = hw
+    for hb in pinned:
+        hb.close()
+    del pinned[:]
+    # the two-number summary the driver's parsed record keeps (it keeps `config`)
+    out["config"]["host_witness"] = {"pageable_proofs_per_s": round(rates["host"], 3) if "host" in rates else None,
+                                     "pinned_proofs_per_s": round(rates["pinned"], 3) if "pinned" in rates else None,
+                                     "device_resident_proofs_per_s": round(rates["device"], 3) if "device" in rates else None,
+                                     "value_is": a.witness}
 
     # ---- N > 1: proofs sharded over the ranks (config 4), measured in the same run -------------------------------------
     if world > 1 and not a.no_sharded:
@@ -600,6 +650,9 @@ def main():
             # the DATA plane: RCCL, opened here and nowhere else, with a deadline; every rank ends up on the same backend
             grp, used, rccl_err = open_data_group(dev, a.backend, a.rccl_deadline)
             sh["backend"] = used
+            from crescent_credentials_amd import distributed as _d
+            if _d.RCCL_TAINTED:      # a helper thread is still inside RCCL on this rank: what follows shares the process with it
+                sh["rccl_tainted"] = _d.RCCL_TAINTED
             if rccl_err:
                 sh["error"] = "%s group did not come up on this rank set: %s" % (a.backend, rccl_err)
                 sh["backend_fallback"] = used

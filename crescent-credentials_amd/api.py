@@ -16,11 +16,15 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libcrescent_gpu.so")
+# CRESCENT_GPU_LIB (read by this Python harness, not by the library): load another build of the same ABI - the tuning
+# build `libcrescent_gpu_tuning.so` of tools/ab_*.sh and of the fault-injection test
+_LIB_PATH = os.environ.get("CRESCENT_GPU_LIB") or os.path.join(_HERE, "libcrescent_gpu.so")
+TUNING_LIB_PATH = os.path.join(_HERE, "libcrescent_gpu_tuning.so")
 
 FR_MODULUS = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 CG_FORM_CANONICAL, CG_FORM_MONTGOMERY = 0, 1
 CG_FLAG_H_COEFFICIENT_BASIS = 1
+CG_FLAG_LATENCY_MODE, CG_FLAG_THROUGHPUT_MODE, CG_FLAG_SPIN_WAIT, CG_FLAG_CONTIGUOUS_H_SHARDS = 2, 4, 8, 16
 
 
 class CrescentGpuError(RuntimeError):
@@ -338,14 +342,22 @@ class Prover:
     """A circuit loaded on one GPU (cg_ctx): proving key tables + matrices resident in HBM."""
 
     def __init__(self, pk: ProvingKey, matrices: ConstraintMatrices, device: int = -1, window_bits: int = 0,
-                 shard_rank: int = 0, shard_count: int = 1, proof_slots: int = 1, h_coefficient_basis: bool = False):
-        """h_coefficient_basis=True keeps the h query as loaded (seven transforms per proof, CG_FLAG_H_COEFFICIENT_BASIS)."""
+                 shard_rank: int = 0, shard_count: int = 1, proof_slots: int = 1, h_coefficient_basis: bool = False,
+                 mode: Optional[str] = None, spin_wait: bool = False, contiguous_h_shards: bool = False, flags: int = 0):
+        """h_coefficient_basis=True keeps the h query as loaded (seven transforms per proof, CG_FLAG_H_COEFFICIENT_BASIS).
+        mode: None (proof_slots decides), "latency" or "throughput" (CG_FLAG_LATENCY_MODE / CG_FLAG_THROUGHPUT_MODE);
+        spin_wait: CG_FLAG_SPIN_WAIT; contiguous_h_shards: CG_FLAG_CONTIGUOUS_H_SHARDS; flags: further raw CG_FLAG_* bits."""
+        if mode not in (None, "latency", "throughput"):
+            raise ValueError("mode must be None, 'latency' or 'throughput'")
+        flags |= (CG_FLAG_H_COEFFICIENT_BASIS if h_coefficient_basis else 0) | (CG_FLAG_LATENCY_MODE if mode == "latency" else 0) | \
+                 (CG_FLAG_THROUGHPUT_MODE if mode == "throughput" else 0) | (CG_FLAG_SPIN_WAIT if spin_wait else 0) | \
+                 (CG_FLAG_CONTIGUOUS_H_SHARDS if contiguous_h_shards else 0)
         L = lib()
         self.num_inputs = matrices.num_instance_variables
         self.num_constraints = matrices.num_constraints
         self.num_variables = matrices.num_variables
         opt = _CgOptions(device=device, window_bits=window_bits, shard_rank=shard_rank, shard_count=shard_count,
-                         proof_slots=proof_slots, flags=CG_FLAG_H_COEFFICIENT_BASIS if h_coefficient_basis else 0)
+                         proof_slots=proof_slots, flags=flags)
         self.proof_slots = max(1, proof_slots)
         cpk = pk._c()
         abc, _keep = matrices._c()

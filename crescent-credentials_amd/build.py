@@ -15,6 +15,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libcrescent_gpu.so")
+# the A/B + fault-injection build (-DCG_TUNING: the only build that reads CG_* environment switches; csrc/common.hpp).
+# Same sources, objects under _build_tuning/.  tools/ab_*.sh and the fault-injection test load it through CRESCENT_GPU_LIB.
+TUNING_LIB = os.path.join(HERE, "libcrescent_gpu_tuning.so")
+TUNING_BUILD = os.path.join(HERE, "_build_tuning")
 SYNTH_LIB = os.path.join(HERE, "libcg_synth.so")
 # the reference-side caller in plain C (integration/c): built here so that every build proves the header is valid C
 # and that the ABI links without Python or torch
@@ -61,11 +65,40 @@ def _newest_header() -> float:
     return t
 
 
-def _compile(src: str, obj: str) -> None:
-    cmd = [_hipcc(), *HIPCC_FLAGS, *EXTRA_FLAGS, "-c", src, "-o", obj]
+def _compile(src: str, obj: str, more=()) -> None:
+    cmd = [_hipcc(), *HIPCC_FLAGS, *EXTRA_FLAGS, *more, "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
+
+
+def build_tuning(verbose: bool = False, jobs: int = int(os.environ.get("CG_BUILD_JOBS", "4"))) -> str:
+    """libcrescent_gpu_tuning.so: the same sources with -DCG_TUNING (environment switches compiled in)."""
+    os.makedirs(TUNING_BUILD, exist_ok=True)
+    hdr_t = _newest_header()
+    stamp = os.path.join(TUNING_BUILD, "flags.txt")
+    flags_now = " ".join(HIPCC_FLAGS + EXTRA_FLAGS + ["-DCG_TUNING"])
+    flags_changed = (open(stamp).read() if os.path.exists(stamp) else "") != flags_now
+    todo, objs = [], []
+    for s in HIP_SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(TUNING_BUILD, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if flags_changed or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            todo.append((src, obj))
+    if todo:
+        if verbose:
+            print("[build:tuning] compiling", [os.path.basename(s) for s, _ in todo], file=sys.stderr)
+        with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
+            for f in [ex.submit(_compile, s, o, ("-DCG_TUNING",)) for s, o in todo]:
+                f.result()
+        with open(stamp, "w") as f:
+            f.write(flags_now)
+    if todo or not os.path.exists(TUNING_LIB):
+        r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", TUNING_LIB, *objs], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+    return TUNING_LIB
 
 
 def build(verbose: bool = False, jobs: int = int(os.environ.get("CG_BUILD_JOBS", "4"))) -> str:
@@ -126,3 +159,5 @@ def build(verbose: bool = False, jobs: int = int(os.environ.get("CG_BUILD_JOBS",
 
 if __name__ == "__main__":
     print(build(verbose=True))
+    if "--tuning" in sys.argv[1:]:
+        print(build_tuning(verbose=True))

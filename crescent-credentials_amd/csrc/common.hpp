@@ -39,6 +39,17 @@ struct HipError : std::runtime_error {
 
 #define CG_KERNEL_CHECK() CG_HIP(hipGetLastError())
 
+// Tuning / A-B / fault-injection switches are read from the environment ONLY in builds made with -DCG_TUNING
+// (`python crescent-credentials_amd/build.py --tuning` -> libcrescent_gpu_tuning.so, tools/ab_*.sh); the shipped library
+// never looks at the host's environment: what a host may legitimately choose is a cg_options field or flag
+// (include/crescent_gpu.h).  CG_TUNE_ENV("X") is getenv("CG_X") there and a null pointer here (no string in the binary;
+// tests/test_abi.py checks `strings`).
+#ifdef CG_TUNING
+#define CG_TUNE_ENV(name) getenv("CG_" name)
+#else
+#define CG_TUNE_ENV(name) ((const char*)nullptr)
+#endif
+
 // Device-memory accounting (cg_ctx_get_info): while an AllocScope is alive on a thread, every DevBuf that thread
 // allocates adds its bytes to the scope's counter and every DevBuf it releases subtracts them, so temporaries made and
 // freed inside a scope cancel out and what is left is what stays resident.
@@ -69,7 +80,19 @@ struct DevBuf {
     ~DevBuf() { release(); }
     void alloc(size_t count) {
         release();
-        if (count) CG_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+        if (count) {
+            const hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+            if (e != hipSuccess) {
+                p = nullptr;
+                (void)hipGetLastError();        // the failure is reported here, not left behind as the thread's sticky error
+                size_t free_b = 0, total_b = 0;
+                (void)hipMemGetInfo(&free_b, &total_b);
+                char b[256];
+                snprintf(b, sizeof(b), "device allocation of %zu bytes failed: %s (%zu of %zu bytes free on the device)",
+                         count * sizeof(T), hipGetErrorString(e), free_b, total_b);
+                throw ::cg::HipError(e == hipErrorOutOfMemory ? CG_ERR_OUT_OF_MEMORY : CG_ERR_HIP, b);
+            }
+        }
         n = count;
         AllocScope::note((int64_t)(count * sizeof(T)));
     }
@@ -106,6 +129,25 @@ struct PinnedBuf {
         return (T*)d;
     }
 };
+
+// A stream that lives for one scope (loaders): destroyed on every way out, an exception included.
+struct ScopedStream {
+    hipStream_t st = nullptr;
+    ScopedStream() { CG_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); }
+    ~ScopedStream() { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } }
+    ScopedStream(const ScopedStream&) = delete;
+    ScopedStream& operator=(const ScopedStream&) = delete;
+    operator hipStream_t() const { return st; }
+};
+
+// Host -> device copy of a loader's temporary (a std::vector about to go out of scope): on the LOADER'S stream, and waited
+// for.  No synchronous hipMemcpy / hipMemset in this library: they run on the legacy default stream, which does not order
+// itself against the non-blocking streams every context works on ("stream-order audit").
+inline void h2d_sync(void* dst, const void* src, size_t bytes, hipStream_t st) {
+    if (!bytes) return;
+    CG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+    CG_HIP(hipStreamSynchronize(st));
+}
 
 // zero `bytes` (a multiple of 16) of device memory with full-width stores on the whole chip
 // (hipMemsetAsync's fill kernel reaches ~0.2 TB/s on these sizes)

@@ -207,7 +207,7 @@ void ec_fold_c_into_l(const uint32_t* h_row0, const uint8_t* h_valid, uint64_t n
         HostCsc t;
         csr_transpose(c_matrix, num_constraints, M, t);
         DevCsr ct;
-        ct.upload(t.view, M, num_constraints, false);
+        ct.upload(t.view, M, num_constraints, st, false);
         std::vector<uint32_t> keys_h(nnz);
         for (uint64_t k = 0; k < M; ++k)
             for (uint64_t e = t.ptr[k]; e < t.ptr[k + 1]; ++e) keys_h[e] = (uint32_t)k;

@@ -380,12 +380,16 @@ __global__ void __launch_bounds__(PART_THREADS) k_part_count(PartShape sh, const
     // The block that finishes LAST turns the histogram into the plan (entry total, segment geometry, bin starts, chunk
     // table) - what a one-block launch of its own did before.  Everything the blocks hand to it goes through agent-scope
     // ATOMICS (the histogram adds, the PLAN_DONE count, the last block's loads), which are performed at the coherence
-    // point of the eight XCDs' L2s: each wave waits for its own adds to be acknowledged (a workgroup-scope release is the
-    // s_waitcnt), the block meets at the barrier, one thread counts the block in.  No __threadfence(): at agent scope that
-    // is an L2 write-back + invalidate, and with it in every wave of this kernel the pipeline lost 17 %
-    // (profiles/r04_f_fold_ab.txt).
-    if (!pa.start1) return;            // CG_PLAN_LAUNCH=1 (A/B aid): the plan is made by a launch of its own
+    // point of the eight XCDs' L2s: each wave waits for its own adds to be ACKNOWLEDGED - an explicit `s_waitcnt vmcnt(0)`:
+    // the no-return global atomics are vector-memory operations, and a workgroup-scope release alone only drains
+    // lgkmcnt in non-tgsplit mode (round 4 shipped without it: the ISA went from the atomic loop straight into s_barrier,
+    // so the last block could in principle read a short histogram; tests/test_abi.py now checks the disassembly) - the
+    // block meets at the barrier, one thread counts the block in.  No __threadfence(): at agent scope that is an L2
+    // write-back + invalidate, and with it in every wave of this kernel the pipeline lost 17 % (profiles/r04_f_fold_ab.txt);
+    // the s_waitcnt writes nothing back.
+    if (!pa.start1) return;            // tuning builds, CG_PLAN_LAUNCH=1 (A/B aid): the plan is made by a launch of its own
     __shared__ uint32_t is_last;
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0) (gfx9 encoding: expcnt and lgkmcnt left at their maxima)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0)
@@ -572,8 +576,9 @@ static void launch_part_level1_c(bool count, const PartShape& sh, uint32_t tiles
     if (count) { k_part_count<C><<<tiles, PART_THREADS, lds, st>>>(sh, scalars, valid, blk_hist, hist1, plan, pa); return; }
     if constexpr (C >= STAGE_MIN_C) {
         // latency contexts only: the staging costs 15 M wave-instructions per proof more than it saves in stores (23.9 M against
-        // 9.1 M for the h MSM), which is 0.1 ms off a lone proof and 0.7 % ON a proof in the pipeline.  CG_PLACE_STAGED=1 / 0 forces either.
-        static const char* force = getenv("CG_PLACE_STAGED");
+        // 9.1 M for the h MSM), which is 0.1 ms off a lone proof and 0.7 % ON a proof in the pipeline.  (Tuning builds:
+        // CG_PLACE_STAGED=1 / 0 forces either.)
+        static const char* force = CG_TUNE_ENV("PLACE_STAGED");
         const bool staged = (force && (force[0] == '0' || force[0] == '1')) ? force[0] == '1' : sh.staged != 0;
         if (staged && sh.precomputed) {
             constexpr int W = (SCALAR_BITS + C - 1) / C;
@@ -943,10 +948,10 @@ k_accum_affine_g2_pair(const uint64_t* __restrict__ entries, const uint32_t* __r
 // per addition (the lane exchanges and operand selects), and with a dozen proofs in flight every issue slot the one-lane
 // kernel leaves idle is taken by another proof's kernel: all-uniform witnesses prove at 77.2 proofs/s with the pair kernel
 // against 79.3 with the one-lane kernel, circom-like ones the same either way (profiles/r03_c_g2_lane_pair.txt).  So:
-// pair kernel for latency contexts (a lone proof, a shard), one-lane kernel for throughput contexts.  CG_G2_PAIR=1 / 0
-// forces either.
+// pair kernel for latency contexts (a lone proof, a shard), one-lane kernel for throughput contexts.  (Tuning builds:
+// CG_G2_PAIR=1 / 0 forces either.)
 static bool g2_pair_kernel(bool latency_mode) {
-    static const char* e = getenv("CG_G2_PAIR");
+    static const char* e = CG_TUNE_ENV("G2_PAIR");
     if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
     return latency_mode;
 }
@@ -1323,7 +1328,7 @@ static constexpr uint32_t ACC_TARGET_PAIRS = 256u * 4u * CG_G2PAIR_RESIDENT_WAVE
 template <class F29T> static uint32_t acc_target_segments(bool latency_mode) {
     // CG_ACC_QUARTERS (tuning aid, throughput contexts): lanes of the largest accumulation launch in quarters of a resident
     // round - 3 leaves one wave slot per SIMD to whatever else is in flight, 8 is two rounds
-    static const uint32_t quarters = [] { const char* e = getenv("CG_ACC_QUARTERS"); const int v = e ? atoi(e) : 4; return (uint32_t)(v >= 1 && v <= 16 ? v : 4); }();
+    static const uint32_t quarters = [] { const char* e = CG_TUNE_ENV("ACC_QUARTERS"); const int v = e ? atoi(e) : 4; return (uint32_t)(v >= 1 && v <= 16 ? v : 4); }();
     const uint32_t full = latency_mode ? ACC_TARGET_THREADS : ACC_TARGET_THREADS / 4u * quarters;
     if (Words29<F29T>::NF != 2) return full;
     return g2_pair_kernel(latency_mode) ? ACC_TARGET_PAIRS : full;
@@ -1367,7 +1372,7 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
     max_chunks = bits2 ? (uint32_t)(cap_entries / PART_CHUNK) + B1 + 1 : 0;
     bucket_sums.alloc(((size_t)nbuckets_total + 1) * ACC);
     min_L = latency_mode ? ACC_MIN_L_LATENCY : ACC_MIN_L;
-    if (const char* e = getenv("CG_MIN_SEGMENT")) {          // tuning aid, like CG_SERIAL_STREAMS
+    if (const char* e = CG_TUNE_ENV("MIN_SEGMENT")) {        // tuning builds only
         const int v = atoi(e);
         if (v >= 1 && v <= 4096) min_L = (uint32_t)v;
     }
@@ -1394,8 +1399,8 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
 #ifdef CG_WITH_BATCH_AFFINE
     ba_rounds = 0;
     if constexpr (Words29<F29T>::NF == 1) {
-        if (const char* e = getenv("CG_BA_ROUNDS"); e && ba_allowed) ba_rounds = atoi(e) < 0 ? 0 : (atoi(e) > 6 ? 6 : atoi(e));
-        if (const char* e = getenv("CG_BA_SLOTS")) { const int v = atoi(e); if (v >= 1 && v <= 1024) ba_B = (uint32_t)v; }
+        if (const char* e = CG_TUNE_ENV("BA_ROUNDS"); e && ba_allowed) ba_rounds = atoi(e) < 0 ? 0 : (atoi(e) > 6 ? 6 : atoi(e));
+        if (const char* e = CG_TUNE_ENV("BA_SLOTS")) { const int v = atoi(e); if (v >= 1 && v <= 1024) ba_B = (uint32_t)v; }
     }
     if (ba_rounds) {
         uint64_t ncap = cap_entries, out1 = 0, out2 = 0;
@@ -1505,7 +1510,7 @@ void MsmEngine<F>::digits(const Fr* scalars_dev, uint64_t n, hipStream_t st) {
     PlanArgs pa;
     pa.start1 = start1; pa.chunk0 = chunk0; pa.target_threads = acc_target_segments<F29T>(latency_mode); pa.min_L = min_L;
     pa.two_level = bits2 ? 1 : 0;
-    static const bool plan_launch = getenv("CG_PLAN_LAUNCH") != nullptr && getenv("CG_PLAN_LAUNCH")[0] == '1';
+    static const bool plan_launch = CG_TUNE_ENV("PLAN_LAUNCH") != nullptr && CG_TUNE_ENV("PLAN_LAUNCH")[0] == '1';   // tuning builds: the reference path of the A/B
     if (plan_launch) {
         PlanArgs none = pa;
         none.start1 = nullptr;
@@ -1625,7 +1630,7 @@ void MsmEngine<F>::enqueue_reduction(hipStream_t st) {
     const uint32_t nb = 1u << (bases->c - 1);
     const uint32_t C = 1u << red_cbits(bases->c), R = nb / C;
     const size_t lds = (size_t)256 * ACC * 4;
-    static const bool force_tree = getenv("CG_RED_TREE") != nullptr;      // A/B aid
+    static const bool force_tree = CG_TUNE_ENV("RED_TREE") != nullptr;      // A/B aid (tuning builds)
     if (latency_mode || force_tree) {   // a block per row / column with an LDS tree: depth log, more additions
         k_bucket_rows_cols<F29T><<<dim3(R + C, wins), 256, lds, st>>>(bucket_sums.p, R, C, rows_buf.p, cols_buf.p);
         CG_KERNEL_CHECK();

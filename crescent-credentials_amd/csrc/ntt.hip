@@ -137,7 +137,7 @@ void csr_transpose(const cg_csr& m, uint64_t rows, uint64_t cols, HostCsc& out) 
 }
 
 
-void DevCsr::upload(const cg_csr& m, uint64_t rows_, uint64_t num_variables, bool sliced) {
+void DevCsr::upload(const cg_csr& m, uint64_t rows_, uint64_t num_variables, hipStream_t st, bool sliced) {
     rows = rows_;
     nnz = m.nnz;
     if (nnz >= (1ull << 32)) throw HipError(CG_ERR_INVALID_ARGUMENT, "matrix with >= 2^32 non-zeros");
@@ -180,22 +180,22 @@ void DevCsr::upload(const cg_csr& m, uint64_t rows_, uint64_t num_variables, boo
         for (uint64_t i = 0; i < rows; ++i) if (rp[i + 1] - rp[i] > 4096u) lr.push_back((uint32_t)i);
         n_long_rows = lr.size();
         long_rows.alloc(lr.size() ? lr.size() : 1);
-        if (!lr.empty()) CG_HIP(hipMemcpy(long_rows.p, lr.data(), lr.size() * 4, hipMemcpyHostToDevice));
+        if (!lr.empty()) h2d_sync(long_rows.p, lr.data(), lr.size() * 4, st);
     }
     col.alloc(nnz ? nnz : 1);
     coef_idx.alloc(nnz ? nnz : 1);
     dict.alloc(dict_h.size());
-    CG_HIP(hipMemcpy(row_ptr.p, rp.data(), (rows + 1) * 4, hipMemcpyHostToDevice));
+    h2d_sync(row_ptr.p, rp.data(), (rows + 1) * 4, st);
     if (nnz) {
-        CG_HIP(hipMemcpy(col.p, m.col, nnz * 4, hipMemcpyHostToDevice));
-        CG_HIP(hipMemcpy(coef_idx.p, idx.data(), nnz * 4, hipMemcpyHostToDevice));
+        h2d_sync(col.p, m.col, nnz * 4, st);
+        h2d_sync(coef_idx.p, idx.data(), nnz * 4, st);
     }
-    CG_HIP(hipMemcpy(dict.p, dict_h.data(), dict_h.size() * sizeof(Fr), hipMemcpyHostToDevice));
-    if (sliced) build_sell(rp, m.col, idx);
+    h2d_sync(dict.p, dict_h.data(), dict_h.size() * sizeof(Fr), st);
+    if (sliced) build_sell(rp, m.col, idx, st);
 }
 
 // the sliced layout of ntt.hpp's SellLevel, built on the host once per matrix
-void DevCsr::build_sell(const std::vector<uint32_t>& rp, const uint32_t* col_h, const std::vector<uint32_t>& idx) {
+void DevCsr::build_sell(const std::vector<uint32_t>& rp, const uint32_t* col_h, const std::vector<uint32_t>& idx, hipStream_t st) {
     struct Item { uint32_t row, first, len; };              // a row of the current level: `len` terms from `first`
     std::vector<uint32_t> cur_col(col_h, col_h + nnz), cur_idx(idx);
     std::vector<Item> items;
@@ -207,7 +207,7 @@ void DevCsr::build_sell(const std::vector<uint32_t>& rp, const uint32_t* col_h, 
     // then agree on which of their steps multiply.  Circom rows are mostly unit coefficients with the powers of two
     // concentrated in the adder rows (gate mix: 82 % of A's rows carry no other coefficient at all), and a wave pays the
     // 207-instruction product at every step at which ANY of its lanes needs it.
-    static const bool plain = getenv("CG_SELL_PLAIN") != nullptr;       // A/B aid: round 2's layout (terms as given, pieces by length)
+    static const bool plain = CG_TUNE_ENV("SELL_PLAIN") != nullptr;       // A/B aid (tuning builds): round 2's layout (terms as given, pieces by length)
     for (const Item& it : items) {
         if (plain) break;
         uint32_t w = it.first;
@@ -277,10 +277,10 @@ void DevCsr::build_sell(const std::vector<uint32_t>& rp, const uint32_t* col_h, 
         L.n_partials = partials;
         if (partials > sell_scratch) sell_scratch = partials;
         L.slice_ptr.alloc(ns + 1); L.col.alloc(lc.size()); L.cidx.alloc(li.size()); L.dst.alloc(np ? np : 1);
-        CG_HIP(hipMemcpy(L.slice_ptr.p, sp.data(), (ns + 1) * 4, hipMemcpyHostToDevice));
-        CG_HIP(hipMemcpy(L.col.p, lc.data(), lc.size() * 4, hipMemcpyHostToDevice));
-        CG_HIP(hipMemcpy(L.cidx.p, li.data(), li.size() * 4, hipMemcpyHostToDevice));
-        if (np) CG_HIP(hipMemcpy(L.dst.p, dst.data(), np * 4, hipMemcpyHostToDevice));
+        h2d_sync(L.slice_ptr.p, sp.data(), (ns + 1) * 4, st);
+        h2d_sync(L.col.p, lc.data(), lc.size() * 4, st);
+        h2d_sync(L.cidx.p, li.data(), li.size() * 4, st);
+        if (np) h2d_sync(L.dst.p, dst.data(), np * 4, st);
         // the next level sums the partials: unit coefficients over this level's scratch vector
         items.swap(next_items);
         cur_col.swap(next_col);

@@ -56,8 +56,9 @@ struct DevCsr {
     int n_sell = 0;
     uint32_t sell_scratch = 0;  // largest partial count of any level
     // sliced = false: skip the sliced layout (the generator's transposed matrices only run the saturated product)
-    void upload(const cg_csr& m, uint64_t rows, uint64_t num_variables, bool sliced = true);
-    void build_sell(const std::vector<uint32_t>& rp, const uint32_t* col_h, const std::vector<uint32_t>& idx);
+    // st: the loader's stream (the host arrays are copied on it and waited for)
+    void upload(const cg_csr& m, uint64_t rows, uint64_t num_variables, hipStream_t st, bool sliced = true);
+    void build_sell(const std::vector<uint32_t>& rp, const uint32_t* col_h, const std::vector<uint32_t>& idx, hipStream_t st);
 };
 // host-side transpose of a CSR view (rows x cols): CSR of the transpose, terms of one column kept in row order
 struct HostCsc {

@@ -223,6 +223,7 @@ struct cg_ctx {
     // check and its host finish, both of which read the context, so cg_circuit_free waits for this count as well
     std::atomic<int> calls_inside{0};
     bool latency = false;
+    bool spin_wait = false;      // CG_FLAG_SPIN_WAIT
     // device bytes that stay resident (cg_ctx_get_info): window tables + validity flags | matrices and domain tables | one slot
     // (slot_bytes is the sum of slot_part: entry lists, segment pieces, bucket arrays and reduction buffers, the witness
     // map's vectors + the h MSM's scalars, one upload buffer - account_slot)
@@ -385,7 +386,11 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
     const int wb = opt ? opt->window_bits : 0;
     if (wb < 0 || wb == 1 || wb > 22) return fail(CG_ERR_INVALID_ARGUMENT, "window_bits must be 0 (automatic) or in [2, 22]");
     if (opt && opt->proof_slots < 0) return fail(CG_ERR_INVALID_ARGUMENT, "proof_slots must not be negative");
-    if (opt && (opt->flags & ~CG_FLAG_H_COEFFICIENT_BASIS)) return fail(CG_ERR_INVALID_ARGUMENT, "unknown bits in flags");
+    constexpr int32_t KNOWN_FLAGS = CG_FLAG_H_COEFFICIENT_BASIS | CG_FLAG_LATENCY_MODE | CG_FLAG_THROUGHPUT_MODE | CG_FLAG_SPIN_WAIT |
+                                    CG_FLAG_CONTIGUOUS_H_SHARDS;
+    if (opt && (opt->flags & ~KNOWN_FLAGS)) return fail(CG_ERR_INVALID_ARGUMENT, "unknown bits in flags");
+    if (opt && (opt->flags & CG_FLAG_LATENCY_MODE) && (opt->flags & CG_FLAG_THROUGHPUT_MODE))
+        return fail(CG_ERR_INVALID_ARGUMENT, "flags: CG_FLAG_LATENCY_MODE and CG_FLAG_THROUGHPUT_MODE are exclusive");
     // every pointer the structs carry is checked before anything is read through it (a half-filled struct from the
     // C or Rust side must come back as an error, not a fault)
     if (!pk->alpha_g1 || !pk->beta_g1 || !pk->delta_g1 || !pk->beta_g2 || !pk->delta_g2)
@@ -407,8 +412,11 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         c->fixed_window = wb > 0;
         int n_slots = (opt && opt->proof_slots > 0) ? opt->proof_slots : 1;
         if (n_slots > 16) n_slots = 16;
-        hipStream_t s0;
-        CG_HIP(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking));
+        // the loader's stream: every load-time copy and kernel runs on it; destroyed on every way out of this function - a
+        // load that runs out of device memory half-way gives back its stream with everything else (the context's buffers
+        // are RAII members of `c`, the temporaries are scoped DevBufs)
+        ScopedStream s0_guard;
+        const hipStream_t s0 = s0_guard;
         const uint32_t form = pk->coord_form;
         c->alpha_g1 = g1_import(pk->alpha_g1, form);
         c->beta_g1 = g1_import(pk->beta_g1, form);
@@ -424,7 +432,7 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         {
             const int logs = ilog2_ceil((uint64_t)c->shard_count);
             c->h_strided = c->folded && c->shard_count > 1 && (1 << logs) == c->shard_count && logD - logs >= 4 &&
-                           !(getenv("CG_CONTIGUOUS_SHARDS") && getenv("CG_CONTIGUOUS_SHARDS")[0] == '1');   // A/B aid
+                           !(opt && (opt->flags & CG_FLAG_CONTIGUOUS_H_SHARDS));
         }
         c->rh = shard_range(c->folded ? D : D - 1, c->shard_rank, c->shard_count);
         if (c->h_strided) c->rh = {0, D / (uint64_t)c->shard_count};     // positions in the shard's own list of points
@@ -434,9 +442,9 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         std::unique_ptr<AllocScope> booking;
         auto book = [&](int64_t* counter) { booking.reset(); if (counter) booking.reset(new AllocScope(counter)); };
         book(&c->matrix_bytes);
-        c->A.upload(abc[0], m, M);     // validates the CSR views (monotone row_ptr, column range, canonical coefficients)
-        c->B.upload(abc[1], m, M);
-        c->C.upload(abc[2], m, M);
+        c->A.upload(abc[0], m, M, s0);     // validates the CSR views (monotone row_ptr, column range, canonical coefficients)
+        c->B.upload(abc[1], m, M, s0);
+        c->C.upload(abc[2], m, M, s0);
         c->dom.build(logD, true, s0);
         CG_HIP(hipStreamSynchronize(s0));
         book(&c->table_bytes);
@@ -474,7 +482,6 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         if (c->h_strided) c->wstr.build(c->dom, ilog2_ceil((uint64_t)c->shard_count), c->shard_rank, s0);
         c->dA.build(c->A, s0); c->dB.build(c->B, s0); c->dC.build(c->C, s0);
         CG_HIP(hipStreamSynchronize(s0));
-        (void)hipStreamDestroy(s0);
         // the saturated-form tables were only the source of the packed ones
         c->dom.tw_fwd.release(); c->dom.tw_inv.release(); c->dom.coset_br.release(); c->dom.icoset_br.release();
         c->A.dict.release(); c->B.dict.release(); c->C.dict.release();
@@ -482,7 +489,10 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         // flight - whole proofs, or this rank's shards of several proofs (distributed.ShardedProver, proofs_in_flight) -
         // are a throughput job
         c->latency = n_slots == 1;
-        if (const char* e = getenv("CG_LATENCY_MODE")) c->latency = e[0] == '1';    // profiling aid: force either segment length
+        if (opt && (opt->flags & CG_FLAG_LATENCY_MODE)) c->latency = true;
+        if (opt && (opt->flags & CG_FLAG_THROUGHPUT_MODE)) c->latency = false;
+        c->spin_wait = opt && (opt->flags & CG_FLAG_SPIN_WAIT);
+        if (const char* e = CG_TUNE_ENV("LATENCY_MODE")) c->latency = e[0] == '1';    // tuning builds: force either segment length
         book(nullptr);                                    // slots are accounted by kind from their buffers (account_slot)
         for (int k = 0; k < n_slots; ++k) {
             std::unique_ptr<ProofSlot> sl(new ProofSlot());
@@ -491,12 +501,14 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
             // ~24 user queues per process is time-sliced by the hardware scheduler in 15 ms quanta): 192 proofs/s on 16
             // queues against 188 with five streams per proof on 32 (profiles/r03_a_streams_and_queues.txt).  A latency
             // context (one proof at a time, or a shard of one) spreads its five MSMs and the witness map over five streams.
-            // CG_SERIAL_STREAMS=1 / 0 forces either (profiling: a kernel trace of serial streams shows stand-alone durations).
+            // (CG_FLAG_THROUGHPUT_MODE with one slot is the profiling arrangement: a kernel trace of one proof at a time on one
+            // stream shows stand-alone durations of the kernels the pipelined run launches.  Tuning builds: CG_SERIAL_STREAMS=1 / 0
+            // decouples the stream count from the mode.)
             bool serial = !c->latency;
-            if (const char* e = getenv("CG_SERIAL_STREAMS")) serial = e[0] == '1';
-            // CG_CHAIN_PRIORITY=1 (experiment): the witness-map -> h-MSM chain, which sets a lone proof's latency, on a
-            // high-priority stream
-            const bool chain_prio = getenv("CG_CHAIN_PRIORITY") && getenv("CG_CHAIN_PRIORITY")[0] == '1';
+            if (const char* e = CG_TUNE_ENV("SERIAL_STREAMS")) serial = e[0] == '1';
+            // tuning builds, CG_CHAIN_PRIORITY=1 (experiment): the witness-map -> h-MSM chain, which sets a lone proof's latency,
+            // on a high-priority stream
+            const bool chain_prio = CG_TUNE_ENV("CHAIN_PRIORITY") && CG_TUNE_ENV("CHAIN_PRIORITY")[0] == '1';
             int prio_lo = 0, prio_hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
             for (int i = 0; i < 5; ++i) {
@@ -512,11 +524,11 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
             const bool latency = c->latency;
             sl->eh.latency_mode = sl->el.latency_mode = sl->ea.latency_mode = sl->eb1.latency_mode = sl->eb2.latency_mode = latency;
 #ifdef CG_WITH_BATCH_AFFINE
-            if (getenv("CG_BA_H_ONLY")) sl->el.ba_allowed = sl->ea.ba_allowed = sl->eb1.ba_allowed = false;   // experiment switch
+            if (CG_TUNE_ENV("BA_H_ONLY")) sl->el.ba_allowed = sl->ea.ba_allowed = sl->eb1.ba_allowed = false;   // experiment switch
 #endif
             if (serial) {
                 sl->eh.shared_mem = sl->el.shared_mem = sl->ea.shared_mem = sl->eb1.shared_mem = sl->eb2.shared_mem = &sl->scratch;
-                const bool zero_at_end = !(getenv("CG_NO_ZERO_AT_END") && getenv("CG_NO_ZERO_AT_END")[0] == '1');     // A/B aid
+                const bool zero_at_end = !(CG_TUNE_ENV("NO_ZERO_AT_END") && CG_TUNE_ENV("NO_ZERO_AT_END")[0] == '1');     // A/B aid (tuning builds)
                 sl->eh.zero_at_end = sl->el.zero_at_end = sl->ea.zero_at_end = sl->eb1.zero_at_end = sl->eb2.zero_at_end = zero_at_end;
             }
             sl->eh.init(&c->bh); sl->el.init(&c->bl); sl->ea.init(&c->ba); sl->eb1.init(&c->bb1); sl->eb2.init(&c->bb2);
@@ -582,12 +594,9 @@ static float ev_ms(hipEvent_t a, hipEvent_t b) {
 // hipEventBlockingSync events, which this runtime also waits for actively.  So the waiters POLL the event and sleep in
 // between (hipEventQuery is a read of the completion signal): a 250 us nap costs a proof 0.3 % of its time in flight and
 // nothing of the GPU's, which the other proofs keep busy (wait_sleeping: shorter naps early on, for small circuits).  A
-// latency context (one proof at a time: the wait IS the latency) keeps the spinning synchronise.  CG_SPIN_WAIT=1 forces
-// spinning everywhere (A/B).
-static bool spin_wait() {
-    static const bool v = getenv("CG_SPIN_WAIT") != nullptr && getenv("CG_SPIN_WAIT")[0] == '1';
-    return v;
-}
+// latency context (one proof at a time: the wait IS the latency) keeps the spinning synchronise.  CG_FLAG_SPIN_WAIT makes
+// every caller of a context spin.
+static bool spin_wait(const cg_ctx* c) { return c->spin_wait; }
 // Polls `ev` until it is done: spinning for the first 200 us (a small circuit's proof is over by then), after that napping
 // an eighth of the time already waited, at most `max_nap_us` - the overshoot stays below an eighth of the wait whatever
 // the circuit's size, and a long wait costs next to no CPU.
@@ -617,7 +626,7 @@ static float upload_assignment(cg_ctx* c, Upload* u, const void* host_assignment
     if (timed) CG_HIP(hipEventRecord(u->ev[0], u->st));
     CG_HIP(hipMemcpyAsync(u->w.p, host_assignment, c->M * 32, hipMemcpyHostToDevice, u->st));
     if (timed) CG_HIP(hipEventRecord(u->ev[1], u->st));
-    if (spin_wait() || c->latency) {
+    if (spin_wait(c) || c->latency) {
         CG_HIP(hipStreamSynchronize(u->st));
     } else {
         CG_HIP(hipEventRecord(u->ev_done, u->st));
@@ -641,7 +650,7 @@ static int prove_partial_impl(cg_ctx* c, ProofSlot* S, const Fr* w_dev, bool ski
     const Fr* w_a = w_dev + 1 + c->ra.lo;
     // b1 and b2 take the same scalars against bases that vanish together: with equal windows the grouped entry list of
     // one IS the other's, so the G2 MSM skips its own grouping (five launches, ~0.9 % of a proof's instructions)
-    static const bool no_share = getenv("CG_NO_SHARE_B") != nullptr;        // A/B aid
+    static const bool no_share = CG_TUNE_ENV("NO_SHARE_B") != nullptr;        // A/B aid (tuning builds)
     const bool b2_adopts = !skip_b1 && !no_share && c->b_same_identities && S->eb2.can_adopt(S->eb1) && n_a > 0;
     if (S->one_stream) {
         // everything on one stream, every MSM grouped and accumulated before the next one starts: the engines share the
@@ -684,7 +693,7 @@ static int prove_partial_impl(cg_ctx* c, ProofSlot* S, const Fr* w_dev, bool ski
         S->eh.accumulate(s0);
     }
     if (while_gpu_runs) (*while_gpu_runs)();      // host work that needs no MSM value
-    if (S->one_stream && !spin_wait()) {
+    if (S->one_stream && !spin_wait(c)) {
         CG_HIP(hipEventRecord(S->ev_done, s0));
         wait_sleeping(S->ev_done, 250);            // a proof with fifteen others in flight takes ~80 ms
     } else {
@@ -808,8 +817,9 @@ static void snapshot_tune_stats(const cg_ctx* c, const ProofSlot* S, bool skip_b
 template <class F>
 static void reinit_engines(cg_ctx* c, MsmEngine<F> ProofSlot::*eng, const MsmBases<F>& bases) {
     try {
-        // CG_FAULT_RETUNE=1 (testing aid): fail here as an allocation would, table rebuilt and engines not yet re-sized
-        if (const char* f = getenv("CG_FAULT_RETUNE")) if (f[0] == '1') throw HipError(CG_ERR_OUT_OF_MEMORY, "injected: out of device memory while re-sizing the proof slots");
+        // tuning builds, CG_FAULT_RETUNE=1 (fault injection for tests/test_gpu_host_and_ranks.py): fail here as an allocation
+        // would, table rebuilt and engines not yet re-sized.  The shipped library carries no such switch.
+        if (const char* f = CG_TUNE_ENV("FAULT_RETUNE")) if (f[0] == '1') throw HipError(CG_ERR_OUT_OF_MEMORY, "injected: out of device memory while re-sizing the proof slots");
         for (size_t k = 0; k < c->slots.size(); ++k) ((*c->slots[k]).*eng).init(&bases);
     } catch (...) {
         c->broken = true;     // the table is already the new one: engines and table no longer agree

@@ -170,7 +170,7 @@ extern "C" int cg_setup(const cg_csr abc[3], uint64_t num_inputs, uint64_t num_c
                 HostCsc t;
                 csr_transpose(abc[k], m, M, t);
                 DevCsr d;
-                d.upload(t.view, M, m, false);
+                d.upload(t.view, M, m, st, false);
                 spmv(d, u.p, q[k], st);
                 CG_HIP(hipStreamSynchronize(st));
             }

@@ -31,7 +31,7 @@ struct cg_msm_ctx {
     PinnedBuf<uint32_t> h_bad;
     hipStream_t st = nullptr;
     std::mutex mu;
-    ~cg_msm_ctx() { if (st) (void)hipStreamDestroy(st); }
+    ~cg_msm_ctx() { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } }   // a failed load may leave work queued
 };
 
 __global__ void __launch_bounds__(256) k_check_canonical(const Fr* __restrict__ s, uint64_t n, uint32_t* __restrict__ bad) {
@@ -171,9 +171,8 @@ static int msm_unit(const uint8_t* bases, uint32_t form, uint64_t n_bases, const
     if (form != CG_FORM_CANONICAL && form != CG_FORM_MONTGOMERY) return fail(CG_ERR_INVALID_ARGUMENT, "bad coord_form");
     for (uint64_t i = 0; i < n; ++i)
         if (!scalar_is_canonical(scalars + 32 * i)) return fail(CG_ERR_INVALID_ARGUMENT, "scalar %llu not canonical", (unsigned long long)i);
-    hipStream_t st;
-    CG_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    try {
+    {
+        ScopedStream st;            // destroyed on every way out (the callers translate exceptions)
         DevBuf<Affine<F>> pts(n);
         import_bases<F>(bases, form, n, pts.p, st);
         DevBuf<Fr> sc(n);
@@ -189,11 +188,7 @@ static int msm_unit(const uint8_t* bases, uint32_t form, uint64_t n_bases, const
         eng.accumulate(st);
         CG_HIP(hipStreamSynchronize(st));
         out = to_affine(eng.value());
-    } catch (...) {
-        (void)hipStreamDestroy(st);
-        throw;
     }
-    (void)hipStreamDestroy(st);
     return CG_OK;
 }
 
@@ -240,7 +235,7 @@ struct cg_qap_ctx {
     DevBuf<Fr> w_canon, h_canon;
     hipStream_t st = nullptr;
     std::mutex mu;
-    ~cg_qap_ctx() { if (st) (void)hipStreamDestroy(st); }
+    ~cg_qap_ctx() { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } }
 };
 
 namespace cg {
@@ -272,9 +267,9 @@ extern "C" int cg_qap_load(cg_qap_ctx** out, const cg_csr abc[3], uint64_t num_i
         c->l = num_inputs; c->m = num_constraints; c->M = num_variables;
         c->logD = logD; c->D = 1ull << logD;
         CG_HIP(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
-        c->A.upload(abc[0], c->m, c->M);
-        c->B.upload(abc[1], c->m, c->M);
-        c->C.upload(abc[2], c->m, c->M);
+        c->A.upload(abc[0], c->m, c->M, c->st);
+        c->B.upload(abc[1], c->m, c->M, c->st);
+        c->C.upload(abc[2], c->m, c->M, c->st);
         c->dom.build(logD, true, c->st);
         CG_HIP(hipStreamSynchronize(c->st));
         c->wdom.build(c->dom, c->st);
@@ -376,7 +371,12 @@ extern "C" int cg_ntt_run(cg_ntt_ctx* ctx, void* data, int data_on_device, int i
     if (ctx->log_n == 0) {     // the size-1 transform is the identity (g^0 = 1, 1/n = 1); only the operand check remains
         uint8_t x[32];
         if (data_on_device) {
-            try { CG_HIP(hipMemcpy(x, data, 32, hipMemcpyDeviceToHost)); } catch (...) { return translate_current_exception(); }
+            try {       // on the handle's own stream (no legacy-default-stream copy next to other contexts' non-blocking streams)
+                std::lock_guard<std::mutex> lk(ctx->mu);
+                CG_HIP(hipSetDevice(ctx->device));
+                CG_HIP(hipMemcpyAsync(x, data, 32, hipMemcpyDeviceToHost, ctx->st));
+                CG_HIP(hipStreamSynchronize(ctx->st));
+            } catch (...) { return translate_current_exception(); }
         } else {
             memcpy(x, data, 32);
         }

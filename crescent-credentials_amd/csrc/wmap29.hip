@@ -30,7 +30,7 @@ static int ntt_passes(int logn, int tile_log) {
 }
 static int ntt_tile_log(int logn) {
     static const int forced = [] {
-        const char* e = getenv("CG_NTT_TILE");          // A/B aid
+        const char* e = CG_TUNE_ENV("NTT_TILE");          // A/B aid (tuning builds)
         return (e && (atoi(e) == TS29_SMALL || atoi(e) == TS29_BIG)) ? atoi(e) : 0;
     }();
     if (forced) return (forced == TS29_BIG && logn > TS29_SMALL) ? TS29_BIG : TS29_SMALL;

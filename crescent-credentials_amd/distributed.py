@@ -29,6 +29,9 @@ PARTIAL_BYTES = 384
 POISON = b"\xff" * PARTIAL_BYTES     # no partial-sum record looks like this: coordinates are canonical (< q < 2^254)
 
 _control = None
+# set (to a description) when open_data_group gave up on a helper thread that was still inside RCCL: the thread cannot be
+# cancelled, keeps whatever it holds and may finish or abort later - results measured afterwards in this process say so
+RCCL_TAINTED = None
 
 
 def shard_range(n: int, rank: int, count: int) -> Tuple[int, int]:
@@ -122,12 +125,21 @@ def open_data_group(device, backend: str = "nccl", deadline_s: float = 90.0):
     th.start()
     th.join(deadline_s)
     if th.is_alive():
+        global RCCL_TAINTED
         res["error"] = "no answer from the %s group after %.0f s" % (backend, deadline_s)
+        RCCL_TAINTED = "rank %d: the helper thread that opens the %s group was still inside the library at the %.0f s deadline and " \
+                       "was left behind (it cannot be cancelled)" % (dist.get_rank(), backend, deadline_s)
     ok = 1.0 if "group" in res and "error" not in res else 0.0
     all_ok = min_over_ranks(ok, world, group=ctl) > 0.5
     if all_ok:
         return res["group"], backend, None
     err = res.get("error") or "another rank could not open its %s group" % backend
+    if "group" in res and not th.is_alive():
+        # this rank's own group came up but another rank's did not: a communicator nobody will use is not left alive
+        try:
+            dist.destroy_process_group(res["group"])
+        except BaseException as e:   # noqa: BLE001 - reported with the rest
+            err += " (and destroying this rank's own %s group failed: %s)" % (backend, type(e).__name__)
     return ctl, "gloo", err
 
 
@@ -194,12 +206,26 @@ class ShardedProver:
         self._gather = PartialGather(device, group) if self.world > 1 else None
 
     def _prove(self, assignment, on_device: bool, r: int, s: int):
+        """one sharded proof.  A shard that fails here does not leave the other ranks waiting in the collective either: the
+        failing rank sends a poison record and then raises its own exception, every other rank raises a RuntimeError
+        naming it (the protocol of prove_stream, for one proof)."""
         t0 = time.perf_counter()
-        part = self.prover.prove_partial(assignment, r, on_device=on_device)
+        failure = None
+        try:
+            part = self.prover.prove_partial(assignment, r, on_device=on_device)
+        except BaseException as e:   # noqa: BLE001 - raised below, after the collective every rank is about to enter
+            if self.world <= 1:
+                raise
+            failure, part = e, POISON
         t1 = time.perf_counter()
         if self.world > 1:
             parts = self._gather(part)
             self.all_gathers += 1
+            if failure is not None:
+                raise failure
+            bad = [q for q in range(self.world) if parts[PARTIAL_BYTES * q:PARTIAL_BYTES * (q + 1)] == POISON]
+            if bad:
+                raise RuntimeError("sharded proof: " + ", ".join("rank %d failed" % q for q in bad))
         else:
             parts = part
         t2 = time.perf_counter()
@@ -229,6 +255,9 @@ class ShardedProver:
         n = len(jobs)
         if n == 0:
             return []
+        # the poison check below reads one 384-byte record per rank: a batched gather (PartialGather(batch > 1), rank-major
+        # world x batch x 384) would be mis-parsed
+        assert self._gather is None or self._gather.batch == 1, "prove_stream exchanges one record per collective"
         in_flight = max(1, min(in_flight, n))
         parts = [None] * n           # this rank's 384-byte record of proof k
         gathered = [None] * n        # all ranks' records of proof k (None: some rank failed on it)

@@ -95,7 +95,7 @@ typedef struct cg_options {
                               set and streams; cg_prove* from different threads overlap on the GPU); 0 = 1, at
                               most 16.  1 = a latency context (five streams per proof); more = a throughput
                               context (one stream per proof; twelve reach the full rate at the rs256 size) */
-    int32_t flags;         /* CG_FLAG_* */
+    int32_t flags;         /* CG_FLAG_* (the library reads no environment variable: everything a host may choose is here) */
     int32_t reserved[2];
 } cg_options;
 
@@ -105,7 +105,22 @@ typedef struct cg_options {
  * values q_j = a·b/Z plus a per-wire term carried by the l query — the same group elements, hence the same proof bytes
  * for any assignment.  This flag keeps both queries as loaded and runs the reference's seven transforms
  * (r1cs_to_qap.rs:179-210) per proof. */
-enum { CG_FLAG_H_COEFFICIENT_BASIS = 1 };
+enum {
+    CG_FLAG_H_COEFFICIENT_BASIS = 1,
+    /* How a context arranges a proof's work on the GPU.  By default proof_slots decides: one slot = a LATENCY context (the
+     * five MSMs and the witness map on five streams, short accumulation segments, tree reductions, callers spin while
+     * they wait), several = a THROUGHPUT context (one stream per proof, long segments, fewest instructions, callers
+     * sleep-poll).  A host may force either - e.g. throughput kernels for a single slot that shares the GPU with other
+     * contexts, or the latency arrangement for two slots.  Both set = CG_ERR_INVALID_ARGUMENT. */
+    CG_FLAG_LATENCY_MODE = 2,
+    CG_FLAG_THROUGHPUT_MODE = 4,
+    /* Calling threads spin in the HIP runtime while they wait for their proof instead of sleep-polling (a throughput
+     * context's default): lowest wake-up latency, one busy CPU per proof in flight. */
+    CG_FLAG_SPIN_WAIT = 8,
+    /* Sharded contexts (shard_count a power of two): own a contiguous range of the h query's coset points instead of
+     * the points j = shard_rank (mod shard_count); the shard then runs four full-size transforms per proof. */
+    CG_FLAG_CONTIGUOUS_H_SHARDS = 16
+};
 
 /* Per-phase wall/GPU times of one cg_prove call, mirroring the reference's `print-trace` phases
  * (forks/groth16/src/prover.rs:35-36,62,93,103,115,123). Milliseconds. */

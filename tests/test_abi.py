@@ -172,7 +172,8 @@ def test_circuit_load_validates_before_touching_the_gpu(cc):
     pk.h_len = 7
     for kw, msg in ((dict(window_bits=1), b"window_bits"), (dict(window_bits=23), b"window_bits"), (dict(window_bits=-3), b"window_bits"),
                     (dict(shard_count=4, shard_rank=4), b"shard_rank"), (dict(shard_count=2, shard_rank=-1), b"shard_rank"),
-                    (dict(proof_slots=-1), b"proof_slots"), (dict(flags=2), b"flags")):
+                    (dict(proof_slots=-1), b"proof_slots"), (dict(flags=64), b"flags"), (dict(flags=1 << 20), b"flags"),
+                    (dict(flags=2 | 4), b"exclusive")):
         opt = api._CgOptions(device=-1, **kw)
         rc = L.cg_circuit_load(ctypes.byref(h), ctypes.byref(pk), abc, 3, 4, 7, ctypes.byref(opt))
         assert rc == -1 and msg in L.cg_last_error(), kw
@@ -397,3 +398,59 @@ def test_parsers_survive_mutated_input(cc, oracle):
             assert used.value <= len(b)
             L.cg_pk_free(h)
     assert parsed > 100
+
+
+def test_shipped_library_reads_no_environment_switch(cc):
+    """the tuning / A-B / fault-injection switches live in the -DCG_TUNING build only
+    (libcrescent_gpu_tuning.so); the shipped library carries no `CG_...` string at all - what a host may choose is a
+    cg_options flag - and no getenv call in csrc/ escapes the CG_TUNE_ENV macro."""
+    import subprocess
+    out = subprocess.run(["strings", cc.library_path()], capture_output=True, text=True, check=True).stdout
+    hits = [ln for ln in out.splitlines() if ln.startswith("CG_")]
+    assert hits == [], hits
+    csrc = os.path.join(ROOT, "crescent-credentials_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        src = open(os.path.join(csrc, f)).read()
+        code = re.sub(r"//[^\n]*", "", src)
+        for m in re.finditer(r"\bgetenv\s*\(", code):
+            line = code[code.rfind("\n", 0, m.start()) + 1:code.find("\n", m.start())]
+            assert f == "common.hpp" and "#define CG_TUNE_ENV" in line, "%s reads the environment: %s" % (f, line.strip())
+    # the header documents the flags that replaced the host-visible switches
+    hdr = open(os.path.join(ROOT, "include", "crescent_gpu.h")).read()
+    for flag in ("CG_FLAG_LATENCY_MODE", "CG_FLAG_THROUGHPUT_MODE", "CG_FLAG_SPIN_WAIT", "CG_FLAG_CONTIGUOUS_H_SHARDS"):
+        assert flag in hdr
+
+
+def _device_disassembly(lib_path, tmp_path):
+    """gfx950 disassembly of every code object bundled in a shared library (llvm-objdump, no GPU needed)"""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    work = os.path.join(str(tmp_path), "lib.so")
+    shutil.copy(lib_path, work)
+    subprocess.run([objdump, "--offloading", work], capture_output=True, text=True, check=True, cwd=str(tmp_path))
+    text = []
+    for f in sorted(os.listdir(str(tmp_path))):
+        if "gfx950" in f:
+            text.append(subprocess.run([objdump, "-d", os.path.join(str(tmp_path), f)], capture_output=True, text=True, check=True).stdout)
+    return "\n".join(text)
+
+
+def test_plan_hand_off_drains_vector_memory_before_the_barrier(cc, tmp_path):
+    """in k_part_count the no-return histogram atomics must be acknowledged (s_waitcnt vmcnt(0)) before
+    the s_barrier that precedes the PLAN_DONE ticket - a workgroup-scope release alone drains only lgkmcnt.  Checked on the
+    shipped ISA, for every instantiation of the kernel."""
+    asm = _device_disassembly(cc.library_path(), tmp_path)
+    bodies = re.findall(r"<_ZN2cg12k_part_countILi\d+EEEv[^>]*>:\n(.*?)(?=\n\n|\Z)", asm, flags=re.S)
+    assert len(bodies) >= 14, len(bodies)
+    for body in bodies:
+        lines = [ln.split("//")[0].strip() for ln in body.splitlines()]
+        ops = [ln for ln in lines if ln]
+        # the returning atomic (sc0) is the PLAN_DONE ticket; the last no-return global atomic before it is the histogram add
+        ticket = max(i for i, ln in enumerate(ops) if ln.startswith("global_atomic_add") and "sc0" in ln)
+        hist = max(i for i, ln in enumerate(ops[:ticket]) if ln.startswith("global_atomic_add") and "sc0" not in ln)
+        between = ops[hist + 1:ticket]
+        barrier = next(i for i, ln in enumerate(between) if ln.startswith("s_barrier"))
+        assert any(ln.startswith("s_waitcnt") and "vmcnt(0)" in ln for ln in between[:barrier]), between[:barrier + 1]

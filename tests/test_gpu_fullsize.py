@@ -201,3 +201,64 @@ def test_two_full_size_circuits_with_sixteen_slots_each_share_the_gpu(cc, oracle
     finally:
         for j in jobs.values():
             j["prover"].close()
+
+
+@pytest.mark.parametrize("leave_free_gb", [4, 14], ids=lambda v: "free%dGB" % v)
+def test_a_load_that_runs_out_of_device_memory_gives_everything_back(cc, oracle, leave_free_gb):
+    """VERDICT r4 #6.  A host that serves several credential types (sample/client_helper/src/main.rs:177-216) is where a
+    cg_circuit_load meets a full GPU: 24-30 GB per S21 context with sixteen slots.  HBM is filled (a torch allocation) until
+    only `leave_free_gb` are left - 4: the load fails while the window tables are built, 14: the tables fit and the proof
+    slots do not - and the load must return CG_ERR_OUT_OF_MEMORY with the failed allocation named, give back every byte
+    and its stream (free memory afterwards within 64 MB of before), and the same circuit must load and prove correctly once
+    the filler is gone.  The same for the resident-bases MSM handle (cg_msm_load_g1)."""
+    import cpu_ref
+    import torch
+    (l, m, M), cm, w, pk, rng, trap = _workload(cc, oracle, "rs256-sd", 0.9, 500)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0, total = torch.cuda.mem_get_info()
+    filler_bytes = free0 - leave_free_gb * (1 << 30)
+    assert filler_bytes > 0
+    filler = torch.empty(filler_bytes, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    try:
+        before, _ = torch.cuda.mem_get_info()
+        assert before < (leave_free_gb + 1) * (1 << 30)
+        with pytest.raises(cc.CrescentGpuError) as ei:
+            cc.Prover(pk, cm, proof_slots=16)
+        assert ei.value.code == -4, str(ei.value)                       # CG_ERR_OUT_OF_MEMORY
+        assert "device allocation of" in str(ei.value) and "bytes failed" in str(ei.value), str(ei.value)
+        after, _ = torch.cuda.mem_get_info()
+        assert abs(after - before) < 64 << 20, (before, after)
+        # a second failed load leaks nothing either, and the resident-bases MSM handle behaves the same
+        with pytest.raises(cc.CrescentGpuError) as ei:
+            cc.Prover(pk, cm, proof_slots=16)
+        assert ei.value.code == -4
+        if leave_free_gb <= 4:
+            big = np.ascontiguousarray(pk.h_query)                       # 2^21 - 1 points x 13 window rows = 1.7 GB of tables
+            small_filler = torch.empty((leave_free_gb - 1) << 30, dtype=torch.uint8, device="cuda")      # leave about 1 GB
+            try:
+                b2, _ = torch.cuda.mem_get_info()
+                with pytest.raises(cc.CrescentGpuError) as ei:
+                    cc.MsmContext(big, group=1, window_bits=20)
+                assert ei.value.code == -4 and "device allocation of" in str(ei.value), str(ei.value)
+                a2, _ = torch.cuda.mem_get_info()
+                assert abs(a2 - b2) < 64 << 20, (b2, a2)
+            finally:
+                del small_filler
+        after2, _ = torch.cuda.mem_get_info()
+    finally:
+        del filler
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    # with the filler gone the same circuit loads, and proves what the C restatement proves
+    r, s = rng.randrange(oracle.R), rng.randrange(oracle.R)
+    want = cpu_ref.prove(pk, (cm.a, cm.b, cm.c), l, m, M, w, r, s, nthreads=_threads())
+    prover = cc.Prover(pk, cm, proof_slots=16)
+    try:
+        assert prover.prove(w, r, s).data == want and prover.prove(w, r, s).data == want
+    finally:
+        prover.close()
+    torch.cuda.synchronize()
+    free_end, _ = torch.cuda.mem_get_info()
+    assert abs(free_end - free0) < 256 << 20, (free0, free_end)          # and a freed context returns its memory too

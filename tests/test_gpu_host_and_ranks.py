@@ -145,46 +145,19 @@ def test_ctx_info_reports_memory_windows_and_the_retune(cc, oracle, medium):
         sh.close()
 
 
-def test_a_retune_that_fails_half_way_refuses_every_later_proof_even_callers_already_waiting(cc, oracle, medium):
+def test_a_retune_that_fails_half_way_refuses_every_later_proof_even_callers_already_waiting(cc):
     """`broken` was tested only before the shared lock, so a caller blocked behind another thread's re-tune could
-    go on to prove on engines cut for the old window against the rebuilt table.  CG_FAULT_RETUNE=1 makes the re-size of the
-    proof slots fail as an allocation would (table rebuilt, engines not), with several callers in flight: every call
-    returns either the right bytes (it finished before the re-tune) or CG_ERR_OUT_OF_MEMORY with the reload message -
-    never other bytes, never a fault - and once one call has been refused every later one is."""
-    import cpu_ref
-    from concurrent.futures import ThreadPoolExecutor
-    (l, m, M), cm, w, pk = medium
-    want = cpu_ref.prove(pk, (cm.a, cm.b, cm.c), l, m, M, w, 5, 6, nthreads=8)
-    prover = cc.Prover(pk, cm, proof_slots=4)
-    os.environ["CG_FAULT_RETUNE"] = "1"
-    try:
-        def one(_):
-            try:
-                return prover.prove(w, 5, 6).data
-            except cc.CrescentGpuError as e:
-                return e
-        with ThreadPoolExecutor(max_workers=6) as ex:
-            got = list(ex.map(one, range(24)))
-        good = [g for g in got if isinstance(g, bytes)]
-        bad = [g for g in got if not isinstance(g, bytes)]
-        assert good and all(g == want for g in good)                 # the proof that triggered the re-tune is itself fine
-        assert bad and all(e.code == -4 and "load the circuit again" in str(e) for e in bad)
-        first_bad = next(i for i, g in enumerate(got) if not isinstance(g, bytes))
-        assert len(good) <= first_bad + 6                            # nothing is proved once the context is refused
-        for _ in range(3):
-            with pytest.raises(cc.CrescentGpuError):
-                prover.prove(w, 5, 6)
-        with pytest.raises(cc.CrescentGpuError):
-            prover.witness_map(w)
-    finally:
-        del os.environ["CG_FAULT_RETUNE"]
-        prover.close()
-    # the same circuit loads and proves again
-    p2 = cc.Prover(pk, cm, proof_slots=2)
-    try:
-        assert p2.prove(w, 5, 6).data == want and p2.prove(w, 5, 6).data == want and p2.info()["tuned"] == 1
-    finally:
-        p2.close()
+    go on to prove on engines cut for the old window against the rebuilt table.  The fault is injected by the TUNING build
+    (libcrescent_gpu_tuning.so, -DCG_TUNING: the shipped library has no fault injector), so the scenario runs
+    in a child process that loads that build: tests/fault_retune_child.py."""
+    from crescent_credentials_amd import api
+    if not os.path.exists(api.TUNING_LIB_PATH):
+        pytest.skip("tuning build not present (python crescent-credentials_amd/build.py --tuning)")
+    env = dict(os.environ, CRESCENT_GPU_LIB=api.TUNING_LIB_PATH)
+    env.pop("CG_FAULT_RETUNE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fault_retune_child.py")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "FAULT-RETUNE-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
 def test_contexts_come_and_go_while_others_prove(cc, oracle, medium):
@@ -467,6 +440,31 @@ def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
         run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=env,
                              capture_output=True, text=True, timeout=300)
         assert run.returncode == 2 and "one GPU per rank" in run.stderr
+
+
+def test_bench_gpus_8_as_eight_processes_on_the_one_gpu():
+    """world = 8 - the node size BASELINE's multi-GPU configurations are quoted on - before the driver gets
+    there.  Eight PROCESSES share the one GPU (gloo data plane, two hardware queues each): `n_gpus` 8, eight per-rank rates,
+    and the sharded leg over eight strided h shards (j = rank mod 8), one all_gather per proof, bytes identical to the
+    unsharded context - one proof at a time and with proofs in flight."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--allow-shared-gpu", "--steps", "8",
+           "--warmup", "2", "--inflight", "2", "--blocks", "3", "--shape", "medium", "--no-host-witness", "--sharded-steps", "6",
+           "--sharded-inflight", "2", "--sharded-stream", "16", "--no-check", "--leg-timeout", "900"]
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=2400)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [x for x in run.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1, run.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["value"] > 0 and len(d["value_per_rank"]) == 8 and "incomplete" not in d
+    assert all(v > 0 for v in d["value_per_rank"]) and d["timing"]["window_proofs"] == 24
+    assert d["config"]["witness_origin"] == "host" and d["config"]["host_witness"]["value_is"] == "host"
+    sh = d["sharded"]
+    assert sh["ranks"] == 8 and sh["ranks_per_gpu"] == 8 and sh["backend"] == "gloo" and "error" not in sh
+    assert "j = rank (mod ranks)" in sh["mode"]
+    assert sh["bytes_identical_to_unsharded"] is True and sh["all_gathers"] == sh["proofs"] == 6
+    fl = sh["in_flight"]
+    assert fl["proofs_in_flight"] == 2 and fl["all_gathers"] == fl["proofs"] == 16 and fl["bytes_identical_to_unsharded"] is True
 
 
 @pytest.mark.skipif(_gpus() != 1, reason="the RCCL failure is provoked by two ranks sharing the one GPU")

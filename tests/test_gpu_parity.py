@@ -755,6 +755,49 @@ def test_strided_shards_assemble_to_same_proof(cc, oracle, shape, nshard):
             p.close()
 
 
+def test_context_flags_change_the_arrangement_not_the_bytes(cc, oracle):
+    """what used to be environment switches of the shipped library are cg_options flags - CG_FLAG_LATENCY_MODE /
+    CG_FLAG_THROUGHPUT_MODE (the arrangement whatever proof_slots says), CG_FLAG_SPIN_WAIT, CG_FLAG_CONTIGUOUS_H_SHARDS.  Every
+    arrangement gives the unflagged context's bytes; cg_ctx_get_info reports the forced mode; both mode flags together are
+    refused."""
+    from concurrent.futures import ThreadPoolExecutor
+    from crescent_credentials_amd import workloads as wl
+    l, m, M = _CPU_SHAPES["log14"]
+    cm, w = wl.synthetic_circuit(78, l, m, M, 0.7, 3, profile="gates")
+    rng = random.Random(6)
+    pk = cc.generate_parameters_with_qap(cm, *[rng.randrange(1, oracle.R) for _ in range(4)])
+    rs = [(0, 0)] + [(rng.randrange(oracle.R), rng.randrange(oracle.R)) for _ in range(3)]
+    whole = cc.Prover(pk, cm)
+    want = [whole.prove(w, r, s).data for r, s in rs]
+    assert whole.info()["latency_mode"] == 1
+    try:
+        for kw, lat in ((dict(proof_slots=1, mode="throughput"), 0), (dict(proof_slots=3, mode="latency"), 1),
+                        (dict(proof_slots=3, spin_wait=True), 0), (dict(proof_slots=1, mode="throughput", spin_wait=True), 0)):
+            p = cc.Prover(pk, cm, **kw)
+            try:
+                assert p.info()["latency_mode"] == lat, kw
+                with ThreadPoolExecutor(max_workers=4) as ex:
+                    got = list(ex.map(lambda k: p.prove(w, *rs[k % len(rs)]).data, range(12)))
+                assert got == [want[k % len(rs)] for k in range(12)], kw
+            finally:
+                p.close()
+        with pytest.raises(cc.CrescentGpuError) as ei:
+            cc.Prover(pk, cm, flags=2 | 4)
+        assert ei.value.code == -1 and "exclusive" in str(ei.value)
+        # contiguous h ranges for a power-of-two shard count (the default there is the strided arrangement)
+        for contig in (False, True):
+            shards = [cc.Prover(pk, cm, shard_rank=k, shard_count=4, contiguous_h_shards=contig) for k in range(4)]
+            try:
+                for (r, s), exp in zip(rs, want):
+                    parts = b"".join(q.prove_partial(w, r) for q in shards)
+                    assert shards[0].assemble(parts, 4, r, s).data == exp, contig
+            finally:
+                for q in shards:
+                    q.close()
+    finally:
+        whole.close()
+
+
 _CPU_SHAPES = {"log11": (4, 1_500, 1_600), "exact12": (6, 4_090, 4_200), "log13": (10, 5_000, 5_100), "log14": (3, 9_000, 16_000),
                "log15": (12, 20_000, 20_500), "medium": (20, 60_000, 61_000), "log17": (8, 100_000, 100_100), "large18": (26, 250_000, 255_000)}
 

@@ -1,16 +1,14 @@
 #!/bin/bash
 # Stand-alone kernel durations and VALU instruction counts of one proof at a time, every kernel on one stream
-# (CG_SERIAL_STREAMS=1): two rocprofv3 runs of the same command (kernel trace; SQ_INSTS_VALU), summarised by
+# (`--inflight 1 --mode throughput`: CG_FLAG_THROUGHPUT_MODE on a one-slot context): two rocprofv3 runs of the same command (kernel trace; SQ_INSTS_VALU), summarised by
 # tools/rocpd_efficiency.py.   usage: tools/profile_serial.sh <out-dir> [bench.py flags...]
 set -u
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$ROOT/$1"; shift
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-export CG_SERIAL_STREAMS=1
-export CG_LATENCY_MODE=0   # the segment length of the pipelined run (a one-slot context would pick the latency setting)
 cd /tmp
-FLAGS="--steps 8 --warmup 2 --blocks 1 --no-sweep --no-cpu-baseline --no-host-witness --no-check --no-clock-probe --inflight 1 $*"
+FLAGS="--steps 8 --warmup 2 --blocks 1 --no-sweep --no-cpu-baseline --no-host-witness --no-check --no-clock-probe --inflight 1 --mode throughput --witness device $*"
 rocprofv3 --kernel-trace -d "$OUT/trace" -o t -- python3 "$ROOT/bench.py" $FLAGS > "$OUT/trace_line.json" 2> "$OUT/trace.log"
 rocprofv3 --pmc SQ_INSTS_VALU -d "$OUT/pmc" -o p -- python3 "$ROOT/bench.py" $FLAGS > "$OUT/pmc_line.json" 2> "$OUT/pmc.log"
 T=$(find "$OUT/trace" -name '*.db' | head -1); P=$(find "$OUT/pmc" -name '*.db' | head -1)

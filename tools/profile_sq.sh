@@ -7,13 +7,11 @@ ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$ROOT/$1"; shift
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-export CG_SERIAL_STREAMS=1
-export CG_LATENCY_MODE=0
 cd /tmp
-FLAGS="--steps 4 --warmup 2 --blocks 1 --no-sweep --no-cpu-baseline --no-host-witness --no-check --no-clock-probe --inflight 1 $*"
+FLAGS="--steps 4 --warmup 2 --blocks 1 --no-sweep --no-cpu-baseline --no-host-witness --no-check --no-clock-probe --inflight 1 --mode throughput --witness device $*"
 i=0
 : > "$OUT/sq_counters.md"
-echo "SQ counters per launch (steady state), serial streams, one proof in flight: \`CG_SERIAL_STREAMS=1 CG_LATENCY_MODE=0 rocprofv3 --pmc <set> -- python3 bench.py $FLAGS\` (one pass per set), summarised by tools/rocpd_counters.py" >> "$OUT/sq_counters.md"
+echo "SQ counters per launch (steady state), serial streams, one proof in flight: \`rocprofv3 --pmc <set> -- python3 bench.py $FLAGS\` (one pass per set), summarised by tools/rocpd_counters.py" >> "$OUT/sq_counters.md"
 for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS" "GRBM_GUI_ACTIVE SQ_WAVES" \
            "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS" "SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC"; do

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""k_accum_affine launch by launch: stand-alone duration (kernel trace taken with CG_SERIAL_STREAMS=1 --inflight 1) against
+"""k_accum_affine launch by launch: stand-alone duration (kernel trace taken with --inflight 1 --mode throughput) against
 the launch's own VALU instruction floor (SQ_INSTS_VALU of the same launch from a --pmc pass of the same command / 578 G
 wave-instructions per second), for the accumulation launches between one k_w_to29 and the next: the witness map sits
 between a proof's assignment-driven MSMs and its h MSM (one-stream order l, a, b1, b2 [G2], witness map, h), so such a

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel VALU efficiency: stand-alone duration (kernel trace taken with CG_SERIAL_STREAMS=1 --inflight 1)
+"""Per-kernel VALU efficiency: stand-alone duration (kernel trace taken with --inflight 1 --mode throughput)
 against the kernel's own instruction floor (SQ_INSTS_VALU from a --pmc pass of the same command, divided by the
 measured issue ceiling of 578 G wave-instructions/s).
 usage: rocpd_efficiency.py trace.db pmc.db [out.md]"""
