@@ -86,6 +86,22 @@ CG_HD Affine29<Fq29> load_table_point_lazy_y(const uint32_t* __restrict__ table,
     return a;
 }
 
+// the signed accumulation's form: both coordinates as stored (the digit's sign is applied inside madd29s, as a multiplier)
+CG_HD Affine29<Fq29> load_table_point_plain(const uint32_t* __restrict__ table, uint32_t idx) {
+    constexpr int AFF = Words29<Fq29>::AFF;
+    const uint4* p = reinterpret_cast<const uint4*>(table + (size_t)idx * AFF);
+    uint32_t w[AFF];
+#pragma unroll
+    for (int i = 0; i < AFF / 4; ++i) {
+        uint4 v = p[i];
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+    Affine29<Fq29> a;
+    load_coord(a.x, w);
+    load_coord(a.y, w + AFF / 2);
+    return a;
+}
+
 // the same in two steps, so that the (random, HBM-latency) read can be issued an iteration early
 template <class F>
 struct RawPoint29 {
@@ -230,6 +246,82 @@ CG_HD void madd29(XYZZ29<F>& acc, bool& inf, const Affine29<F>& p) {
     acc.x = X3;
     acc.zz = ZZ3;
     acc.zzz = ZZZ3;
+}
+
+// ---- the same mixed addition on SIGNED limbs (field29.hpp S29): the G1 bucket accumulation's inner loop -----------------
+// The running accumulator of a lane stays in this form from one entry to the next and is converted to the stored
+// (unsigned) invariant only when a run is flushed (acc_to_stored).  It carries
+//     x, sy, zz, zzz  s-normalised,   t = +-1   with   Y = t·sy,
+// and every subtraction of madd-2008-s is either fused into the product that precedes it or a limb-wise difference:
+//     u   = sigma·t                                  (sigma = -1 for a negated table point)
+//     P   = zz·px - x                                 fused                                   U2 - X1
+//     R*  = zzz·py - u·sy                             fused, the per-lane u as the multiplier  = sigma·(S2 - Y1)
+//     X3  = R*² - PPP - 2Q                            fused
+//     sy3 = R*·(u·(X3 - Q)) + sy·PPP,  t3 = -t        Y3 = R·(Q - X3) - Y1·PPP = -t·sy3: the sign flips instead of a negation
+// Bounds (tools/bounds29.py, "signed accumulator"): 0 <= zz < 1.05 N, -0.01 N < zzz < 1.01 N, -3.5 N < x < 1.2 N, |sy| < 1.2 N;
+// P in (-1.3 N, 4.6 N), |R*| < 2.3 N, PP < 1.2 N, |PPP| < 1.1 N, |Q| < 1.1 N; every multiplicand limb is below 2^29 in
+// magnitude except the limb-wise difference X3 - Q (below 2^29 as well: both are s-normalised).
+struct G1AccS {
+    Fq29s x, sy, zz, zzz;
+    int32_t t;
+};
+// neg1, neg2: the constants -1 and -2 held OPAQUE (a kernel keeps them in SGPRs the optimiser cannot see through), so that
+// "c -= x" stays the one v_mad_i64_i32 it is written as instead of becoming a two-instruction 64-bit subtraction
+CG_HD void madd29s(G1AccS& acc, bool& inf, const Affine29<Fq29>& p, int32_t sigma, int32_t neg1, int32_t neg2) {
+    typedef Fq29P P;
+    const Fq29s px = Fq29s::from_unsigned(p.x), py = Fq29s::from_unsigned(p.y);
+    if (inf) {
+        acc.x = px; acc.sy = py; acc.zz = Fq29s::one(); acc.zzz = Fq29s::one(); acc.t = sigma;
+        inf = false;
+        return;
+    }
+    const int32_t u = sigma * acc.t;
+    const Fq29s Pd = mul_s(acc.zz, px, FuseMul1<P>{acc.x, neg1});
+    const Fq29s PP = sqr_s(Pd);
+    const Fq29s ZZ3 = mul_s(acc.zz, PP);
+    if (is_zero_mod(ZZ3)) {                      // P ≡ 0: same x.  Rare (repeated base / s and r-s).
+        const Fq29s R0 = mul_s(acc.zzz, py, FuseMul1<P>{acc.sy, -u});
+        if (is_zero_mod(canonical(to_unsigned<4>(R0)))) {       // same point: double it (the unsigned formulas; rare)
+            Affine29<Fq29> q = p;
+            if (sigma < 0) q.y = normalize(sub<2, 1>(Fq29::zero(), p.y));
+            const XYZZ29<Fq29> d2 = dbl_affine29(q);
+            // made canonical (below N): inside the signed accumulator's intervals whatever the unsigned formulas' bounds are
+            acc.x = Fq29s::from_unsigned(canonical(d2.x)); acc.sy = Fq29s::from_unsigned(canonical(d2.y));
+            acc.zz = Fq29s::from_unsigned(canonical(d2.zz)); acc.zzz = Fq29s::from_unsigned(canonical(d2.zzz)); acc.t = 1;
+        } else {
+            inf = true;
+        }
+        return;
+    }
+    const Fq29s Q = mul_s(acc.x, PP);
+    const Fq29s PPP = mul_s(Pd, PP);
+    const Fq29s Rs = mul_s(acc.zzz, py, FuseMul1<P>{acc.sy, -u});
+    const Fq29s ZZZ3 = mul_s(acc.zzz, PPP);
+    const Fq29s X3 = sqr_s(Rs, FuseMul2<P>{PPP, neg1, Q, neg2});
+    // d = u·(X3 - Q) limb-wise.  With um = 0 / -1 for u = +1 / -1:  u·(a - b) = (a ^ um) + (b ^ ~um) + 1  - two v_xad_u32 per
+    // limb (a 32-bit multiplication by u would be a quarter-rate v_mul_lo)
+    const uint32_t um = (uint32_t)(u >> 31), un = ~um;
+    Fq29s d;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) d.l[i] = (int32_t)(((uint32_t)X3.l[i] ^ um) + (((uint32_t)Q.l[i] ^ un) + 1u));
+    acc.sy = mul2_s(Rs, d, acc.sy, PPP);
+    acc.t = -acc.t;
+    acc.x = X3;
+    acc.zz = ZZ3;
+    acc.zzz = ZZZ3;
+}
+// the signed running accumulator -> the stored invariant (X < 13 N, Y < 8 N, ZZ, ZZZ < 3 N, normalised, non-negative)
+CG_HD XYZZ29<Fq29> acc_to_stored(const G1AccS& a) {
+    XYZZ29<Fq29> r;
+    r.x = to_unsigned<4>(a.x);                       // (-3.5 N, 1.2 N) + 4 N
+    Fq29s y;
+    const int32_t tm = a.t >> 31;                    // 0 / -1
+#pragma unroll
+    for (int i = 0; i < 9; ++i) y.l[i] = (a.sy.l[i] ^ tm) - tm;      // t·sy limb-wise
+    r.y = to_unsigned<2>(y);                         // (-1.2 N, 1.2 N) + 2 N
+    r.zz = to_unsigned<0>(a.zz);                     // non-negative as it is
+    r.zzz = to_unsigned<1>(a.zzz);                   // (-0.01 N, 1.01 N) + N: a product's negative side is a hundredth of N
+    return r;
 }
 
 // acc += q (both XYZZ under the stored invariant)   (add-2008-s)

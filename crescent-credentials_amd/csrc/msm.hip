@@ -22,6 +22,7 @@
 #include "g2pair.hpp"
 
 #include <cstring>
+#include <type_traits>
 
 namespace cg {
 
@@ -247,8 +248,16 @@ __device__ __forceinline__ void for_each_digit(const uint32_t s[8], int c, int W
 // The same walk with the window size known at compile time: every digit's limb index and shift are constants, so a digit
 // costs one funnel shift, the mask, the carry and the sign - no bit buffer, no refills, no dynamic limb selection (the
 // generic walk spends ~40 instructions per digit, most of them on those).  The walk still ends where the scalar does.
+template <int I, int N, class Fn>
+__device__ __forceinline__ void static_for(Fn&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+// (The walk is unrolled by template recursion, so every limb index below is a literal.)
 template <int C, class Fn>
-__device__ __forceinline__ void for_each_digit_c(const uint32_t s[8], Fn f) {
+__device__ __forceinline__ void for_each_digit_c(const uint32_t (&s)[8], Fn f) {
     constexpr int W = (SCALAR_BITS + C - 1) / C;
     constexpr uint32_t mask = (1u << C) - 1u, half = 1u << (C - 1);
     int hl = -1;
@@ -261,18 +270,30 @@ __device__ __forceinline__ void for_each_digit_c(const uint32_t s[8], Fn f) {
     if (hl < 0) return;
     const int topbit = hl * 32 + 31 - __clz((int)top);         // index of the scalar's highest set bit
     uint32_t carry = 0;
-#pragma unroll
-    for (int j = 0; j < W; ++j) {
-        const int bit = C * j, lo = bit >> 5, sh = bit & 31;
-        if (bit > topbit && carry == 0) break;                  // nothing left above this window
-        uint64_t v = lo < 8 ? s[lo] : 0u;
-        if (lo + 1 < 8) v |= (uint64_t)s[lo + 1] << 32;
-        const uint32_t raw = ((uint32_t)(v >> sh) & mask) + carry;
+    bool live = true;
+    static_for<0, W>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int bit = C * j, lo = bit >> 5, sh = bit & 31;
+        if (!live) return;
+        if (bit > topbit && carry == 0) { live = false; return; }      // nothing left above this window
+        // the window's bits lie in limb lo and, when it straddles, limb lo + 1: one funnel shift (v_alignbit_b32) of the two
+        // limbs.  Rounds 2-4 wrote it as `(s[lo] | (uint64_t)s[lo + 1] << 32) >> sh`: the optimiser merges the two adjacent
+        // 4-byte reads into one 8-byte read at offset 4·lo of the scalar, an access the pass that moves small arrays into
+        // registers does not split, so the four scalars of a thread stayed in SCRATCH in every level-1 kernel but the
+        // C = 16 one: 144 bytes per thread, 230 MB written and read back per proof
+        // (profiles/r04_n_hbm_write_per_proof_gates.md; `.private_segment_fixed_size` is 0 now, tests/test_abi.py)
+        uint32_t w = 0;
+        if constexpr (lo < 8) {
+            if constexpr (sh == 0) w = s[lo];
+            else if constexpr (lo + 1 < 8) w = __builtin_amdgcn_alignbit(s[lo + 1], s[lo], sh);
+            else w = s[lo] >> sh;
+        }
+        const uint32_t raw = (w & mask) + carry;
         int32_t d;
         if (raw > half) { d = (int32_t)raw - (int32_t)(1u << C); carry = 1; }
         else { d = (int32_t)raw; carry = 0; }
         f(j, d);
-    }
+    });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -309,6 +330,23 @@ struct PartShape {
     int bits1, bits2;      // key bits taken by level 1 (high) and level 2 (low; 0 = single level)
     int staged;            // host side only: level-1 placement through the LDS staging area (latency contexts)
 };
+
+// A scalar's eight words as eight VALUES.  (`Fr sc = ok ? scalars[i] : Fr::zero()` is a 32-byte copy from one of two
+// addresses; the optimiser keeps such an object in memory, and every level-1 kernel instantiated for a window size carried
+// 144 bytes of scratch per thread for its four scalars - 230 MB written and read back per proof, profiles/
+// r04_n_hbm_write_per_proof_gates.md.  Two 16-byte loads into named words stay in registers.)
+__device__ __forceinline__ Fr load_scalar_or_zero(const Fr* __restrict__ scalars, uint32_t i, bool ok) {
+    uint4 a = make_uint4(0u, 0u, 0u, 0u), b = a;
+    if (ok) {
+        const uint4* p = reinterpret_cast<const uint4*>(scalars + i);
+        a = p[0];
+        b = p[1];
+    }
+    Fr r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
 
 // C = the window size when the kernel was instantiated for it, 0 = taken from the shape at run time
 template <int C, class Fn>
@@ -351,18 +389,18 @@ __global__ void __launch_bounds__(PART_THREADS) k_part_count(PartShape sh, const
     for (int u = 0; u < PER; ++u) {
         const uint32_t i = base + u * PART_THREADS + threadIdx.x;
         ok[u] = i < sh.n && valid[i] != 0;
-        sc[u] = ok[u] ? scalars[i] : Fr::zero();
+        sc[u] = load_scalar_or_zero(scalars, i, ok[u]);
     }
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        if (!ok[u]) continue;
+    static_for<0, PER>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        if (!ok[u]) return;
         bool any = false;
         for_each_entry<C>(sh, sc[u], base + u * PART_THREADS + threadIdx.x, [&](uint32_t key, uint32_t) {
             atomicAdd(&lds[key >> sh.bits2], 1u);
             any = true;
         });
         nonzero += any;
-    }
+    });
     // one atomic per block: same-address atomics serialise at ~10 ns each
     __shared__ uint32_t nz_block;
     if (threadIdx.x == 0) nz_block = 0;
@@ -488,17 +526,17 @@ __global__ void __launch_bounds__(PART_THREADS) k_part_place(PartShape sh, const
     for (int u = 0; u < PER; ++u) {
         const uint32_t i = base + u * PART_THREADS + threadIdx.x;
         ok[u] = i < sh.n && valid[i] != 0;
-        sc[u] = ok[u] ? scalars[i] : Fr::zero();
+        sc[u] = load_scalar_or_zero(scalars, i, ok[u]);
     }
     __syncthreads();
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        if (!ok[u]) continue;
+    static_for<0, PER>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        if (!ok[u]) return;
         for_each_entry<C>(sh, sc[u], base + u * PART_THREADS + threadIdx.x, [&](uint32_t key, uint32_t val) {
             const uint32_t pos = atomicAdd(&lds[key >> sh.bits2], 1u);
             out[pos] = ((uint64_t)key << 32) | val;
         });
-    }
+    });
 }
 
 // Level-1 placement staged through LDS, for the wide windows (C >= 18: at most 15 digits per scalar).  k_part_place hands every
@@ -766,6 +804,59 @@ __global__ void __launch_bounds__(256) CG_ACCUM_ATTR k_accum_affine(const uint64
     }
 }
 
+// ---- G1 on SIGNED limbs (round 5): the kernel the prove path runs ---------------------------------------------------------
+// The same walk with the lane's running accumulator in the signed form of curve29.hpp (G1AccS / madd29s): the differences
+// of the mixed addition are fused into the products that precede them, the sign of a digit enters as a multiplier instead
+// of a negated y, and the sign of Y flips instead of being subtracted - ~140 of the ~2180 instructions of an addition go.
+// A run is converted to the stored (unsigned) invariant only when it is flushed, so the pieces and buckets every later
+// kernel reads are what k_accum_affine<Fq29> writes.
+__global__ void __launch_bounds__(256) CG_ACCUM_ATTR k_accum_affine_g1s(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ plan,
+                                                          const uint32_t* __restrict__ table,
+                                                          uint32_t* __restrict__ bucket_sums, uint32_t* __restrict__ part_keys,
+                                                          uint32_t* __restrict__ part_pts) {
+    typedef Fq29 F29T;
+    constexpr int ACC = Words29<F29T>::ACC;
+    const uint32_t N = plan[PLAN_N], L = plan[PLAN_L], T = plan[PLAN_T];
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    // -1 and -2 as values the optimiser cannot see through: "column -= limb" stays one v_mad_i64_i32 (limb, -1, column)
+    int32_t neg1 = -1, neg2 = -2;
+    asm volatile("" : "+s"(neg1), "+s"(neg2));
+    const bool final_level = (T == 1);
+    uint32_t beg = t * L;
+    uint32_t end = beg + L < N ? beg + L : N;
+    G1AccS acc;
+    bool inf = true;
+    uint64_t next_ent = entries[beg];                  // fetched an iteration ahead (see k_accum_affine)
+    uint32_t cur = (uint32_t)(next_ent >> 32);
+    bool first = true;
+    for (uint32_t k = beg; k < end; ++k) {
+        const uint64_t ent = next_ent;
+        if (k + 1 < end) next_ent = entries[k + 1];
+        const uint32_t key = (uint32_t)(ent >> 32), v = (uint32_t)ent;
+        if (key != cur) {
+            flush_run(cur, acc_to_stored(acc), inf, first, final_level, t, bucket_sums, part_keys, part_pts);
+            first = false;
+            inf = true;
+            cur = key;
+        }
+        const Affine29<F29T> p = load_table_point_plain(table, v & 0x7fffffffu);
+        madd29s(acc, inf, p, (int32_t)v >> 31 | 1, neg1, neg2);       // sigma = -1 for a negative digit, +1 otherwise
+    }
+    const XYZZ29<F29T> st = acc_to_stored(acc);
+    if (final_level) {
+        store_acc(bucket_sums + (size_t)cur * ACC, st, inf);
+    } else if (first) {  // the whole segment is one run
+        part_keys[2 * t] = cur;
+        store_acc(part_pts + (size_t)(2 * t) * ACC, st, inf);
+        part_keys[2 * t + 1] = cur;
+        store_acc(part_pts + (size_t)(2 * t + 1) * ACC, st, true);
+    } else {
+        part_keys[2 * t + 1] = cur;
+        store_acc(part_pts + (size_t)(2 * t + 1) * ACC, st, inf);
+    }
+}
+
 // ---- the same over Fq2 with the accumulator in LDS -------------------------------------------------------------------
 // An Fq2 XYZZ accumulator is 72 VGPRs; held in registers next to the point and the temporaries of a mixed addition
 // it pushes the kernel past 400 VGPRs (one wave per SIMD, spills).  Here the running accumulator lives in LDS
@@ -969,8 +1060,12 @@ static void launch_accum_affine(const uint64_t* entries, const uint32_t* plan, u
     if constexpr (Words29<F29T>::NF == 2) {
         if (!g2_pair_kernel(latency_mode)) k_accum_affine_g2<<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
         else k_accum_affine_g2_pair<<<ceil_div(2ull * T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
-    } else
-        k_accum_affine<F29T><<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
+    } else {
+        // (tuning builds: CG_ACCUM_UNSIGNED=1 runs round 4's kernel on unsigned limbs - the A/B reference)
+        static const bool unsigned_ref = CG_TUNE_ENV("ACCUM_UNSIGNED") != nullptr && CG_TUNE_ENV("ACCUM_UNSIGNED")[0] == '1';
+        if (unsigned_ref) k_accum_affine<F29T><<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
+        else k_accum_affine_g1s<<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
+    }
 }
 
 template <class F29T>

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 
 #include "../../crescent-credentials_amd/csrc/curve29.hpp"
 
@@ -214,7 +215,111 @@ static void test_curve(const char* name) {
     printf("%s curve ok\n", name);
 }
 
+// ---- the signed-limb mixed addition of the G1 bucket accumulation (curve29.hpp madd29s) ----------------------------------
+static void check_s_normalised(const Fq29s& f, double lo, double hi, const char* what) {
+    for (int i = 0; i < 8; ++i) CHECK(f.l[i] >= 0 && (uint32_t)f.l[i] <= M29, what);
+    const double v = (double)f.l[8] / (double)0x30644e;          // value / N, to a hundredth
+    CHECK(v >= lo - 0.02 && v <= hi + 0.02, what);
+}
+static void test_signed_field() {
+    const int32_t neg1 = -1, neg2 = -2;
+    for (int it = 0; it < 20000; ++it) {
+        Fq a = rand_canon<FqP>(), b = rand_canon<FqP>(), c = rand_canon<FqP>(), e = rand_canon<FqP>();
+        Fq29 x = from_canonical_bytes<Fq29P>(a), y = from_canonical_bytes<Fq29P>(b), z = from_canonical_bytes<Fq29P>(c), w = from_canonical_bytes<Fq29P>(e);
+        Fq am = to_mont(a), bm = to_mont(b), cm = to_mont(c), em = to_mont(e);
+        Fq29s xs = Fq29s::from_unsigned(x), ys = Fq29s::from_unsigned(y), zs = Fq29s::from_unsigned(z), ws = Fq29s::from_unsigned(w);
+        CHECK(val(to_unsigned<0>(mul_s(xs, ys))) == from_mont(mul(am, bm)), "mul_s");
+        CHECK(val(to_unsigned<0>(sqr_s(xs))) == from_mont(sqr(am)), "sqr_s");
+        // fused difference (may be negative): x·y - z, and with a per-lane sign
+        Fq29s dneg = mul_s(xs, ys, FuseMul1<Fq29P>{zs, neg1});
+        check_s_normalised(dneg, -1.0, 1.0, "fused difference s-normalised");
+        CHECK(val(to_unsigned<2>(dneg)) == from_mont(sub(mul(am, bm), cm)), "mul_s fused -z");
+        Fq29s dpos = mul_s(xs, ys, FuseMul1<Fq29P>{zs, 1});
+        CHECK(val(to_unsigned<0>(dpos)) == from_mont(add(mul(am, bm), cm)), "mul_s fused +z");
+        // a NEGATIVE multiplicand: (x·y - z)·w and (x·y - z)²
+        CHECK(val(to_unsigned<2>(mul_s(dneg, ws))) == from_mont(mul(sub(mul(am, bm), cm), em)), "mul_s with a negative operand");
+        CHECK(val(to_unsigned<0>(sqr_s(dneg))) == from_mont(sqr(sub(mul(am, bm), cm))), "sqr_s of a negative value");
+        // x² - z - 2w fused
+        Fq t2 = sub(sub(sqr(am), cm), add(em, em));
+        Fq29s f2 = sqr_s(xs, FuseMul2<Fq29P>{zs, neg1, ws, neg2});
+        check_s_normalised(f2, -3.0, 1.0, "fused square s-normalised");
+        CHECK(val(to_unsigned<4>(f2)) == from_mont(t2), "sqr_s fused -z -2w");
+        // dual product with a limb-wise (lazy, signed) difference as one operand
+        Fq29s lazy;
+        for (int i = 0; i < 9; ++i) lazy.l[i] = zs.l[i] - ws.l[i];
+        CHECK(val(to_unsigned<2>(mul2_s(xs, lazy, ys, dneg))) == from_mont(add(mul(am, sub(cm, em)), mul(bm, sub(mul(am, bm), cm)))), "mul2_s");
+    }
+    printf("signed Fq ok\n");
+}
+static void test_signed_madd() {
+    const int32_t neg1 = -1, neg2 = -2;
+    Affine<Fq> g = Gen<Fq>::g();
+    const int NP = 300;
+    static Affine<Fq> pts[NP];
+    static Affine29<Fq29> pts29[NP];
+    XYZZ<Fq> run = XYZZ<Fq>::from_affine(g);
+    for (int i = 0; i < NP; ++i) {
+        uint32_t k[8] = {(uint32_t)rnd(), (uint32_t)rnd(), 0, 0, 0, 0, 0, 0};
+        run = scalar_mul(run, k);
+        if (run.is_inf()) run = XYZZ<Fq>::from_affine(g);
+        pts[i] = to_affine(run);
+        pts29[i] = to_aff29(pts[i]);
+    }
+    XYZZ<Fq> ref = XYZZ<Fq>::inf();
+    G1AccS acc{};
+    bool inf = true;
+    double xlo = 0, xhi = 0, ylo = 0, yhi = 0, zlo = 0, zhi = 0;
+    for (int it = 0; it < 40000; ++it) {
+        int i = (int)(rnd() % NP);
+        int kind = (int)(rnd() % 64);
+        Affine<Fq> p = pts[i];
+        Affine29<Fq29> p29 = pts29[i];
+        int32_t sigma = (rnd() & 1) ? -1 : 1;            // signed digits: half of the entries carry a negated point
+        if (kind == 0 && !ref.is_inf()) {                // the current sum itself (doubling branch), under either sign convention
+            Affine<Fq> cur = to_affine(ref);
+            if (sigma < 0) { p29 = to_aff29(neg(cur)); } else { p29 = to_aff29(cur); }
+            p = cur;
+        } else if (kind == 1 && !ref.is_inf()) {         // the negative of the current sum -> identity
+            Affine<Fq> cur = to_affine(ref);
+            if (sigma < 0) { p29 = to_aff29(cur); } else { p29 = to_aff29(neg(cur)); }
+            p = neg(cur);
+        } else if (sigma < 0) {
+            p = neg(p);
+        }
+        madd(ref, p);
+        madd29s(acc, inf, p29, sigma, neg1, neg2);
+        if (!inf) {
+            check_s_normalised(acc.x, -3.5, 1.2, "signed X");        // the intervals tools/bounds29.py proves closed
+            check_s_normalised(acc.sy, -1.2, 1.2, "signed sY");
+            check_s_normalised(acc.zz, 0.0, 1.05, "signed ZZ");
+            check_s_normalised(acc.zzz, -0.01, 1.01, "signed ZZZ");
+            CHECK(acc.t == 1 || acc.t == -1, "sign");
+            const double N8 = (double)0x30644e;
+            xlo = std::min(xlo, acc.x.l[8] / N8); xhi = std::max(xhi, acc.x.l[8] / N8);
+            ylo = std::min(ylo, acc.sy.l[8] / N8); yhi = std::max(yhi, acc.sy.l[8] / N8);
+            zlo = std::min(zlo, acc.zzz.l[8] / N8); zhi = std::max(zhi, acc.zzz.l[8] / N8);
+            if ((it & 7) == 0 || kind < 2) {
+                XYZZ29<Fq29> st = acc_to_stored(acc);
+                check_inv(st.x, 13, "stored X"); check_inv(st.y, 8, "stored Y"); check_inv(st.zz, 3, "stored ZZ"); check_inv(st.zzz, 3, "stored ZZZ");
+                expect_same_point(st, false, ref, "signed madd chain");
+                // and the stored form feeds the unsigned formulas (the combine / reduction kernels)
+                if ((it & 63) == 0) {
+                    XYZZ29<Fq29> two = st;
+                    bool i2 = false;
+                    add29(two, i2, st, false);
+                    expect_same_point(two, i2, dbl(ref), "stored form through add29");
+                }
+            }
+        } else {
+            CHECK(ref.is_inf(), "signed madd chain: identity");
+        }
+    }
+    printf("signed G1 madd ok (observed X in (%.2f, %.2f) N, sY in (%.2f, %.2f) N, ZZZ in (%.2f, %.2f) N)\n", xlo, xhi, ylo, yhi, zlo, zhi);
+}
+
 int main() {
+    test_signed_field();
+    test_signed_madd();
     test_field<Fq29P>("Fq");
     test_field<Fr29P>("Fr");
     test_fq2();

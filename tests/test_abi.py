@@ -454,3 +454,29 @@ def test_plan_hand_off_drains_vector_memory_before_the_barrier(cc, tmp_path):
         between = ops[hist + 1:ticket]
         barrier = next(i for i, ln in enumerate(between) if ln.startswith("s_barrier"))
         assert any(ln.startswith("s_waitcnt") and "vmcnt(0)" in ln for ln in between[:barrier]), between[:barrier + 1]
+
+
+def test_level1_grouping_kernels_use_no_scratch(cc, tmp_path):
+    """VERDICT r4 #1b: the level-1 grouping kernels kept their four scalars in scratch (144 B per thread, 230 MB per proof).
+    The shipped code objects must declare no private segment for any k_part_* kernel, nor for the accumulation kernels."""
+    import shutil
+    import subprocess
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(readelf) and os.path.exists(objdump)):
+        pytest.skip("llvm-readelf / llvm-objdump not available")
+    work = os.path.join(str(tmp_path), "lib.so")
+    shutil.copy(cc.library_path(), work)
+    subprocess.run([objdump, "--offloading", work], capture_output=True, text=True, check=True, cwd=str(tmp_path))
+    seen = 0
+    for f in sorted(os.listdir(str(tmp_path))):
+        if "gfx950" not in f:
+            continue
+        notes = subprocess.run([readelf, "--notes", os.path.join(str(tmp_path), f)], capture_output=True, text=True, check=True).stdout
+        for blk in re.split(r"\n\s*- \.", notes):
+            nm = re.search(r"\.name:\s+(\S+)", blk)
+            ps = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk)
+            if nm and ps and re.search(r"k_part_(count|place)|k_accum_affine", nm.group(1)):
+                seen += 1
+                assert int(ps.group(1)) == 0, "%s uses %s bytes of scratch per thread" % (nm.group(1), ps.group(1))
+    assert seen >= 30, seen

@@ -209,7 +209,7 @@ def test_a_load_that_runs_out_of_device_memory_gives_everything_back(cc, oracle,
     cg_circuit_load meets a full GPU: 24-30 GB per S21 context with sixteen slots.  HBM is filled (a torch allocation) until
     only `leave_free_gb` are left - 4: the load fails while the window tables are built, 14: the tables fit and the proof
     slots do not - and the load must return CG_ERR_OUT_OF_MEMORY with the failed allocation named, give back every byte
-    and its stream (free memory afterwards within 64 MB of before), and the same circuit must load and prove correctly once
+    and its stream (free memory afterwards no lower than 64 MB below what it was before), and the same circuit must load and prove correctly once
     the filler is gone.  The same for the resident-bases MSM handle (cg_msm_load_g1)."""
     import cpu_ref
     import torch
@@ -229,7 +229,7 @@ def test_a_load_that_runs_out_of_device_memory_gives_everything_back(cc, oracle,
         assert ei.value.code == -4, str(ei.value)                       # CG_ERR_OUT_OF_MEMORY
         assert "device allocation of" in str(ei.value) and "bytes failed" in str(ei.value), str(ei.value)
         after, _ = torch.cuda.mem_get_info()
-        assert abs(after - before) < 64 << 20, (before, after)
+        assert after > before - (64 << 20), (before, after)       # (more may be free than before: the runtime trims its pools)
         # a second failed load leaks nothing either, and the resident-bases MSM handle behaves the same
         with pytest.raises(cc.CrescentGpuError) as ei:
             cc.Prover(pk, cm, proof_slots=16)
@@ -243,7 +243,7 @@ def test_a_load_that_runs_out_of_device_memory_gives_everything_back(cc, oracle,
                     cc.MsmContext(big, group=1, window_bits=20)
                 assert ei.value.code == -4 and "device allocation of" in str(ei.value), str(ei.value)
                 a2, _ = torch.cuda.mem_get_info()
-                assert abs(a2 - b2) < 64 << 20, (b2, a2)
+                assert a2 > b2 - (64 << 20), (b2, a2)
             finally:
                 del small_filler
         after2, _ = torch.cuda.mem_get_info()
@@ -261,4 +261,4 @@ def test_a_load_that_runs_out_of_device_memory_gives_everything_back(cc, oracle,
         prover.close()
     torch.cuda.synchronize()
     free_end, _ = torch.cuda.mem_get_info()
-    assert abs(free_end - free0) < 256 << 20, (free0, free_end)          # and a freed context returns its memory too
+    assert free_end > free0 - (256 << 20), (free0, free_end)          # and a freed context returns its memory too

@@ -225,7 +225,100 @@ def check(F, inv, k):
     assert k["KX"] >= inv["x"] + 1 and k["KY"] >= inv["y"] + 1
 
 
+# ---- the SIGNED mixed addition of the G1 bucket accumulation (curve29.hpp madd29s, field29.hpp S29) ------------------------
+# Values are tracked as intervals (lo, hi) in units of N.  Every operand of a product is s-normalised (limbs 0..7 in
+# [0, 2^29), limb 8 signed and small) or a limb-wise difference of two s-normalised values (|limbs| < 2^29), so the column
+# bound does not depend on the values - it is asserted once per product shape - and what has to be proved is that the
+# intervals are closed under the step, that the test `is_zero_mod(ZZ3)` sees a value in [0, 2N), and that acc_to_stored's
+# offsets land inside the stored invariant.
+class I:
+    def __init__(self, lo, hi):
+        assert lo <= hi
+        self.lo, self.hi = lo, hi
+        assert max(abs(lo), abs(hi)) < CAP / 2, "signed value out of the representable range"
+        # top limb = value / 2^232 must stay far inside an int32: |v| < 84 N  <=>  |l8| < 2^28
+        assert max(abs(lo), abs(hi)) < 84.0
+
+    def __repr__(self):
+        return "I(%.3f, %.3f)" % (self.lo, self.hi)
+
+
+def s_col_ok(nprod, lim_a=1.0, lim_b=1.0, fused=0):
+    """nprod products per column term group (9 each), operand limb magnitudes in units of 2^29, `fused` extra 2^31 terms"""
+    tot = nprod * 9 * (lim_a * 2 ** 29) * (lim_b * 2 ** 29) + 9 * (2 ** 29) ** 2 + fused * 2 ** 31 + 2 ** 36
+    assert tot < 2 ** 63, "signed column accumulator overflow: 2^%.2f" % math.log2(tot)
+
+
+def s_prod(a, b):
+    c = [a.lo * b.lo, a.lo * b.hi, a.hi * b.lo, a.hi * b.hi]
+    return min(c) / RN, max(c) / RN
+
+
+def s_mul(a, b, sub=()):
+    """a·b/R' + [0, N) - Σ k·x for (k, x) in sub (fused)"""
+    s_col_ok(1, fused=len(sub))
+    lo, hi = s_prod(a, b)
+    hi += 1.0
+    for k, x in sub:                         # subtract k·x, k > 0; a signed multiplier (+-1) is given as k·x with x symmetric
+        lo -= k * x.hi
+        hi -= k * x.lo
+    return I(lo, hi)
+
+
+def s_sqr(a, sub=()):
+    s_col_ok(1, lim_a=2.0, fused=len(sub))   # the doubled copy
+    m = max(abs(a.lo), abs(a.hi))
+    lo, hi = 0.0, m * m / RN + 1.0
+    for k, x in sub:
+        lo -= k * x.hi
+        hi -= k * x.lo
+    return I(lo, hi)
+
+
+def s_mul2(a, b, c, d):
+    s_col_ok(2)
+    l1, h1 = s_prod(a, b)
+    l2, h2 = s_prod(c, d)
+    return I(l1 + l2, h1 + h2 + 1.0)
+
+
+def signed_madd(inv):
+    X, SY, ZZ, ZZZ = I(*inv["x"]), I(*inv["sy"]), I(*inv["zz"]), I(*inv["zzz"])
+    px = py = I(0.0, 1.0)                                    # table coordinates: canonical
+    sym = lambda v: I(-max(abs(v.lo), abs(v.hi)), max(abs(v.lo), abs(v.hi)))
+    P = s_mul(ZZ, px, [(1, X)])
+    PP = s_sqr(P)
+    ZZ3 = s_mul(ZZ, PP)
+    assert ZZ3.lo >= 0.0 and ZZ3.hi < 2.0, "is_zero_mod(ZZ3) needs 0 <= ZZ3 < 2N"
+    Q = s_mul(X, PP)
+    PPP = s_mul(P, PP)
+    Rs = s_mul(ZZZ, py, [(1, sym(SY))])                      # - u·sy with u = +-1
+    ZZZ3 = s_mul(ZZZ, PPP)
+    X3 = s_sqr(Rs, [(1, PPP), (2, Q)])
+    d = sym(I(X3.lo - Q.hi, X3.hi - Q.lo))                   # u·(X3 - Q), limb-wise: |limbs| < 2^29
+    SY3 = s_mul2(Rs, d, SY, PPP)
+    return dict(x=X3, sy=SY3, zz=ZZ3, zzz=ZZZ3), dict(P=P, PP=PP, Q=Q, PPP=PPP, Rs=Rs, d=d)
+
+
+def check_signed():
+    # the running accumulator's intervals; the widest start is right after a run begins (x, sy = canonical table coordinates,
+    # zz = zzz = R' mod N) or after the rare doubling (dbl_affine29's outputs made canonical: below N)
+    inv = dict(x=(-3.5, 1.2), sy=(-1.2, 1.2), zz=(0.0, 1.05), zzz=(-0.01, 1.01))
+    out, mid = signed_madd(inv)
+    for k in ("x", "sy", "zz", "zzz"):
+        ok = inv[k][0] <= out[k].lo and out[k].hi <= inv[k][1]
+        print("G1s  madd29s    %-3s in (%.3f, %.3f)  within (%g, %g)  %s" % (k, out[k].lo, out[k].hi, inv[k][0], inv[k][1], "ok" if ok else "VIOLATED"))
+        assert ok
+    print("G1s  intermediates:", ", ".join("%s %r" % kv for kv in mid.items()))
+    # acc_to_stored: x + 4N, t·sy + 2N, zz, zzz + N inside the stored invariant (X < 13 N, Y < 8 N, ZZ, ZZZ < 3 N), all >= 0
+    assert inv["x"][0] + 4 >= 0 and inv["x"][1] + 4 < 13
+    assert -max(map(abs, inv["sy"])) + 2 >= 0 and max(map(abs, inv["sy"])) + 2 < 8
+    assert inv["zz"][0] >= 0 and inv["zz"][1] < 3
+    assert inv["zzz"][0] + 1 >= 0 and inv["zzz"][1] + 1 < 3
+
+
 if __name__ == "__main__":
+    check_signed()
     # invariant of stored accumulators (values in units of N) and the K constants of curve29.hpp
     INV = dict(x=13.0, y=8.0, z=3.0)
     KC = dict(KX=14, KY=9, K1=4, K2=6)
