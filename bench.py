@@ -701,6 +701,42 @@ def main():
                        "scaling": "strong", "bytes_identical_to_unsharded": bool(same)})
             assert same, "sharded and unsharded proofs differ"
             sp_ctx.close()
+            # SURVEY 8e asks for both arrangements to be measured: above every rank recomputes the witness map for its own
+            # h points; here rank 0 runs it once for all shards (cg_witness_map_coset), a scatter over the data plane hands out
+            # the D/N-element slices, and the ranks prove with them (cg_prove_partial_q; ranks != 0 hold no witness-map memory)
+            if not a.h_coefficient_basis:
+                try:
+                    sc_ctx = cc.Prover(pk, cm, device=local_rank, window_bits=a.window, shard_rank=rank, shard_count=world,
+                                       h_scalars_external=(rank != 0))
+                    sps = ShardedProver(sc_ctx, dev, group=grp, arrangement="scatter")
+                    for _ in range(3):
+                        sps.prove_dev(ws_dev[0].data_ptr(), srng.randrange(R), srng.randrange(R))
+                    barrier_sync(world)
+                    sps.reset_breakdown()
+                    c0 = (sps.scatters, sps.all_gathers)
+                    t_start = time.perf_counter()
+                    for k in range(a.sharded_steps):
+                        sps.prove_dev(ws_dev[k % len(ws_dev)].data_ptr(), srng.randrange(R), srng.randrange(R))
+                    torch.cuda.synchronize()
+                    barrier_sync(world)
+                    dsc = max_over_ranks(time.perf_counter() - t_start, world)
+                    r_, s_ = srng.randrange(R), srng.randrange(R)
+                    same_s = sps.prove_dev(ws_dev[0].data_ptr(), r_, s_).data == prover.prove_dev(ws_dev[0].data_ptr(), r_, s_).data
+                    sh["arrangements"] = {
+                        "recompute": {"ms_per_proof": sh["ms_per_proof"], "collectives_per_proof": 1,
+                                      "what": "every rank runs the witness map for its own h points (two full-size + two 1/N-size transforms)"},
+                        "scatter": {"ms_per_proof": round(dsc / a.sharded_steps * 1e3, 3), "collectives_per_proof": 2,
+                                    "scatter_bytes_per_peer": int(prover.domain_size * 32 // world),
+                                    "scatters": sps.scatters - 1 - c0[0], "all_gathers": sps.all_gathers - 1 - c0[1],
+                                    "ms_breakdown_rank0": sps.breakdown_ms(), "bytes_identical_to_unsharded": bool(same_s),
+                                    "what": "rank 0 runs the witness map once (four full-size transforms), scatters the coset values, "
+                                            "every rank proves with its slice"}}
+                    assert same_s, "the scatter arrangement's proof differs from the unsharded one"
+                    sc_ctx.close()
+                except AssertionError:
+                    raise
+                except Exception as e:
+                    sh["arrangements"] = {"error": repr(e)}
             # several sharded proofs in flight per rank (the reference's host runs one task per credential concurrently,
             # sample/client_helper/src/main.rs:177-216): partial sums of proofs k+1.. on the GPU while proof k's record is
             # exchanged and finished

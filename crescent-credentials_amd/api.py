@@ -24,7 +24,7 @@ TUNING_LIB_PATH = os.path.join(_HERE, "libcrescent_gpu_tuning.so")
 FR_MODULUS = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 CG_FORM_CANONICAL, CG_FORM_MONTGOMERY = 0, 1
 CG_FLAG_H_COEFFICIENT_BASIS = 1
-CG_FLAG_LATENCY_MODE, CG_FLAG_THROUGHPUT_MODE, CG_FLAG_SPIN_WAIT, CG_FLAG_CONTIGUOUS_H_SHARDS = 2, 4, 8, 16
+CG_FLAG_LATENCY_MODE, CG_FLAG_THROUGHPUT_MODE, CG_FLAG_SPIN_WAIT, CG_FLAG_CONTIGUOUS_H_SHARDS, CG_FLAG_H_SCALARS_EXTERNAL = 2, 4, 8, 16, 32
 
 
 class CrescentGpuError(RuntimeError):
@@ -115,6 +115,9 @@ _SIGNATURES = {
     "cg_prove_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(CgTimings)]),
     "cg_prove_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(CgTimings)]),
     "cg_assemble": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cg_witness_map_coset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "cg_h_scalars_slice": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "cg_prove_partial_q": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(CgTimings)]),
     "cg_host_alloc": (C.c_void_p, [C.c_uint64]),
     "cg_host_free": (None, [C.c_void_p]),
     "cg_host_register": (C.c_int, [C.c_void_p, C.c_uint64]),
@@ -343,15 +346,17 @@ class Prover:
 
     def __init__(self, pk: ProvingKey, matrices: ConstraintMatrices, device: int = -1, window_bits: int = 0,
                  shard_rank: int = 0, shard_count: int = 1, proof_slots: int = 1, h_coefficient_basis: bool = False,
-                 mode: Optional[str] = None, spin_wait: bool = False, contiguous_h_shards: bool = False, flags: int = 0):
+                 mode: Optional[str] = None, spin_wait: bool = False, contiguous_h_shards: bool = False,
+                 h_scalars_external: bool = False, flags: int = 0):
         """h_coefficient_basis=True keeps the h query as loaded (seven transforms per proof, CG_FLAG_H_COEFFICIENT_BASIS).
         mode: None (proof_slots decides), "latency" or "throughput" (CG_FLAG_LATENCY_MODE / CG_FLAG_THROUGHPUT_MODE);
-        spin_wait: CG_FLAG_SPIN_WAIT; contiguous_h_shards: CG_FLAG_CONTIGUOUS_H_SHARDS; flags: further raw CG_FLAG_* bits."""
+        spin_wait: CG_FLAG_SPIN_WAIT; contiguous_h_shards: CG_FLAG_CONTIGUOUS_H_SHARDS; h_scalars_external:
+        CG_FLAG_H_SCALARS_EXTERNAL (a shard that never runs the witness map: prove_partial_q only); flags: further raw bits."""
         if mode not in (None, "latency", "throughput"):
             raise ValueError("mode must be None, 'latency' or 'throughput'")
         flags |= (CG_FLAG_H_COEFFICIENT_BASIS if h_coefficient_basis else 0) | (CG_FLAG_LATENCY_MODE if mode == "latency" else 0) | \
                  (CG_FLAG_THROUGHPUT_MODE if mode == "throughput" else 0) | (CG_FLAG_SPIN_WAIT if spin_wait else 0) | \
-                 (CG_FLAG_CONTIGUOUS_H_SHARDS if contiguous_h_shards else 0)
+                 (CG_FLAG_CONTIGUOUS_H_SHARDS if contiguous_h_shards else 0) | (CG_FLAG_H_SCALARS_EXTERNAL if h_scalars_external else 0)
         L = lib()
         self.num_inputs = matrices.num_instance_variables
         self.num_constraints = matrices.num_constraints
@@ -448,6 +453,47 @@ class Prover:
         tm = CgTimings()
         _check(lib().cg_prove_partial(self._h, ptr, 1 if on_device else 0, _ptr(rb), _ptr(out), C.byref(tm) if timings else None))
         return (out.tobytes(), tm.as_dict()) if timings else out.tobytes()
+
+    def prove_partial_q(self, assignment, q_slice, r: int, on_device: bool = False, q_on_device: bool = False, timings: bool = False):
+        """cg_prove_partial_q: this shard's partial sums with its h scalars supplied (its slice of witness_map_coset's
+        output: h_scalars_slice); the witness map is skipped.  assignment / q_slice: numpy bytes, or device addresses."""
+        out = np.zeros(384, dtype=np.uint8)
+        rb = _u8(fr_to_bytes(r))
+        if on_device:
+            ptr = C.c_void_p(int(assignment))
+        else:
+            w = _u8(assignment, self.num_variables * 32)
+            ptr = C.c_void_p(_ptr(w))
+        if q_on_device:
+            qptr = C.c_void_p(int(q_slice))
+        else:
+            q = _u8(q_slice)
+            qptr = C.c_void_p(_ptr(q) if q.size else _ptr(rb))
+        tm = CgTimings()
+        _check(lib().cg_prove_partial_q(self._h, ptr, 1 if on_device else 0, qptr, 1 if q_on_device else 0, _ptr(rb), _ptr(out),
+                                        C.byref(tm) if timings else None))
+        return (out.tobytes(), tm.as_dict()) if timings else out.tobytes()
+
+    def h_scalars_slice(self, shard: int) -> Tuple[int, int]:
+        """(offset, count) of shard `shard`'s scalars inside witness_map_coset's output, in elements (cg_h_scalars_slice)"""
+        off, cnt = C.c_uint64(), C.c_uint64()
+        _check(lib().cg_h_scalars_slice(self._h, shard, C.byref(off), C.byref(cnt)))
+        return int(off.value), int(cnt.value)
+
+    def witness_map_coset(self, assignment, on_device: bool = False, out_dev: Optional[int] = None):
+        """cg_witness_map_coset: ALL coset values q_j of the quotient's a·b part (folded key), domain_size x 32 B canonical,
+        shard-major for this context's shard count.  -> numpy bytes, or written to the device address out_dev."""
+        if on_device:
+            ptr = C.c_void_p(int(assignment))
+        else:
+            w = _u8(assignment, self.num_variables * 32)
+            ptr = C.c_void_p(_ptr(w))
+        if out_dev is not None:
+            _check(lib().cg_witness_map_coset(self._h, ptr, 1 if on_device else 0, C.c_void_p(int(out_dev)), 1))
+            return None
+        q = np.zeros(self.domain_size * 32, dtype=np.uint8)
+        _check(lib().cg_witness_map_coset(self._h, ptr, 1 if on_device else 0, _ptr(q), 0))
+        return q
 
     def assemble(self, partials: bytes, n_shards: int, r: int, s: int) -> Proof:
         pb = _u8(partials, 384 * n_shards)

@@ -149,6 +149,11 @@ CG_HD void store_acc(uint32_t* __restrict__ dst, const XYZZ29<F>& a, bool inf) {
 #pragma unroll
     for (int i = 0; i < ACC / 4; ++i) p[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
+// A G1 record may be in the SIGNED form the bucket accumulation leaves (store_acc_signed below): bit 31 of the top ZZ word
+// set, bit 30 = the sign of Y.  It is brought to the stored invariant here, by whoever reads it: the conversion (~160
+// instructions) is paid once per record by kernels whose additions cost 3000, instead of inside the accumulation's loop,
+// where a flush runs for one or two lanes of a wave in 71 % of the iterations and every instruction of it costs the wave.
+CG_HD void signed_record_to_stored(uint32_t* w);          // defined after G1AccS
 template <class F>
 CG_HD bool load_acc(const uint32_t* __restrict__ src, XYZZ29<F>& a) {   // returns inf
     constexpr int ACC = Words29<F>::ACC;
@@ -158,6 +163,9 @@ CG_HD bool load_acc(const uint32_t* __restrict__ src, XYZZ29<F>& a) {   // retur
     for (int i = 0; i < ACC / 4; ++i) {
         uint4 v = p[i];
         w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+    if constexpr (Words29<F>::NF == 1) {
+        if (w[ACC / 2 + 8] & 0x80000000u) signed_record_to_stored(w);
     }
     load_limbs(a.x, w);
     load_limbs(a.y, w + ACC / 4);
@@ -322,6 +330,55 @@ CG_HD XYZZ29<Fq29> acc_to_stored(const G1AccS& a) {
     r.zz = to_unsigned<0>(a.zz);                     // non-negative as it is
     r.zzz = to_unsigned<1>(a.zzz);                   // (-0.01 N, 1.01 N) + N: a product's negative side is a hundredth of N
     return r;
+}
+
+// The accumulation's record: the signed accumulator as it is (36 words: x, sy, zz, zzz), the sign of Y in bit 30 and the
+// "signed record" mark in bit 31 of the top ZZ word (zz is non-negative and below 1.05 N: its top word is below 2^23).
+CG_HD void pack_signed_record(const G1AccS& a, uint32_t* w) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        w[i] = (uint32_t)a.x.l[i]; w[9 + i] = (uint32_t)a.sy.l[i]; w[18 + i] = (uint32_t)a.zz.l[i]; w[27 + i] = (uint32_t)a.zzz.l[i];
+    }
+    w[26] |= 0x80000000u | (((uint32_t)a.t >> 31) << 30);
+}
+#if defined(__HIPCC__)
+// The flush of the accumulation's loop: it runs for one or two lanes of a wave in 71 % of the iterations (equal segments
+// over runs of ~52 entries), so the WAVE pays every vector-ALU instruction of it 0.71 times per entry - 130 of the 2180
+// instructions per entry in rounds 2-4, most of them register moves that line the 36 words up in fours for 16-byte stores
+// (and selects that zero the record of an empty run).  Here the words leave from the registers they are in, one 4-byte
+// store each - relaxed wavefront-scope atomic stores, which the optimiser neither merges nor decorates with cache
+// controls; vector-memory instructions do not take the vector ALU's issue slots - and the empty run (a cancellation: rare)
+// takes a branch of its own.
+CG_HD void store_acc_signed(uint32_t* __restrict__ dst, const G1AccS& a, bool inf) {
+    if (inf) {
+        uint4* p = reinterpret_cast<uint4*>(dst);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) p[i] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
+    auto put = [&](int i, uint32_t v) { __hip_atomic_store(dst + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); };
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        put(i, (uint32_t)a.x.l[i]);
+        put(9 + i, (uint32_t)a.sy.l[i]);
+        put(18 + i, i < 8 ? (uint32_t)a.zz.l[i] : ((uint32_t)a.zz.l[8] | 0x80000000u | (((uint32_t)a.t >> 31) << 30)));
+        put(27 + i, (uint32_t)a.zzz.l[i]);
+    }
+}
+#endif
+CG_HD void signed_record_to_stored(uint32_t* w) {
+    G1AccS a;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        a.x.l[i] = (int32_t)w[i]; a.sy.l[i] = (int32_t)w[9 + i]; a.zz.l[i] = (int32_t)w[18 + i]; a.zzz.l[i] = (int32_t)w[27 + i];
+    }
+    a.t = (w[26] & 0x40000000u) ? -1 : 1;
+    a.zz.l[8] = (int32_t)(w[26] & 0x3fffffffu);
+    const XYZZ29<Fq29> r = acc_to_stored(a);
+    store_limbs(r.x, w);
+    store_limbs(r.y, w + 9);
+    store_limbs(r.zz, w + 18);
+    store_limbs(r.zzz, w + 27);
 }
 
 // acc += q (both XYZZ under the stored invariant)   (add-2008-s)

@@ -808,8 +808,9 @@ __global__ void __launch_bounds__(256) CG_ACCUM_ATTR k_accum_affine(const uint64
 // The same walk with the lane's running accumulator in the signed form of curve29.hpp (G1AccS / madd29s): the differences
 // of the mixed addition are fused into the products that precede them, the sign of a digit enters as a multiplier instead
 // of a negated y, and the sign of Y flips instead of being subtracted - ~140 of the ~2180 instructions of an addition go.
-// A run is converted to the stored (unsigned) invariant only when it is flushed, so the pieces and buckets every later
-// kernel reads are what k_accum_affine<Fq29> writes.
+// A flushed run leaves as a SIGNED record (curve29.hpp store_acc_signed: the accumulator as it is, marked); load_acc brings
+// it to the stored (unsigned) invariant in the kernels that read it - a flush runs for a lane or two of a wave in 71 % of the
+// loop's iterations, so every instruction taken out of it is taken out of the loop.
 __global__ void __launch_bounds__(256) CG_ACCUM_ATTR k_accum_affine_g1s(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ plan,
                                                           const uint32_t* __restrict__ table,
                                                           uint32_t* __restrict__ bucket_sums, uint32_t* __restrict__ part_keys,
@@ -835,7 +836,13 @@ __global__ void __launch_bounds__(256) CG_ACCUM_ATTR k_accum_affine_g1s(const ui
         if (k + 1 < end) next_ent = entries[k + 1];
         const uint32_t key = (uint32_t)(ent >> 32), v = (uint32_t)ent;
         if (key != cur) {
-            flush_run(cur, acc_to_stored(acc), inf, first, final_level, t, bucket_sums, part_keys, part_pts);
+            // the record leaves in the signed form (curve29.hpp store_acc_signed); its readers convert it
+            if (first && !final_level) {
+                part_keys[2 * t] = cur;
+                store_acc_signed(part_pts + (size_t)(2 * t) * ACC, acc, inf);
+            } else {
+                store_acc_signed(bucket_sums + (size_t)cur * ACC, acc, inf);
+            }
             first = false;
             inf = true;
             cur = key;
@@ -843,17 +850,16 @@ __global__ void __launch_bounds__(256) CG_ACCUM_ATTR k_accum_affine_g1s(const ui
         const Affine29<F29T> p = load_table_point_plain(table, v & 0x7fffffffu);
         madd29s(acc, inf, p, (int32_t)v >> 31 | 1, neg1, neg2);       // sigma = -1 for a negative digit, +1 otherwise
     }
-    const XYZZ29<F29T> st = acc_to_stored(acc);
     if (final_level) {
-        store_acc(bucket_sums + (size_t)cur * ACC, st, inf);
+        store_acc_signed(bucket_sums + (size_t)cur * ACC, acc, inf);
     } else if (first) {  // the whole segment is one run
         part_keys[2 * t] = cur;
-        store_acc(part_pts + (size_t)(2 * t) * ACC, st, inf);
+        store_acc_signed(part_pts + (size_t)(2 * t) * ACC, acc, inf);
         part_keys[2 * t + 1] = cur;
-        store_acc(part_pts + (size_t)(2 * t + 1) * ACC, st, true);
+        store_acc_signed(part_pts + (size_t)(2 * t + 1) * ACC, acc, true);
     } else {
         part_keys[2 * t + 1] = cur;
-        store_acc(part_pts + (size_t)(2 * t + 1) * ACC, st, inf);
+        store_acc_signed(part_pts + (size_t)(2 * t + 1) * ACC, acc, inf);
     }
 }
 

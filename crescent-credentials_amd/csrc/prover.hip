@@ -224,6 +224,7 @@ struct cg_ctx {
     std::atomic<int> calls_inside{0};
     bool latency = false;
     bool spin_wait = false;      // CG_FLAG_SPIN_WAIT
+    bool external_q = false;     // CG_FLAG_H_SCALARS_EXTERNAL: no witness-map resources; the h scalars arrive with every proof
     // device bytes that stay resident (cg_ctx_get_info): window tables + validity flags | matrices and domain tables | one slot
     // (slot_bytes is the sum of slot_part: entry lists, segment pieces, bucket arrays and reduction buffers, the witness
     // map's vectors + the h MSM's scalars, one upload buffer - account_slot)
@@ -387,8 +388,10 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
     if (wb < 0 || wb == 1 || wb > 22) return fail(CG_ERR_INVALID_ARGUMENT, "window_bits must be 0 (automatic) or in [2, 22]");
     if (opt && opt->proof_slots < 0) return fail(CG_ERR_INVALID_ARGUMENT, "proof_slots must not be negative");
     constexpr int32_t KNOWN_FLAGS = CG_FLAG_H_COEFFICIENT_BASIS | CG_FLAG_LATENCY_MODE | CG_FLAG_THROUGHPUT_MODE | CG_FLAG_SPIN_WAIT |
-                                    CG_FLAG_CONTIGUOUS_H_SHARDS;
+                                    CG_FLAG_CONTIGUOUS_H_SHARDS | CG_FLAG_H_SCALARS_EXTERNAL;
     if (opt && (opt->flags & ~KNOWN_FLAGS)) return fail(CG_ERR_INVALID_ARGUMENT, "unknown bits in flags");
+    if (opt && (opt->flags & CG_FLAG_H_SCALARS_EXTERNAL) && ((opt->flags & CG_FLAG_H_COEFFICIENT_BASIS) || shard_count <= 1))
+        return fail(CG_ERR_INVALID_ARGUMENT, "flags: CG_FLAG_H_SCALARS_EXTERNAL needs a sharded context over the folded key");
     if (opt && (opt->flags & CG_FLAG_LATENCY_MODE) && (opt->flags & CG_FLAG_THROUGHPUT_MODE))
         return fail(CG_ERR_INVALID_ARGUMENT, "flags: CG_FLAG_LATENCY_MODE and CG_FLAG_THROUGHPUT_MODE are exclusive");
     // every pointer the structs carry is checked before anything is read through it (a half-filled struct from the
@@ -429,6 +432,7 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         c->fb_delta_g1.build(c->delta_g1);
         c->fb_delta_g2.build(c->delta_g2);
         c->folded = !(opt && (opt->flags & CG_FLAG_H_COEFFICIENT_BASIS));
+        c->external_q = opt && (opt->flags & CG_FLAG_H_SCALARS_EXTERNAL);
         {
             const int logs = ilog2_ceil((uint64_t)c->shard_count);
             c->h_strided = c->folded && c->shard_count > 1 && (1 << logs) == c->shard_count && logD - logs >= 4 &&
@@ -442,9 +446,11 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         std::unique_ptr<AllocScope> booking;
         auto book = [&](int64_t* counter) { booking.reset(); if (counter) booking.reset(new AllocScope(counter)); };
         book(&c->matrix_bytes);
-        c->A.upload(abc[0], m, M, s0);     // validates the CSR views (monotone row_ptr, column range, canonical coefficients)
-        c->B.upload(abc[1], m, M, s0);
-        c->C.upload(abc[2], m, M, s0);
+        // validates the CSR views (monotone row_ptr, column range, canonical coefficients); a context that never runs the
+        // witness map skips the sliced layout
+        c->A.upload(abc[0], m, M, s0, !c->external_q);
+        c->B.upload(abc[1], m, M, s0, !c->external_q);
+        c->C.upload(abc[2], m, M, s0, !c->external_q);
         c->dom.build(logD, true, s0);
         CG_HIP(hipStreamSynchronize(s0));
         book(&c->table_bytes);
@@ -478,10 +484,15 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
             }
         }
         book(&c->matrix_bytes);
-        c->wdom.build(c->dom, s0);
-        if (c->h_strided) c->wstr.build(c->dom, ilog2_ceil((uint64_t)c->shard_count), c->shard_rank, s0);
-        c->dA.build(c->A, s0); c->dB.build(c->B, s0); c->dC.build(c->C, s0);
+        if (!c->external_q) {
+            c->wdom.build(c->dom, s0);
+            if (c->h_strided) c->wstr.build(c->dom, ilog2_ceil((uint64_t)c->shard_count), c->shard_rank, s0);
+            c->dA.build(c->A, s0); c->dB.build(c->B, s0); c->dC.build(c->C, s0);
+        }
         CG_HIP(hipStreamSynchronize(s0));
+        if (c->external_q) {      // the matrices were uploaded for their validation and for the load-time fold only
+            c->A = DevCsr(); c->B = DevCsr(); c->C = DevCsr();
+        }
         // the saturated-form tables were only the source of the packed ones
         c->dom.tw_fwd.release(); c->dom.tw_inv.release(); c->dom.coset_br.release(); c->dom.icoset_br.release();
         c->A.dict.release(); c->B.dict.release(); c->C.dict.release();
@@ -532,8 +543,13 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
                 sl->eh.zero_at_end = sl->el.zero_at_end = sl->ea.zero_at_end = sl->eb1.zero_at_end = sl->eb2.zero_at_end = zero_at_end;
             }
             sl->eh.init(&c->bh); sl->el.init(&c->bl); sl->ea.init(&c->ba); sl->eb1.init(&c->bb1); sl->eb2.init(&c->bb2);
-            sl->h_canon.alloc(D);
-            sl->wm.alloc(M, D, std::max(c->A.sell_scratch, std::max(c->B.sell_scratch, c->C.sell_scratch)));
+            if (c->external_q) {      // only the landing buffer of a slice that arrives in host memory, and the input flag
+                sl->h_canon.alloc(c->rh.hi - c->rh.lo ? c->rh.hi - c->rh.lo : 1);
+                sl->wm.h_bad_input.alloc(1);
+            } else {
+                sl->h_canon.alloc(D);
+                sl->wm.alloc(M, D, std::max(c->A.sell_scratch, std::max(c->B.sell_scratch, c->C.sell_scratch)));
+            }
             c->slots.push_back(std::move(sl));
         }
         for (int k = 0; k < n_slots + 2; ++k) {
@@ -574,6 +590,41 @@ extern "C" void cg_circuit_free(cg_ctx* ctx) {
 static void run_witness_map(cg_ctx* c, ProofSlot* S, const Fr* w_canon_dev, hipStream_t st, bool coset_values) {
     wm29_run(c->wdom, c->A, c->B, c->C, c->dA, c->dB, c->dC, S->wm, w_canon_dev, c->M, c->m, c->l, S->h_canon.p, st, coset_values,
              coset_values && c->h_strided ? &c->wstr : nullptr);
+}
+
+// x >= r for any of n scalars -> *bad = 1 (the witness map's own input check, for proofs that skip the witness map)
+__global__ void __launch_bounds__(256) k_flag_non_canonical(const Fr* __restrict__ s, uint64_t n, uint32_t* __restrict__ bad) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fr x = s[i];
+    bool lt = false, decided = false;
+#pragma unroll
+    for (int k = 7; k >= 0; --k)
+        if (!decided && x.l[k] != FrP::N[k]) { lt = x.l[k] < FrP::N[k]; decided = true; }
+    if (!lt) *bad = 1u;
+}
+// out[p·d + k] = in[p + k·count]: the coset values in shard-major order for strided shards (d = n / count)
+__global__ void __launch_bounds__(256) k_shard_major(const Fr* __restrict__ in, Fr* __restrict__ out, uint64_t n, uint32_t count) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t d = n / count, p = i / d, k = i - p * d;
+    out[i] = in[p + k * (uint64_t)count];
+}
+
+// The scalars of this context's share of the h MSM, on stream st: out of the witness map (h_canon: coefficients of h, or the
+// coset values vinv·a·b for a folded key), or - q_dev given - the caller's, with the input check the witness map would
+// have made (canonical assignment) and the same check of the slice.
+static const Fr* witness_map_or_check(cg_ctx* c, ProofSlot* S, const Fr* w_dev, const Fr* q_dev, hipStream_t st) {
+    if (!q_dev) {
+        run_witness_map(c, S, w_dev, st, c->folded);
+        return S->h_canon.p + c->rh.lo;
+    }
+    S->wm.h_bad_input.p[0] = 0;
+    const uint64_t nq = c->rh.hi - c->rh.lo;
+    k_flag_non_canonical<<<ceil_div(c->M, 256), 256, 0, st>>>(w_dev, c->M, S->wm.h_bad_input.dev());
+    if (nq) k_flag_non_canonical<<<ceil_div(nq, 256), 256, 0, st>>>(q_dev, nq, S->wm.h_bad_input.dev());
+    CG_KERNEL_CHECK();
+    return q_dev;
 }
 
 struct Partials {
@@ -636,8 +687,9 @@ static float upload_assignment(cg_ctx* c, Upload* u, const void* host_assignment
 }
 
 // w_dev: the assignment in this context's device memory (the caller's own buffer, or an Upload's)
+// q_dev (optional): this shard's h scalars, supplied by the caller (cg_prove_partial_q) - the witness map is skipped
 static int prove_partial_impl(cg_ctx* c, ProofSlot* S, const Fr* w_dev, bool skip_b1, Partials& P, cg_timings* tm,
-                              const std::function<void()>* while_gpu_runs = nullptr) {
+                              const std::function<void()>* while_gpu_runs = nullptr, const Fr* q_dev = nullptr) {
     CG_HIP(hipSetDevice(c->device));
     auto t0 = std::chrono::steady_clock::now();
     const uint64_t M = c->M, l = c->l;
@@ -663,9 +715,9 @@ static int prove_partial_impl(cg_ctx* c, ProofSlot* S, const Fr* w_dev, bool ski
         if (!b2_adopts) S->eb2.digits(w_a, n_a, s0);
         S->eb2.accumulate(s0);                                                         // ... until here
         if (tm) CG_HIP(hipEventRecord(S->ev_t[0], s0));
-        run_witness_map(c, S, w_dev, s0, c->folded);   // h_canon: coefficients of h, or the coset values vinv·a·b for a folded key
+        const Fr* h_scalars = witness_map_or_check(c, S, w_dev, q_dev, s0);
         if (tm) CG_HIP(hipEventRecord(S->ev_t[1], s0));
-        S->eh.digits(S->h_canon.p + c->rh.lo, c->rh.hi - c->rh.lo, s0);
+        S->eh.digits(h_scalars, c->rh.hi - c->rh.lo, s0);
         S->eh.accumulate(s0);
     } else {
         CG_HIP(hipEventRecord(S->ev_w, s0));
@@ -682,9 +734,9 @@ static int prove_partial_impl(cg_ctx* c, ProofSlot* S, const Fr* w_dev, bool ski
         }
         // witness map, then h digits, on stream 0
         if (tm) CG_HIP(hipEventRecord(S->ev_t[0], s0));
-        run_witness_map(c, S, w_dev, s0, c->folded);   // h_canon: coefficients of h, or the coset values vinv·a·b for a folded key
+        const Fr* h_scalars = witness_map_or_check(c, S, w_dev, q_dev, s0);
         if (tm) CG_HIP(hipEventRecord(S->ev_t[1], s0));
-        S->eh.digits(S->h_canon.p + c->rh.lo, c->rh.hi - c->rh.lo, s0);
+        S->eh.digits(h_scalars, c->rh.hi - c->rh.lo, s0);
         // second phase (each waits for its own entry count)
         S->el.accumulate(S->st[1]);
         S->ea.accumulate(S->st[2]);
@@ -699,7 +751,9 @@ static int prove_partial_impl(cg_ctx* c, ProofSlot* S, const Fr* w_dev, bool ski
     } else {
         for (int i = 0; i < 5; ++i) CG_HIP(hipStreamSynchronize(S->st[i]));
     }
-    if (S->wm.h_bad_input.p[0]) return fail(CG_ERR_INVALID_ARGUMENT, "full_assignment holds a value >= the scalar field modulus");
+    if (S->wm.h_bad_input.p[0])
+        return fail(CG_ERR_INVALID_ARGUMENT, q_dev ? "full_assignment or the h-scalar slice holds a value >= the scalar field modulus"
+                                                   : "full_assignment holds a value >= the scalar field modulus");
     P.h = to_affine(S->eh.value());
     P.l = to_affine(S->el.value());
     P.a = to_affine(S->ea.value());
@@ -939,10 +993,14 @@ extern "C" int cg_prove_dev(cg_ctx* ctx, const void* d_full_assignment, const ui
     return prove_common(ctx, d_full_assignment, true, r, s, proof_out, timings);
 }
 
-extern "C" int cg_prove_partial(cg_ctx* ctx, const void* full_assignment, int assignment_on_device, const uint8_t r[32],
-                                uint8_t out_partials[384], cg_timings* timings) {
-    if (!ctx || !full_assignment || !out_partials || !r) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
+static int prove_partial_common(cg_ctx* ctx, const void* full_assignment, int assignment_on_device, const void* q_slice, int q_on_device,
+                                bool with_q, const uint8_t r[32], uint8_t out_partials[384], cg_timings* timings) {
+    if (!ctx || !full_assignment || !out_partials || !r || (with_q && !q_slice)) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
     if (!scalar_is_canonical(r)) return fail(CG_ERR_INVALID_ARGUMENT, "r not canonical");
+    if (with_q && (!ctx->folded || ctx->shard_count <= 1))
+        return fail(CG_ERR_INVALID_ARGUMENT, "cg_prove_partial_q needs a sharded context over the folded key");
+    if (!with_q && ctx->external_q)
+        return fail(CG_ERR_INVALID_ARGUMENT, "context loaded with CG_FLAG_H_SCALARS_EXTERNAL: its h scalars must be supplied (cg_prove_partial_q)");
     if (ctx->broken) return fail(CG_ERR_OUT_OF_MEMORY, "%s", BROKEN_CONTEXT);
     CallGuard inside(ctx);
     try {
@@ -961,13 +1019,86 @@ extern "C" int cg_prove_partial(cg_ctx* ctx, const void* full_assignment, int as
                 w_dev = up.u->w.p;
             }
             SlotGuard g(ctx);
-            e = prove_partial_impl(ctx, g.s, w_dev, scalar_is_zero(r), P, timings);
+            const Fr* q_dev = nullptr;
+            if (with_q) {
+                q_dev = (const Fr*)q_slice;
+                const uint64_t nq = ctx->rh.hi - ctx->rh.lo;
+                if (!q_on_device && nq) {        // lands in the slot's h vector, in front of the proof's kernels on its stream
+                    CG_HIP(hipSetDevice(ctx->device));
+                    Fr* dst = ctx->external_q ? g.s->h_canon.p : g.s->h_canon.p + ctx->rh.lo;
+                    CG_HIP(hipMemcpyAsync(dst, q_slice, nq * 32, hipMemcpyHostToDevice, g.s->st[0]));
+                    q_dev = dst;
+                }
+            }
+            e = prove_partial_impl(ctx, g.s, w_dev, scalar_is_zero(r), P, timings, nullptr, q_dev);
             if (!e) snapshot_tune_stats(ctx, g.s, scalar_is_zero(r), ts);
             if (!e && timings) { timings->upload_ms = upload_ms; timings->total_ms += upload_ms; }
         }
         if (e) return e;
         maybe_retune(ctx, ts);
         partials_to_bytes(P, out_partials);
+        return CG_OK;
+    } catch (...) {
+        return translate_exception();
+    }
+}
+
+extern "C" int cg_prove_partial(cg_ctx* ctx, const void* full_assignment, int assignment_on_device, const uint8_t r[32],
+                                uint8_t out_partials[384], cg_timings* timings) {
+    return prove_partial_common(ctx, full_assignment, assignment_on_device, nullptr, 0, false, r, out_partials, timings);
+}
+
+extern "C" int cg_prove_partial_q(cg_ctx* ctx, const void* full_assignment, int assignment_on_device, const void* q_slice, int q_on_device,
+                                  const uint8_t r[32], uint8_t out_partials[384], cg_timings* timings) {
+    return prove_partial_common(ctx, full_assignment, assignment_on_device, q_slice, q_on_device, true, r, out_partials, timings);
+}
+
+extern "C" int cg_h_scalars_slice(const cg_ctx* ctx, uint32_t shard, uint64_t* offset, uint64_t* count) {
+    if (!ctx || !offset || !count) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
+    if (!ctx->folded) return fail(CG_ERR_INVALID_ARGUMENT, "context keeps the h query in the coefficient basis");
+    if (shard >= (uint32_t)ctx->shard_count) return fail(CG_ERR_INVALID_ARGUMENT, "shard out of range");
+    if (ctx->h_strided) {
+        *count = ctx->D / (uint64_t)ctx->shard_count;
+        *offset = *count * shard;
+    } else {
+        const Range rg = shard_range(ctx->D, (int)shard, ctx->shard_count);
+        *offset = rg.lo;
+        *count = rg.hi - rg.lo;
+    }
+    return CG_OK;
+}
+
+extern "C" int cg_witness_map_coset(cg_ctx* ctx, const void* full_assignment, int assignment_on_device, void* q_out, int q_on_device) {
+    if (!ctx || !full_assignment || !q_out) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
+    if (!ctx->folded) return fail(CG_ERR_INVALID_ARGUMENT, "context keeps the h query in the coefficient basis: its h scalars are cg_witness_map's");
+    if (ctx->external_q) return fail(CG_ERR_INVALID_ARGUMENT, "context loaded with CG_FLAG_H_SCALARS_EXTERNAL holds no witness-map resources");
+    CallGuard inside(ctx);
+    try {
+        CG_HIP(hipSetDevice(ctx->device));
+        std::shared_lock<std::shared_mutex> tl(ctx->tune_mu);
+        if (ctx->broken) return fail(CG_ERR_OUT_OF_MEMORY, "%s", BROKEN_CONTEXT);
+        UploadGuard up;
+        const Fr* w_dev = (const Fr*)full_assignment;
+        if (!assignment_on_device) {
+            up.take(ctx);
+            (void)upload_assignment(ctx, up.u, full_assignment, false);
+            w_dev = up.u->w.p;
+        }
+        SlotGuard g(ctx);
+        ProofSlot* S = g.s;
+        hipStream_t s0 = S->st[0];
+        // ALL coset values (the whole-domain arrangement, whatever this context's own share is), natural order
+        wm29_run(ctx->wdom, ctx->A, ctx->B, ctx->C, ctx->dA, ctx->dB, ctx->dC, S->wm, w_dev, ctx->M, ctx->m, ctx->l, S->h_canon.p, s0, true, nullptr);
+        const Fr* src = S->h_canon.p;
+        if (ctx->h_strided) {        // shard-major: shard p's scalars q_{p + k·count} become the contiguous slice p
+            Fr* tmp = reinterpret_cast<Fr*>(S->wm.vt.p);
+            k_shard_major<<<ceil_div(ctx->D, 256), 256, 0, s0>>>(S->h_canon.p, tmp, ctx->D, (uint32_t)ctx->shard_count);
+            CG_KERNEL_CHECK();
+            src = tmp;
+        }
+        CG_HIP(hipMemcpyAsync(q_out, src, ctx->D * 32, q_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s0));
+        CG_HIP(hipStreamSynchronize(s0));
+        if (S->wm.h_bad_input.p[0]) return fail(CG_ERR_INVALID_ARGUMENT, "full_assignment holds a value >= the scalar field modulus");
         return CG_OK;
     } catch (...) {
         return translate_exception();
@@ -1000,6 +1131,7 @@ extern "C" int cg_assemble(cg_ctx* ctx, const uint8_t* partials, uint32_t n_shar
 
 extern "C" int cg_witness_map(cg_ctx* ctx, const uint8_t* full_assignment, uint8_t* h_out) {
     if (!ctx || !full_assignment || !h_out) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
+    if (ctx->external_q) return fail(CG_ERR_INVALID_ARGUMENT, "context loaded with CG_FLAG_H_SCALARS_EXTERNAL holds no witness-map resources");
     CallGuard inside(ctx);
     try {
         CG_HIP(hipSetDevice(ctx->device));

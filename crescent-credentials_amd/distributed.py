@@ -182,6 +182,66 @@ def gather_partials(partial: bytes, device, group=None) -> bytes:
     return PartialGather(device, group)(partial)
 
 
+class HScalarScatter:
+    """The exchange step of the "scatter" arrangement: rank 0 computes every shard's h scalars (witness_map_coset), each rank
+    receives its slice.  Chunks are padded to the longest slice (strided shards are all domain_size / world long); buffers are
+    allocated once; with RCCL they live on the device - 32 B x domain_size / world per peer, each over its own xGMI link - with
+    gloo on the host."""
+
+    def __init__(self, prover, device, group, rank: int, world: int):
+        self.prover, self.group, self.rank, self.world = prover, group, rank, world
+        self.on_host = (world <= 1) or _on_host(group)
+        self.slices = [prover.h_scalars_slice(p) for p in range(world)]
+        self.chunk = max(c for _, c in self.slices) * 32
+        total = max(o + c for o, c in self.slices)
+        dev = torch.device("cpu") if self.on_host else device
+        self._recv = torch.zeros(max(1, self.chunk), dtype=torch.uint8, device=dev)
+        self._all = torch.zeros(total * 32, dtype=torch.uint8, device=dev) if rank == 0 else None
+        equal = all(c * 32 == self.chunk for _, c in self.slices)
+        # equal slices: the scatter list is views of the one vector; otherwise padded copies
+        self._pad = None if equal or rank != 0 else [torch.zeros(max(1, self.chunk), dtype=torch.uint8, device=dev) for _ in range(world)]
+        self.src = dist.get_global_rank(group, 0) if (world > 1 and group is not None) else 0
+
+    def __call__(self, assignment, on_device: bool, seconds: dict):
+        """-> (this rank's slice: a device address or numpy bytes, whether it is on the device)"""
+        t0 = time.perf_counter()
+        off, cnt = self.slices[self.rank]
+        failure = None
+        if self.rank == 0:
+            try:
+                if self.on_host:
+                    got = np.frombuffer(bytes(self.prover.witness_map_coset(assignment, on_device=on_device)), dtype=np.uint8)
+                    self._all.numpy()[:] = got[:self._all.numel()]        # (a prover may return more than its shards' slices cover)
+                else:
+                    self.prover.witness_map_coset(assignment, on_device=on_device, out_dev=self._all.data_ptr())
+            except BaseException as e:   # noqa: BLE001 - raised after the scatter the other ranks are already waiting in
+                failure = e
+        t1 = time.perf_counter()
+        if self.world > 1:
+            lst = None
+            if self.rank == 0:
+                if self._pad is None:
+                    lst = [self._all[o * 32:o * 32 + self.chunk] for o, _ in self.slices]
+                else:
+                    for p, (o, c) in enumerate(self.slices):
+                        self._pad[p][:c * 32].copy_(self._all[o * 32:(o + c) * 32])
+                    lst = self._pad
+            dist.scatter(self._recv, lst, src=self.src, group=self.group)
+            if not self.on_host:
+                torch.cuda.current_stream(self._recv.device).synchronize()
+            mine = self._recv
+        else:
+            mine = self._all[off * 32:(off + cnt) * 32]
+        if failure is not None:
+            raise failure            # ShardedProver._prove turns it into a poison record for the gather that follows
+        t2 = time.perf_counter()
+        seconds["witness_map"] += t1 - t0
+        seconds["scatter"] += t2 - t1
+        if self.on_host:
+            return mine.numpy()[:cnt * 32], False
+        return mine.data_ptr(), True
+
+
 class ShardedProver:
     """One proof across all ranks.  `prover` is any object with prove_partial(assignment, r, on_device) and
     assemble(partials, n_shards, r, s) — a crescent_credentials_amd.Prover loaded with shard_rank/shard_count
@@ -195,15 +255,29 @@ class ShardedProver:
     collectives whatever order its partial sums finish in), and the host finish of proof k runs while the partial sums
     of the next proofs are on the GPU."""
 
-    def __init__(self, prover, device, group=None):
+    def __init__(self, prover, device, group=None, arrangement: str = "recompute"):
+        """arrangement ("run the witness map on GPU 0 and scatter h, or recompute it redundantly on every GPU -
+        measure both"):
+          "recompute" - every rank runs the witness map for its own share of the h MSM (cg_prove_partial); one collective
+                        per proof, the 384-byte all_gather;
+          "scatter"   - rank 0 runs the witness map once for all shards (cg_witness_map_coset: domain_size x 32 B, shard-major),
+                        a scatter hands every rank its slice, and the ranks prove with it (cg_prove_partial_q; their contexts
+                        may be loaded with CG_FLAG_H_SCALARS_EXTERNAL and then hold no witness-map memory at all); two
+                        collectives per proof.  `prover` needs witness_map_coset / h_scalars_slice / prove_partial_q."""
+        if arrangement not in ("recompute", "scatter"):
+            raise ValueError("arrangement must be 'recompute' or 'scatter'")
         self.prover = prover
         self.device = device
         self.group = group
+        self.arrangement = arrangement
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.all_gathers = 0          # collectives issued so far (one per proof when world > 1)
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.all_gathers = 0          # all_gathers issued so far (one per proof when world > 1)
+        self.scatters = 0             # scatters issued so far ("scatter" arrangement: one per proof)
         self.proofs = 0
-        self.seconds = {"partial": 0.0, "gather": 0.0, "assemble": 0.0}
+        self.seconds = {"partial": 0.0, "gather": 0.0, "assemble": 0.0, "witness_map": 0.0, "scatter": 0.0}
         self._gather = PartialGather(device, group) if self.world > 1 else None
+        self._scatter = HScalarScatter(prover, device, group, self.rank, self.world) if arrangement == "scatter" else None
 
     def _prove(self, assignment, on_device: bool, r: int, s: int):
         """one sharded proof.  A shard that fails here does not leave the other ranks waiting in the collective either: the
@@ -212,7 +286,13 @@ class ShardedProver:
         t0 = time.perf_counter()
         failure = None
         try:
-            part = self.prover.prove_partial(assignment, r, on_device=on_device)
+            if self._scatter is not None:
+                q, q_on_device = self._scatter(assignment, on_device, self.seconds)
+                self.scatters += 1
+                t0 = time.perf_counter()
+                part = self.prover.prove_partial_q(assignment, q, r, on_device=on_device, q_on_device=q_on_device)
+            else:
+                part = self.prover.prove_partial(assignment, r, on_device=on_device)
         except BaseException as e:   # noqa: BLE001 - raised below, after the collective every rank is about to enter
             if self.world <= 1:
                 raise
@@ -255,6 +335,8 @@ class ShardedProver:
         n = len(jobs)
         if n == 0:
             return []
+        if self._scatter is not None:
+            raise NotImplementedError("prove_stream runs the 'recompute' arrangement; the 'scatter' arrangement is one proof at a time")
         # the poison check below reads one 384-byte record per rank: a batched gather (PartialGather(batch > 1), rank-major
         # world x batch x 384) would be mis-parsed
         assert self._gather is None or self._gather.batch == 1, "prove_stream exchanges one record per collective"

@@ -119,7 +119,12 @@ enum {
     CG_FLAG_SPIN_WAIT = 8,
     /* Sharded contexts (shard_count a power of two): own a contiguous range of the h query's coset points instead of
      * the points j = shard_rank (mod shard_count); the shard then runs four full-size transforms per proof. */
-    CG_FLAG_CONTIGUOUS_H_SHARDS = 16
+    CG_FLAG_CONTIGUOUS_H_SHARDS = 16,
+    /* Sharded contexts over a folded key (SURVEY 8e's other arrangement: "run the witness map on GPU 0 and scatter h"): this
+     * shard never runs the witness map - its h scalars arrive with every proof (cg_prove_partial_q), computed once for all
+     * shards by cg_witness_map_coset on a context loaded WITHOUT this flag.  The context then holds no witness-map vectors
+     * and no matrices; cg_prove_partial / cg_witness_map on it are CG_ERR_INVALID_ARGUMENT. */
+    CG_FLAG_H_SCALARS_EXTERNAL = 32
 };
 
 /* Per-phase wall/GPU times of one cg_prove call, mirroring the reference's `print-trace` phases
@@ -250,6 +255,23 @@ int cg_prove_partial(cg_ctx* ctx, const void* full_assignment, int assignment_on
                      const uint8_t r[32], uint8_t out_partials[384], cg_timings* timings);
 int cg_assemble(cg_ctx* ctx, const uint8_t* partials, uint32_t n_shards, const uint8_t r[32],
                 const uint8_t s[32], uint8_t proof_out[256]);
+
+/* SURVEY 8e's second arrangement of a sharded proof: the witness map runs ONCE (on one rank) and every shard receives the
+ * scalars of its share of the h MSM, instead of every shard repeating the sparse products and the full-size transforms.
+ * With the folded key (the default) those scalars are the coset values q_j = a(g w^j) b(g w^j) / Z(g), j < domain_size
+ * (r1cs_to_qap.rs:187,201-208 without c's part, which the folded l query carries).
+ *   cg_witness_map_coset : on a folded context WITHOUT CG_FLAG_H_SCALARS_EXTERNAL (whole or shard): all domain_size values,
+ *       32 B canonical each, to host or device memory, laid out SHARD-MAJOR for this context's shard_count - shard p's
+ *       scalars are the slice [offset_p, offset_p + count_p) that cg_h_scalars_slice reports (strided shards: q_{p + k·count},
+ *       k < domain_size / count; contiguous shards and unsharded contexts: natural order) - so a scatter sends contiguous
+ *       chunks.
+ *   cg_prove_partial_q   : cg_prove_partial with this shard's slice supplied (host or device memory); the witness map is
+ *       skipped.  Works on any shard context over a folded key; a context loaded with CG_FLAG_H_SCALARS_EXTERNAL can prove
+ *       no other way.  The assignment is still checked for canonical elements (as the witness map would), the slice too. */
+int cg_witness_map_coset(cg_ctx* ctx, const void* full_assignment, int assignment_on_device, void* q_out, int q_on_device);
+int cg_h_scalars_slice(const cg_ctx* ctx, uint32_t shard, uint64_t* offset, uint64_t* count);
+int cg_prove_partial_q(cg_ctx* ctx, const void* full_assignment, int assignment_on_device, const void* q_slice,
+                       int q_on_device, const uint8_t r[32], uint8_t out_partials[384], cg_timings* timings);
 
 /* R1CS -> QAP witness map only: h coefficients, domain_size x 32 B canonical.
  * Replaces: `LibsnarkReduction::witness_map_from_matrices`, r1cs_to_qap.rs:150-213. */

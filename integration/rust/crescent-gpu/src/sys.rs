@@ -9,6 +9,7 @@ pub const CG_FLAG_LATENCY_MODE: i32 = 2;
 pub const CG_FLAG_THROUGHPUT_MODE: i32 = 4;
 pub const CG_FLAG_SPIN_WAIT: i32 = 8;
 pub const CG_FLAG_CONTIGUOUS_H_SHARDS: i32 = 16;
+pub const CG_FLAG_H_SCALARS_EXTERNAL: i32 = 32;
 pub const CG_ERR_POLY_DEGREE_TOO_LARGE: c_int = -5;
 pub const CG_ERR_MALFORMED_KEY: c_int = -6;
 

@@ -300,6 +300,15 @@ static void test_signed_madd() {
             zlo = std::min(zlo, acc.zzz.l[8] / N8); zhi = std::max(zhi, acc.zzz.l[8] / N8);
             if ((it & 7) == 0 || kind < 2) {
                 XYZZ29<Fq29> st = acc_to_stored(acc);
+                {   // the record the accumulation writes and what its readers make of it (load_acc's conversion)
+                    uint32_t w[36], ref_w[36];
+                    pack_signed_record(acc, w);
+                    CHECK((w[26] & 0x80000000u) != 0, "signed record mark");
+                    signed_record_to_stored(w);
+                    store_limbs(st.x, ref_w); store_limbs(st.y, ref_w + 9); store_limbs(st.zz, ref_w + 18); store_limbs(st.zzz, ref_w + 27);
+                    CHECK(memcmp(w, ref_w, sizeof(w)) == 0, "signed record -> stored form");
+                    CHECK((ref_w[26] & 0xc0000000u) == 0, "a stored record never carries the mark");
+                }
                 check_inv(st.x, 13, "stored X"); check_inv(st.y, 8, "stored Y"); check_inv(st.zz, 3, "stored ZZ"); check_inv(st.zzz, 3, "stored ZZZ");
                 expect_same_point(st, false, ref, "signed madd chain");
                 // and the stored form feeds the unsigned formulas (the combine / reduction kernels)

@@ -34,21 +34,43 @@ class OracleShard:
     def __init__(self, o, pk, mats, l, m, M, rank, count):
         from crescent_credentials_amd.distributed import shard_range
         self.o, self.pk, self.mats, self.l, self.m, self.M = o, pk, mats, l, m, M
+        self.count = count
         D = o.domain_size_for(m + l)
         self.rh = shard_range(D - 1, rank, count)
         self.rl = shard_range(M - l, rank, count)
         self.ra = shard_range(M - 1, rank, count)
 
-    def prove_partial(self, w, r, on_device=False):
+    def prove_partial(self, w, r, on_device=False, h_slice=None):
         o, pk, l = self.o, self.pk, self.l
-        h = o.witness_map_from_matrices(self.mats, l, self.m, w)
         (h0, h1), (l0, l1), (a0, a1) = self.rh, self.rl, self.ra
-        ph = o.G1.to_affine(o.G1.msm(pk["h_query"][h0:h1], h[h0:h1]))
+        if h_slice is None:
+            h_slice = o.witness_map_from_matrices(self.mats, l, self.m, w)[h0:h1]
+            self.map_calls = getattr(self, "map_calls", 0) + 1
+        assert len(h_slice) == h1 - h0
+        ph = o.G1.to_affine(o.G1.msm(pk["h_query"][h0:h1], h_slice))
         pl = o.G1.to_affine(o.G1.msm(pk["l_query"][l0:l1], w[l + l0:l + l1]))
         pa = o.G1.to_affine(o.G1.msm(pk["a_query"][1 + a0:1 + a1], w[1 + a0:1 + a1]))
         pb1 = None if r == 0 else o.G1.to_affine(o.G1.msm(pk["b_g1_query"][1 + a0:1 + a1], w[1 + a0:1 + a1]))
         pb2 = o.G2.to_affine(o.G2.msm(pk["b_g2_query"][1 + a0:1 + a1], w[1 + a0:1 + a1]))
         return o.g1_packed(ph) + o.g1_packed(pl) + o.g1_packed(pa) + o.g1_packed(pb1) + o.g2_packed(pb2)
+
+    # the "scatter" arrangement's three calls (cg_witness_map_coset / cg_h_scalars_slice / cg_prove_partial_q).  The stand-in
+    # keeps the key as loaded, so "all the h scalars" are the coefficients of h and a shard's slice is its range of them
+    def witness_map_coset(self, w, on_device=False, out_dev=None):
+        h = self.o.witness_map_from_matrices(self.mats, self.l, self.m, w)
+        self.coset_calls = getattr(self, "coset_calls", 0) + 1
+        return b"".join(self.o.fe_bytes(x) for x in h)
+
+    def h_scalars_slice(self, shard):
+        from crescent_credentials_amd.distributed import shard_range
+        D = self.o.domain_size_for(self.m + self.l)
+        lo, hi = shard_range(D - 1, shard, self.count)
+        return lo, hi - lo
+
+    def prove_partial_q(self, w, q_slice, r, on_device=False, q_on_device=False):
+        q = bytes(q_slice)
+        hs = [int.from_bytes(q[i:i + 32], "little") for i in range(0, len(q), 32)]
+        return self.prove_partial(w, r, h_slice=hs)
 
     def assemble(self, parts, n, r, s):
         o, pk = self.o, self.pk
@@ -138,6 +160,15 @@ def _worker(rank, world, port, q):
             ok = ok and rank != 1 and "rank 1 failed" in str(e)
         c0_ = g["proofs"][0]
         ok = ok and spo.prove(w, int(c0_["r"], 16), int(c0_["s"], 16)).hex() == c0_["proof"] and spo.all_gathers == 2
+        # SURVEY 8e's other arrangement: the witness map runs on rank 0 only and a scatter hands out the h scalars
+        # (unequal slices here: the golden circuit's 7 h points over `world` ranks) - the same golden proofs, one
+        # scatter + one all_gather per proof, and no rank but 0 ever runs the witness map
+        shard_b = OracleShard(o, pk, _rows(g["matrices"]), g["num_inputs"], g["num_constraints"], g["num_variables"], rank, world)
+        sps = ShardedProver(shard_b, torch.device("cpu"), arrangement="scatter")
+        for case in g["proofs"]:
+            ok = ok and sps.prove(w, int(case["r"], 16), int(case["s"], 16)).hex() == case["proof"]
+        ok = ok and sps.all_gathers == sps.scatters == len(g["proofs"]) and getattr(shard_b, "map_calls", 0) == 0
+        ok = ok and getattr(shard_b, "coset_calls", 0) == (len(g["proofs"]) if rank == 0 else 0)
         from crescent_credentials_amd.distributed import control_group, gather_over_ranks, min_over_ranks
         ok = ok and control_group() is dist.group.WORLD          # gloo default group IS the control plane
         # (collectives are evaluated on every rank whatever `ok` holds: a short-circuit would leave the others waiting)

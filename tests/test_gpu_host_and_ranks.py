@@ -307,6 +307,14 @@ res["stream"] = [p.data.hex() for p in sp4.prove_stream(jobs, 4)]
 res["stream_gathers"] = sp4.all_gathers
 res["stream_latency_mode"] = ctx4.info()["latency_mode"]
 ctx4.close()
+# SURVEY 8e's other arrangement: the witness map on rank 0 only, a scatter of the h scalars, cg_prove_partial_q; every rank
+# but 0 holds a context WITHOUT witness-map resources (CG_FLAG_H_SCALARS_EXTERNAL)
+ctxs = cc.Prover(pk, cm, device=gpu, shard_rank=rank, shard_count=world, h_scalars_external=(rank != 0))
+sps = ShardedProver(ctxs, torch.device("cuda", gpu), arrangement="scatter")
+res["scatter_proofs"] = [(sps.prove(w, r, s) if i == 1 else sps.prove_dev(wd.data_ptr(), r, s)).data.hex() for i, (r, s) in enumerate(cases)]
+res["scatter_counts"] = [sps.scatters, sps.all_gathers]
+res["scatter_breakdown_ms"] = sps.breakdown_ms()
+ctxs.close()
 if rank == 0:
     import cpu_ref
     res["want"] = [cpu_ref.prove(pk, (cm.a, cm.b, cm.c), l, m, M, w, r, s, nthreads=16).hex() for r, s in cases]
@@ -339,6 +347,7 @@ def test_two_gloo_ranks_with_real_hip_shards_under_sharded_prover(shape, tmp_pat
         assert r["all_gathers"] == r["n"] == 3              # exactly one collective per proof
         assert r["info"] == 2
         assert r["stream"] == want * 3 and r["stream_gathers"] == 9 and r["stream_latency_mode"] == 0
+        assert r["scatter_proofs"] == want and r["scatter_counts"] == [3, 3]       # both arrangements: the same bytes
     assert len(set(want)) == 3
 
 
@@ -385,6 +394,7 @@ def test_two_rccl_ranks_with_real_hip_shards_under_sharded_prover(tmp_path):
     for r in res:
         assert r["proofs"] == res[0]["want"] and r["all_gathers"] == r["n"] == 3
         assert r["stream"] == res[0]["want"] * 3 and r["stream_gathers"] == 9
+        assert r["scatter_proofs"] == res[0]["want"] and r["scatter_counts"] == [3, 3]
 
 
 @pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs")

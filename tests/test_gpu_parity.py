@@ -798,6 +798,72 @@ def test_context_flags_change_the_arrangement_not_the_bytes(cc, oracle):
         whole.close()
 
 
+@pytest.mark.parametrize("contig", [False, True], ids=["strided", "contiguous"])
+def test_h_scalars_from_one_witness_map_for_all_shards(cc, oracle, contig):
+    """SURVEY 8e's other arrangement: the witness map runs ONCE (cg_witness_map_coset on a context that
+    has the resources) and every shard proves with its slice of the coset values (cg_prove_partial_q); shards loaded with
+    CG_FLAG_H_SCALARS_EXTERNAL hold no witness-map memory and can prove no other way.  Assembled bytes == the unsharded
+    context's, for slices arriving in host and in device memory, satisfying and arbitrary assignments, r = 0 included."""
+    import torch
+    from crescent_credentials_amd import workloads as wl
+    l, m, M = _CPU_SHAPES["log14"]
+    cm, w = wl.synthetic_circuit(79, l, m, M, 0.6, 3, profile="gates")
+    rng = random.Random(8)
+    pk = cc.generate_parameters_with_qap(cm, *[rng.randrange(1, oracle.R) for _ in range(4)])
+    w_bad = _scalars([rng.randrange(oracle.R) for _ in range(M)])
+    n = 4
+    whole = cc.Prover(pk, cm)
+    first = cc.Prover(pk, cm, shard_rank=0, shard_count=n, contiguous_h_shards=contig)                 # runs the witness map for everybody
+    others = [cc.Prover(pk, cm, shard_rank=k, shard_count=n, contiguous_h_shards=contig, h_scalars_external=True) for k in range(1, n)]
+    shards = [first] + others
+    try:
+        D = whole.domain_size
+        slices = [first.h_scalars_slice(k) for k in range(n)]
+        assert sum(c for _, c in slices) == D and slices[0][0] == 0
+        assert all(p.h_scalars_slice(k) == slices[k] for p in others for k in range(n))
+        assert first.info()["slot_transform_bytes"] > 4 * D * 32 > others[0].info()["slot_transform_bytes"]
+        for wit in (w, w_bad):
+            q = first.witness_map_coset(wit)
+            assert q.size == D * 32
+            qd = torch.from_numpy(q).cuda()
+            wd = torch.from_numpy(np.ascontiguousarray(wit)).cuda()
+            first.witness_map_coset(wd.data_ptr(), on_device=True, out_dev=qd.data_ptr())               # device in, device out: the same
+            assert bytes(qd.cpu().numpy()) == bytes(q)
+            for r, s in ((0, 0), (rng.randrange(oracle.R), rng.randrange(oracle.R))):
+                want = whole.prove(wit, r, s).data
+                parts_h = b"".join(p.prove_partial_q(wit, q[o * 32:(o + c) * 32], r) for p, (o, c) in zip(shards, slices))
+                parts_d = b"".join(p.prove_partial_q(wd.data_ptr(), qd.data_ptr() + o * 32, r, on_device=True, q_on_device=True)
+                                   for p, (o, c) in zip(shards, slices))
+                assert parts_h == parts_d
+                assert others[-1].assemble(parts_h, n, r, s).data == want
+                # and the recomputing arrangement on the shard that can: the same partial sums
+                assert first.prove_partial(wit, r) == parts_h[:384]
+        # what an external shard refuses, and what it checks
+        for bad_call in (lambda: others[0].prove_partial(w, 5), lambda: others[0].witness_map_coset(w), lambda: others[0].witness_map(w),
+                         lambda: whole.prove_partial_q(w, q[:32], 5)):
+            with pytest.raises(cc.CrescentGpuError) as ei:
+                bad_call()
+            assert ei.value.code == -1
+        o1, c1 = slices[1]
+        q_bad = q[o1 * 32:(o1 + c1) * 32].copy()
+        q_bad[32 * 3:32 * 4] = np.frombuffer(oracle.R.to_bytes(32, "little"), np.uint8)
+        with pytest.raises(cc.CrescentGpuError):
+            others[0].prove_partial_q(w, q_bad, 5)
+        w_nc = np.ascontiguousarray(w).copy()
+        w_nc[32 * 7:32 * 8] = np.frombuffer(oracle.R.to_bytes(32, "little"), np.uint8)
+        with pytest.raises(cc.CrescentGpuError):
+            others[0].prove_partial_q(w_nc, q[o1 * 32:(o1 + c1) * 32], 5)
+        assert others[0].prove_partial_q(w, q[o1 * 32:(o1 + c1) * 32], 0) is not None                       # and it still works afterwards
+        with pytest.raises(cc.CrescentGpuError):
+            cc.Prover(pk, cm, h_scalars_external=True)                                                   # needs a sharded context
+        with pytest.raises(cc.CrescentGpuError):
+            cc.Prover(pk, cm, shard_rank=0, shard_count=2, h_scalars_external=True, h_coefficient_basis=True)
+    finally:
+        whole.close()
+        for p in shards:
+            p.close()
+
+
 _CPU_SHAPES = {"log11": (4, 1_500, 1_600), "exact12": (6, 4_090, 4_200), "log13": (10, 5_000, 5_100), "log14": (3, 9_000, 16_000),
                "log15": (12, 20_000, 20_500), "medium": (20, 60_000, 61_000), "log17": (8, 100_000, 100_100), "large18": (26, 250_000, 255_000)}
 
