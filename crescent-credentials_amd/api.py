@@ -480,9 +480,10 @@ class Prover:
         _check(lib().cg_h_scalars_slice(self._h, shard, C.byref(off), C.byref(cnt)))
         return int(off.value), int(cnt.value)
 
-    def witness_map_coset(self, assignment, on_device: bool = False, out_dev: Optional[int] = None):
+    def witness_map_coset(self, assignment, on_device: bool = False, out_dev: Optional[int] = None, out_host: Optional[int] = None):
         """cg_witness_map_coset: ALL coset values q_j of the quotient's a·b part (folded key), domain_size x 32 B canonical,
-        shard-major for this context's shard count.  -> numpy bytes, or written to the device address out_dev."""
+        shard-major for this context's shard count.  -> numpy bytes, or written to the device address out_dev / the host
+        address out_host (domain_size x 32 writable bytes)."""
         if on_device:
             ptr = C.c_void_p(int(assignment))
         else:
@@ -490,6 +491,9 @@ class Prover:
             ptr = C.c_void_p(_ptr(w))
         if out_dev is not None:
             _check(lib().cg_witness_map_coset(self._h, ptr, 1 if on_device else 0, C.c_void_p(int(out_dev)), 1))
+            return None
+        if out_host is not None:
+            _check(lib().cg_witness_map_coset(self._h, ptr, 1 if on_device else 0, C.c_void_p(int(out_host)), 0))
             return None
         q = np.zeros(self.domain_size * 32, dtype=np.uint8)
         _check(lib().cg_witness_map_coset(self._h, ptr, 1 if on_device else 0, _ptr(q), 0))

@@ -811,12 +811,18 @@ __global__ void __launch_bounds__(256) CG_ACCUM_ATTR k_accum_affine(const uint64
 // A flushed run leaves as a SIGNED record (curve29.hpp store_acc_signed: the accumulator as it is, marked); load_acc brings
 // it to the stored (unsigned) invariant in the kernels that read it - a flush runs for a lane or two of a wave in 71 % of the
 // loop's iterations, so every instruction taken out of it is taken out of the loop.
+#if !defined(CG_FLUSH_HOW)
+#define CG_FLUSH_HOW 0
+#endif
+template <int FLUSH>
 __global__ void __launch_bounds__(256) CG_ACCUM_ATTR k_accum_affine_g1s(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ plan,
                                                           const uint32_t* __restrict__ table,
                                                           uint32_t* __restrict__ bucket_sums, uint32_t* __restrict__ part_keys,
                                                           uint32_t* __restrict__ part_pts) {
     typedef Fq29 F29T;
     constexpr int ACC = Words29<F29T>::ACC;
+    __shared__ __attribute__((aligned(16))) uint32_t flush_slots[FLUSH == 2 ? 4 * 36 : 4];       // one 144-byte slot per wave
+    uint32_t* const wave_slot = flush_slots + (FLUSH == 2 ? (threadIdx.x >> 6) * 36 : 0);
     const uint32_t N = plan[PLAN_N], L = plan[PLAN_L], T = plan[PLAN_T];
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
@@ -839,9 +845,9 @@ __global__ void __launch_bounds__(256) CG_ACCUM_ATTR k_accum_affine_g1s(const ui
             // the record leaves in the signed form (curve29.hpp store_acc_signed); its readers convert it
             if (first && !final_level) {
                 part_keys[2 * t] = cur;
-                store_acc_signed(part_pts + (size_t)(2 * t) * ACC, acc, inf);
+                store_acc_signed<FLUSH>(part_pts + (size_t)(2 * t) * ACC, acc, inf, wave_slot);
             } else {
-                store_acc_signed(bucket_sums + (size_t)cur * ACC, acc, inf);
+                store_acc_signed<FLUSH>(bucket_sums + (size_t)cur * ACC, acc, inf, wave_slot);
             }
             first = false;
             inf = true;
@@ -851,15 +857,15 @@ __global__ void __launch_bounds__(256) CG_ACCUM_ATTR k_accum_affine_g1s(const ui
         madd29s(acc, inf, p, (int32_t)v >> 31 | 1, neg1, neg2);       // sigma = -1 for a negative digit, +1 otherwise
     }
     if (final_level) {
-        store_acc_signed(bucket_sums + (size_t)cur * ACC, acc, inf);
+        store_acc_signed<FLUSH>(bucket_sums + (size_t)cur * ACC, acc, inf, wave_slot);
     } else if (first) {  // the whole segment is one run
         part_keys[2 * t] = cur;
-        store_acc_signed(part_pts + (size_t)(2 * t) * ACC, acc, inf);
+        store_acc_signed<FLUSH>(part_pts + (size_t)(2 * t) * ACC, acc, inf, wave_slot);
         part_keys[2 * t + 1] = cur;
-        store_acc_signed(part_pts + (size_t)(2 * t + 1) * ACC, acc, true);
+        store_acc_signed<FLUSH>(part_pts + (size_t)(2 * t + 1) * ACC, acc, true, wave_slot);
     } else {
         part_keys[2 * t + 1] = cur;
-        store_acc_signed(part_pts + (size_t)(2 * t + 1) * ACC, acc, inf);
+        store_acc_signed<FLUSH>(part_pts + (size_t)(2 * t + 1) * ACC, acc, inf, wave_slot);
     }
 }
 
@@ -1070,7 +1076,16 @@ static void launch_accum_affine(const uint64_t* entries, const uint32_t* plan, u
         // (tuning builds: CG_ACCUM_UNSIGNED=1 runs round 4's kernel on unsigned limbs - the A/B reference)
         static const bool unsigned_ref = CG_TUNE_ENV("ACCUM_UNSIGNED") != nullptr && CG_TUNE_ENV("ACCUM_UNSIGNED")[0] == '1';
         if (unsigned_ref) k_accum_affine<F29T><<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
-        else k_accum_affine_g1s<<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
+        else {
+#ifdef CG_TUNING      // CG_FLUSH=0 / 1 / 2: how a flushed record leaves (curve29.hpp store_acc_signed)
+            static const int how = [] { const char* e = CG_TUNE_ENV("FLUSH"); return e ? atoi(e) : CG_FLUSH_HOW; }();
+            if (how == 1) k_accum_affine_g1s<1><<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
+            else if (how == 2) k_accum_affine_g1s<2><<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
+            else k_accum_affine_g1s<0><<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
+#else
+            k_accum_affine_g1s<CG_FLUSH_HOW><<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
+#endif
+        }
     }
 }
 

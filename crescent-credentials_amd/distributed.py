@@ -197,6 +197,13 @@ class HScalarScatter:
         dev = torch.device("cpu") if self.on_host else device
         self._recv = torch.zeros(max(1, self.chunk), dtype=torch.uint8, device=dev)
         self._all = torch.zeros(total * 32, dtype=torch.uint8, device=dev) if rank == 0 else None
+        # a real context (cg_witness_map_coset) can write into host memory it is handed; page-locked when a GPU is there
+        self._direct_host = self.on_host and rank == 0 and hasattr(prover, "domain_size") and total == getattr(prover, "domain_size", -1)
+        if self._direct_host and torch.cuda.is_available():
+            try:
+                self._all = self._all.pin_memory()
+            except Exception:
+                pass
         equal = all(c * 32 == self.chunk for _, c in self.slices)
         # equal slices: the scatter list is views of the one vector; otherwise padded copies
         self._pad = None if equal or rank != 0 else [torch.zeros(max(1, self.chunk), dtype=torch.uint8, device=dev) for _ in range(world)]
@@ -210,8 +217,11 @@ class HScalarScatter:
         if self.rank == 0:
             try:
                 if self.on_host:
-                    got = np.frombuffer(bytes(self.prover.witness_map_coset(assignment, on_device=on_device)), dtype=np.uint8)
-                    self._all.numpy()[:] = got[:self._all.numel()]        # (a prover may return more than its shards' slices cover)
+                    if self._direct_host:       # the library writes straight into the (page-locked) tensor the scatter sends from
+                        self.prover.witness_map_coset(assignment, on_device=on_device, out_host=self._all.data_ptr())
+                    else:
+                        got = np.frombuffer(bytes(self.prover.witness_map_coset(assignment, on_device=on_device)), dtype=np.uint8)
+                        self._all.numpy()[:] = got[:self._all.numel()]    # (a stand-in may return more than its shards' slices cover)
                 else:
                     self.prover.witness_map_coset(assignment, on_device=on_device, out_dev=self._all.data_ptr())
             except BaseException as e:   # noqa: BLE001 - raised after the scatter the other ranks are already waiting in

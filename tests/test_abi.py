@@ -480,3 +480,28 @@ def test_level1_grouping_kernels_use_no_scratch(cc, tmp_path):
                 seen += 1
                 assert int(ps.group(1)) == 0, "%s uses %s bytes of scratch per thread" % (nm.group(1), ps.group(1))
     assert seen >= 30, seen
+
+
+def test_stream_order_audit_of_the_kernel_sources():
+    """VERDICT r4 #7 (the hipMemset race of round 4 was found by luck): no call in csrc/ may run on the legacy default
+    stream or be a synchronous copy / fill - the default stream does not order itself against the non-blocking streams
+    every context works on.  Enforced on the sources: no hipMemcpy( / hipMemset( / hipMemcpyDtoH-style synchronous forms,
+    every kernel launch names a stream, every stream is created non-blocking, and hipDeviceSynchronize appears only in the
+    four *_free entry points ("stream-order audit")."""
+    csrc = os.path.join(ROOT, "crescent-credentials_amd", "csrc")
+    dev_syncs = []
+    for f in sorted(os.listdir(csrc)):
+        src = open(os.path.join(csrc, f)).read()
+        code = re.sub(r"//[^\n]*", "", src)
+        code = re.sub(r"/\*.*?\*/", "", code, flags=re.S)
+        for bad in (r"\bhipMemcpy\s*\(", r"\bhipMemset\s*\(", r"\bhipMemcpy(DtoH|HtoD|DtoD)\s*\(", r"\bhipMemcpy2D\s*\(",
+                    r"\bhipMemsetD(8|16|32)\s*\(", r"\bhipStreamCreate\s*\(", r"\bhipMemcpyToSymbol\s*\(", r"\bhipMemcpyFromSymbol\s*\("):
+            m = re.search(bad, code)
+            assert not m, "%s: %s" % (f, code[m.start():m.start() + 60] if m else "")
+        for m in re.finditer(r"<<<(.*?)>>>", code, flags=re.S):
+            parts = [p.strip() for p in re.split(r",(?![^()]*\))", m.group(1))]
+            assert len(parts) == 4 and parts[3] not in ("0", "nullptr", "NULL", "hipStreamDefault"), "%s: launch without a stream: <<<%s>>>" % (f, m.group(1)[:80])
+        for m in re.finditer(r"hipStreamCreateWithFlags\s*\(([^;]*?)\)\s*\)?;", code):
+            assert "hipStreamNonBlocking" in m.group(1), "%s: blocking stream" % f
+        dev_syncs += [f] * len(re.findall(r"\bhipDeviceSynchronize\s*\(", code))
+    assert sorted(dev_syncs) == ["prover.hip", "unit.hip", "unit.hip", "unit.hip"], dev_syncs

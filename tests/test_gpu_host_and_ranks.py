@@ -429,7 +429,10 @@ def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 12 and d["value"] > 0 and d["timing"]["blocks"] == 3
     sh = d["sharded"]
     assert sh["ranks"] == 2 and sh["backend"] == "gloo" and sh["bytes_identical_to_unsharded"] is True
-    assert sh["all_gathers"] == sh["proofs"] == 6 and set(sh["ms_breakdown_rank0"]) == {"partial", "gather", "assemble"}
+    assert sh["all_gathers"] == sh["proofs"] == 6 and set(sh["ms_breakdown_rank0"]) >= {"partial", "gather", "assemble"}
+    arr = sh["arrangements"]                      # both arrangements measured in the same run
+    assert arr["recompute"]["ms_per_proof"] == sh["ms_per_proof"] and arr["scatter"]["bytes_identical_to_unsharded"] is True
+    assert arr["scatter"]["scatters"] == arr["scatter"]["all_gathers"] == 6 and arr["scatter"]["ms_per_proof"] > 0
     assert "error" not in sh and "backend_fallback" not in sh
     fl = sh["in_flight"]
     assert fl["proofs_in_flight"] == 8 and fl["all_gathers"] == fl["proofs"] and fl["bytes_identical_to_unsharded"] is True
