@@ -60,6 +60,14 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E (guides/MI355X_MICROARCH.md)
 PEAK_CLOCK_GHZ = 2.4
 VALU_PEAK = 256 * 4 * PEAK_CLOCK_GHZ * 1e9 / 4   # wave-instructions/s: 256 CUs x 4 SIMDs, one VALU instruction per 4 cycles at 2.4 GHz
+# What the vector ALU really issues (round 5, tools/ubench/valu_rates.hip -> profiles/r05_e_valu_issue_rates.txt, cycles per
+# wave-instruction per SIMD): the 64-bit multiply-add the limb products are made of takes 4.91 - not the 4 the nominal peak
+# assumes - other VOP3 / 64-bit integer operations 4.5, and simple 32-bit VOP1/VOP2 operations (mov, and, add, sub, shifts)
+# 2.5.  With the static mix of the hot loops (G1 mixed addition 72 / 14 / 14 %, butterflies 68 / 21 / 11 %: ~70 % multiply-adds,
+# ~16 % simple, ~14 % other) an instruction of this workload costs 4.47 cycles: the ceiling is 0.895 of the nominal peak.
+ISSUE_CYCLES = {"mad64": 4.91, "other": 4.5, "simple32": 2.5}
+ISSUE_MIX = {"mad64": 0.70, "other": 0.14, "simple32": 0.16}
+MIX_CYCLES = sum(ISSUE_CYCLES[k] * ISSUE_MIX[k] for k in ISSUE_MIX)
 G1_PAIR_BYTES = 96             # 64 B affine base + 32 B scalar   
 G2_PAIR_BYTES = 160
 SWEEP_FRACTIONS = (0.0, 0.5, 0.75, 0.9)
@@ -507,12 +515,19 @@ def main():
                  "frac_of_sustained_clock_peak": round(instr * value / world / (VALU_PEAK * sustained / PEAK_CLOCK_GHZ), 4)
                  if instr and sustained else None,
                  "wave_instr_per_proof": instr,
+                 "issue_model": {"cycles_per_wave_instr": ISSUE_CYCLES, "static_mix_of_the_hot_loops": ISSUE_MIX,
+                                 "cycles_per_wave_instr_of_this_mix": round(MIX_CYCLES, 3),
+                                 "source": "tools/ubench/valu_rates.hip on MI355X (profiles/r05_e_valu_issue_rates.txt); mix from the ISA of "
+                                           "k_accum_affine / k_ntt29_pass"},
+                 "frac_of_mix_ceiling_at_sustained_clock": round(instr * value / world / (VALU_PEAK * 4.0 / MIX_CYCLES * sustained / PEAK_CLOCK_GHZ), 4)
+                 if instr and sustained else None,
                  "counters": {"source": "committed pass (profiles/pmc_counters.json), not this run", "csrc_sha16_of_pass": pmc.get("csrc_sha16"),
                               "csrc_sha16_of_this_tree": fingerprint, "current": bool(pmc_current)},
                  "note": "SQ_INSTS_VALU per steady-state proof from the committed rocprofv3 --pmc pass of this command for this "
                          "workload (null when none is committed for the kernel sources on disk) x this run's proofs/s per GPU, "
                          "against 256 CU x 4 SIMD x 2.4 GHz / 4; sustained_clock_ghz is measured on the device during the "
-                         "timed proofs (cg_probe_shader_clock)"}
+                         "timed proofs (cg_probe_shader_clock); frac_of_mix_ceiling_at_sustained_clock prices an instruction at what "
+                         "the vector ALU measurably takes for it (issue_model) instead of 4 cycles"}
 
     out = {
         "metric": "Groth16 proofs/sec (rs256-sd-shaped circuit, BN254), G1 MSM scalar-adds/sec reported alongside",

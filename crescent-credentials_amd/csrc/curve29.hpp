@@ -136,16 +136,17 @@ CG_HD Affine29<F> unpack_point(const RawPoint29<F>& r, bool negate) {
 template <class F>
 CG_HD void store_acc(uint32_t* __restrict__ dst, const XYZZ29<F>& a, bool inf) {
     constexpr int ACC = Words29<F>::ACC;
+    uint4* p = reinterpret_cast<uint4*>(dst);
+    if (inf) {       // a branch of its own (rare), not a select on every word of the common case
+#pragma unroll
+        for (int i = 0; i < ACC / 4; ++i) p[i] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
     uint32_t w[ACC];
     store_limbs(a.x, w);
     store_limbs(a.y, w + ACC / 4);
     store_limbs(a.zz, w + ACC / 2);
     store_limbs(a.zzz, w + 3 * ACC / 4);
-    if (inf) {
-#pragma unroll
-        for (int i = 0; i < ACC; ++i) w[i] = 0;
-    }
-    uint4* p = reinterpret_cast<uint4*>(dst);
 #pragma unroll
     for (int i = 0; i < ACC / 4; ++i) p[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }

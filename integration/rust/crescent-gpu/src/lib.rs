@@ -197,7 +197,15 @@ impl GpuCircuit {
         }
         let (rb, sb) = (r.into_bigint().to_bytes_le(), s.into_bigint().to_bytes_le());
         let mut out = [0u8; 256];
-        let rc = unsafe { sys::cg_prove(self.ctx, buf.as_ptr(), rb.as_ptr(), sb.as_ptr(), out.as_mut_ptr(), std::ptr::null_mut()) };
+        // the phases the reference prints under its `print-trace` feature (forks/groth16/Cargo.toml:48; start_timer! /
+        // end_timer! at prover.rs:35-36,62,93,103,115,123), with the GPU's own times: cg_timings mirrors them 1:1
+        let mut tm = sys::cg_timings::default();
+        let tm_ptr: *mut sys::cg_timings = if cfg!(feature = "print-trace") { &mut tm } else { std::ptr::null_mut() };
+        let rc = unsafe { sys::cg_prove(self.ctx, buf.as_ptr(), rb.as_ptr(), sb.as_ptr(), out.as_mut_ptr(), tm_ptr) };
+        #[cfg(feature = "print-trace")]
+        if rc == 0 {
+            print_trace(&tm);
+        }
         if let Some(p) = pinned {
             let mut pool = self.pool.lock().unwrap();
             if pool.len() < self.pool_max {
@@ -210,6 +218,22 @@ impl GpuCircuit {
         // a ‖ b ‖ c, ark-serialize uncompressed (data_structures.rs:7-14)
         Proof::deserialize_uncompressed_unchecked(&out[..]).map_err(|_| SynthesisError::MalformedVerifyingKey)
     }
+}
+
+/// The reference's `print-trace` output for one proof, phase names as prover.rs spells them, times from cg_timings (the
+/// five MSMs overlap on the GPU, so the phases do not add up to the total the way the CPU prover's do).
+#[cfg(feature = "print-trace")]
+fn print_trace(tm: &sys::cg_timings) {
+    let line = |depth: usize, name: &str, ms: f32| println!("{}End:     {} {:.3}ms", "··".repeat(depth), name, ms);
+    println!("Start:   Groth16::Prover");                                                  // prover.rs:35
+    line(1, "R1CS to QAP witness map", tm.witness_map_ms);                                 // :36
+    line(1, "Compute C", tm.msm_h_ms.max(tm.msm_l_ms));                                    // :62  (h_query and l_query MSMs)
+    line(1, "Compute A", tm.msm_a_ms);                                                     // :93
+    line(1, "Compute B in G1", tm.msm_b1_ms);                                              // :103 (0 when r = 0: skipped, :102-112)
+    line(1, "Compute B in G2", tm.msm_b2_ms);                                              // :115
+    line(1, "Finish C", tm.finish_ms);                                                     // :123
+    line(1, "(upload of the assignment)", tm.upload_ms);
+    line(0, "Groth16::Prover", tm.total_ms);                                               // :48
 }
 
 impl GpuCircuit {

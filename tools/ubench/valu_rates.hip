@@ -56,6 +56,34 @@ __global__ void __launch_bounds__(256) k_rate(uint32_t* out, int iters, uint32_t
         } else if (KIND == 11) {  // v_mul_u32_u24
             REP64(asm volatile("v_mul_u32_u24 %0, %0, %4\n v_mul_u32_u24 %1, %1, %4\n v_mul_u32_u24 %2, %2, %4\n v_mul_u32_u24 %3, %3, %4\n"
                                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed));)
+        } else if (KIND == 13) {  // v_mad_i64_i32 (the signed product of round 5's G1 accumulation)
+            REP64(asm volatile("v_mad_i64_i32 %0, s[10:11], %4, %5, %0\n v_mad_i64_i32 %1, s[10:11], %4, %6, %1\n"
+                               "v_mad_i64_i32 %2, s[10:11], %5, %6, %2\n v_mad_i64_i32 %3, s[10:11], %6, %7, %3\n"
+                               : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "s10", "s11");)
+        } else if (KIND == 14) {  // v_ashrrev_i64
+            REP64(asm volatile("v_ashrrev_i64 %0, 29, %0\n v_ashrrev_i64 %1, 29, %1\n v_ashrrev_i64 %2, 29, %2\n v_ashrrev_i64 %3, 29, %3\n"
+                               : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));)
+        } else if (KIND == 15) {  // v_lshrrev_b64
+            REP64(asm volatile("v_lshrrev_b64 %0, 29, %0\n v_lshrrev_b64 %1, 29, %1\n v_lshrrev_b64 %2, 29, %2\n v_lshrrev_b64 %3, 29, %3\n"
+                               : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));)
+        } else if (KIND == 16) {  // v_xad_u32
+            REP64(asm volatile("v_xad_u32 %0, %0, %4, %1\n v_xad_u32 %1, %1, %4, %2\n v_xad_u32 %2, %2, %4, %3\n v_xad_u32 %3, %3, %4, %0\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed));)
+        } else if (KIND == 17) {  // v_and_b32 (VOP2)
+            REP64(asm volatile("v_and_b32 %0, %0, %1\n v_and_b32 %1, %1, %2\n v_and_b32 %2, %2, %3\n v_and_b32 %3, %3, %0\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+        } else if (KIND == 18) {  // v_mad_u64_u32 with an SGPR multiplier (the constant limbs of N)
+            REP64(asm volatile("v_mad_u64_u32 %0, s[10:11], %4, s12, %0\n v_mad_u64_u32 %1, s[10:11], %5, s12, %1\n"
+                               "v_mad_u64_u32 %2, s[10:11], %6, s12, %2\n v_mad_u64_u32 %3, s[10:11], %7, s12, %3\n"
+                               : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "s10", "s11", "s12");)
+        } else if (KIND == 19) {  // a dependent chain: ONE accumulator, as in a product's column (4 waves per SIMD hide it or not)
+            REP64(asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %2, %0\n v_mad_u64_u32 %0, s[10:11], %2, %3, %0\n"
+                               "v_mad_u64_u32 %0, s[10:11], %3, %4, %0\n v_mad_u64_u32 %0, s[10:11], %4, %1, %0\n"
+                               : "+v"(d0) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "s10", "s11");)
+        } else if (KIND == 20) {  // the same chain signed
+            REP64(asm volatile("v_mad_i64_i32 %0, s[10:11], %1, %2, %0\n v_mad_i64_i32 %0, s[10:11], %2, %3, %0\n"
+                               "v_mad_i64_i32 %0, s[10:11], %3, %4, %0\n v_mad_i64_i32 %0, s[10:11], %4, %1, %0\n"
+                               : "+v"(d0) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "s10", "s11");)
         } else if (KIND == 12) {  // v_cndmask_b32
             REP64(asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %0, vcc\n"
                                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) :: "vcc");)
@@ -112,6 +140,14 @@ int main() {
     run<8>("v_fma_f64", 4, d_out, clk);
     run<9>("v_add3_u32", 4, d_out, clk);
     run<12>("v_cndmask_b32", 4, d_out, clk);
+    run<13>("v_mad_i64_i32", 4, d_out, clk);
+    run<14>("v_ashrrev_i64", 4, d_out, clk);
+    run<15>("v_lshrrev_b64", 4, d_out, clk);
+    run<16>("v_xad_u32", 4, d_out, clk);
+    run<17>("v_and_b32", 4, d_out, clk);
+    run<18>("v_mad_u64_u32 sgpr operand", 4, d_out, clk);
+    run<19>("v_mad_u64_u32 one chain", 4, d_out, clk);
+    run<20>("v_mad_i64_i32 one chain", 4, d_out, clk);
     // field mul throughput
     {
         const int blocks = 256 * 8, threads = 256, iters = 2000;
