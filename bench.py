@@ -497,7 +497,7 @@ def main():
     pmc = pmc or {}
     fingerprint = source_fingerprint()
     sustained = clock.median() if clock else None
-    roof = {"kernel": "k_accum_affine<Fq> (G1 bucket accumulation)", "bound": "hbm", "achieved": round(achieved, 2),
+    roof = {"kernel": "k_accum_affine_g1s (G1 bucket accumulation, signed 29-bit limbs)", "bound": "hbm", "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": pmc.get("accum_affine_g1_hbm_bytes_per_launch") if pmc_current else None,
             "launches_per_proof": launches, "avg_launch_ms": round(acc_ms / launches, 4),

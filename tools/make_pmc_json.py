@@ -16,7 +16,7 @@ def rows(db, ctr):
 
 key, fdb, wdb, vdb, cmd = sys.argv[1:6]
 out_path = sys.argv[6] if len(sys.argv) > 6 else None
-is_acc = lambda n: "k_accum_affine<" in n and "Fq2_29" not in n
+is_acc = lambda n: ("k_accum_affine<" in n and "Fq2_29" not in n) or "k_accum_affine_g1s" in n     # the G1 accumulation, either form
 f, nf = rows(fdb, "FETCH_SIZE")
 w, nw = rows(wdb, "WRITE_SIZE")
 v, nv = rows(vdb, "SQ_INSTS_VALU")

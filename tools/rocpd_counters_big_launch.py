@@ -7,7 +7,7 @@ usage: rocpd_counters_big_launch.py results.db [kernel-substring]"""
 import sqlite3, sys
 
 db = sqlite3.connect(sys.argv[1])
-pat = sys.argv[2] if len(sys.argv) > 2 else "k_accum_affine<cg::F29<cg::Fq29P"
+pat = sys.argv[2] if len(sys.argv) > 2 else "k_accum_affine_g1s"
 rows = db.execute("select kernel_name, counter_name, value, start from counters_collection").fetchall()
 t_tab = max([r[3] for r in rows if "k_table_next" in r[0]] + [0])
 by = {}

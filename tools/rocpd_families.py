@@ -11,7 +11,7 @@ import re
 import sqlite3
 import sys
 
-FAMILIES = [("G1 accumulation", r"k_accum_affine<"), ("G2 accumulation", r"k_accum_affine_g2"), ("transform passes", r"k_ntt29_pass"),
+FAMILIES = [("G1 accumulation", r"k_accum_affine<|k_accum_affine_g1s"), ("G2 accumulation", r"k_accum_affine_g2"), ("transform passes", r"k_ntt29_pass"),
             ("sparse products", r"k_sell29"), ("grouping (count/place)", r"k_part_"), ("combine levels", r"k_combine_wave"),
             ("bucket reduction", r"k_bucket_|k_bit_sums"), ("witness conversion / fills / folds", r"k_w_to29|k_fill_zero|k_fold29|k_replan")]
 out_path, dbs = sys.argv[1], sys.argv[2:]
