@@ -633,19 +633,34 @@ def _content_digest(*arrays) -> bytes:
     return h.digest()
 
 
-def _freeze(*arrays) -> tuple:
-    """The digest of an object is remembered on it, so its arrays must not change afterwards: they are made read-only
-    (an in-place write then raises instead of silently proving against the old resident copy), and the memo also carries
-    where each array lives - an attribute REPLACED by another array (the supported way to change a key or a matrix) is
-    seen and hashed again."""
+class _Held:
+    """The arrays a content digest was computed over, HELD (so that neither their ids nor their addresses can be recycled by
+    an array that replaces them: the memo of rounds 3-4 kept (id, address, size) only, and a dropped array's id and address
+    are commonly handed to the next one of the same size) and compared by identity."""
+
+    def __init__(self, arrays):
+        self.arrays = tuple(arrays)
+
+    def same_as(self, arrays) -> bool:
+        return len(arrays) == len(self.arrays) and all(a is b for a, b in zip(arrays, self.arrays))
+
+
+def _freeze(*arrays) -> "_Held":
+    """The digest of an object is remembered on it, so its arrays must not change afterwards: they are made read-only - and so
+    is every array they are views of, since a write through a writable base would change them all the same - so that an
+    in-place write raises instead of silently proving against the old resident copy.  (A side effect on arrays the caller
+    owns, documented on Groth16.prove / Prover: the key and matrix arrays a prover was made from become read-only.)  An
+    attribute REPLACED by another array (the supported way to change a key or a matrix) is seen - the memo holds the
+    arrays themselves - and hashed again."""
     for a in arrays:
-        if isinstance(a, np.ndarray):
-            a.setflags(write=False)
-    return _where(arrays)
-
-
-def _where(arrays) -> tuple:
-    return tuple((id(a), a.__array_interface__["data"][0], a.size) if isinstance(a, np.ndarray) else (id(a), 0, len(a)) for a in arrays)
+        b = a
+        while isinstance(b, np.ndarray):
+            try:
+                b.setflags(write=False)
+            except ValueError:
+                pass
+            b = b.base
+    return _Held(arrays)
 
 
 def _matrices_key(m: "ConstraintMatrices") -> tuple:
@@ -653,7 +668,7 @@ def _matrices_key(m: "ConstraintMatrices") -> tuple:
     per object and remembered on it; the arrays are immutable from then on, see _freeze)"""
     arrays = (m.a.row_ptr, m.a.col, m.a.coeff, m.b.row_ptr, m.b.col, m.b.coeff, m.c.row_ptr, m.c.col, m.c.coeff)
     memo = getattr(m, "_content_key", None)
-    if memo is not None and memo[0] == _where(arrays):
+    if memo is not None and memo[0].same_as(arrays):
         return memo[1]
     k = (m.num_instance_variables, m.num_witness_variables, m.num_constraints, m.a.nnz, m.b.nnz, m.c.nnz, _content_digest(*arrays))
     m._content_key = (_freeze(*arrays), k)
@@ -665,7 +680,7 @@ def _pk_key(pk: "ProvingKey") -> tuple:
     arrays = (pk.vk.alpha_g1, pk.vk.beta_g2, pk.vk.gamma_g2, pk.vk.delta_g1, pk.vk.delta_g2, pk.vk.gamma_abc_g1,
               pk.beta_g1, pk.delta_g1, pk.a_query, pk.b_g1_query, pk.b_g2_query, pk.h_query, pk.l_query)
     memo = getattr(pk, "_content_key", None)
-    if memo is not None and memo[0] == _where(arrays) and memo[2] == pk.coord_form:
+    if memo is not None and memo[0].same_as(arrays) and memo[2] == pk.coord_form:
         return memo[1]
     k = (pk.coord_form, pk.a_query.size, pk.h_query.size, pk.l_query.size, _content_digest(*arrays))
     pk._content_key = (_freeze(*arrays), k, pk.coord_form)

@@ -125,3 +125,30 @@ def test_counter_pass_is_tied_to_the_kernel_sources():
     finally:
         mod.EXTRA_FLAGS[:] = old_flags
     assert mod.source_fingerprint() == fp
+
+
+def test_content_digest_memo_holds_its_arrays_and_freezes_bases():
+    """the digest memo kept (id, address, size) of the arrays, which CPython and malloc recycle - a replaced
+    array of the same size could be taken for the old one.  It now holds the arrays and compares by identity; and a view's
+    writable base is frozen with it."""
+    import numpy as np
+    from crescent_credentials_amd import api
+    base = np.arange(64 * 4, dtype=np.uint8)
+    view = base[:64]
+    held = api._freeze(view, b"abc")
+    assert held.same_as((view, held.arrays[1])) and not held.same_as((base[:64], held.arrays[1]))     # another view object: not "the same"
+    assert not view.flags.writeable and not base.flags.writeable
+    import pytest
+    with pytest.raises(ValueError):
+        base[0] = 1
+    # a replacing array that lands on the old one's address cannot be confused with it: the memo keeps the old one alive
+    rows = [[(1, 0)], [(1, 1)]]
+    cm = api.ConstraintMatrices.from_rows(rows, rows, rows, 1, 2)
+    k1 = api._matrices_key(cm)
+    assert api._matrices_key(cm) is k1
+    old = cm.a.coeff
+    cm.a.coeff = old.copy()
+    cm.a.coeff.setflags(write=True)
+    cm.a.coeff[0] ^= 1
+    assert api._matrices_key(cm) != k1
+    assert cm._content_key[0].arrays[2] is cm.a.coeff and old is not cm.a.coeff
