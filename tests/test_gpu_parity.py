@@ -390,6 +390,44 @@ def test_msm_context_matches_one_shot_and_closed_form(cc, oracle, group):
             ctx.close()
 
 
+@pytest.mark.parametrize("wb", [3, 8, 14, 0])
+def test_signed_accumulation_rare_branches_on_the_gpu(cc, oracle, wb):
+    """Round 5's G1 accumulation keeps its running sum on signed limbs with the sign of Y tracked apart (curve29.hpp madd29s).
+    Its rare branches - the same point met again (doubling, under either sign of the digit and of the tracked sign), a point
+    and its negative (cancellation: an empty run flushed as an identity record), runs that restart after a cancellation - are
+    reached here on purpose: ONE base repeated (every addition inside a bucket is a doubling candidate), P and -P alternating,
+    and both with scalars that put many entries into the same bucket with mixed digit signs; against the closed form
+    (Σ s_i k_i)·G, through resident tables with narrow, medium, wide and default windows, twice per handle."""
+    rng = random.Random(505 + wb)
+    n = 6001
+    k0 = rng.randrange(1, oracle.R)
+    bases_sets = {
+        "one base": [k0] * n,
+        "P and -P": [k0 if i & 1 else oracle.R - k0 for i in range(n)],
+        "three bases": [(k0, 2 * k0 % oracle.R, oracle.R - k0)[i % 3] for i in range(n)],
+    }
+    half = 1 << ((wb or 13) - 1)
+    pops = {
+        "ones": [1] * n,
+        "minus ones": [oracle.R - 1] * n,                                   # every digit pattern negative at the top
+        "same digit both signs": [(half - 1) if i & 1 else (half + 1) for i in range(n)],       # |d| equal, sign differs after recoding
+        "uniform": [rng.randrange(oracle.R) for _ in range(n)],
+        "two values": [5 if i % 3 else oracle.R - 5 for i in range(n)],
+    }
+    for bname, ks in bases_sets.items():
+        bases = cc.fixed_base_g1(_scalars(ks))
+        ctx = cc.MsmContext(bases, group=1, window_bits=wb)
+        try:
+            for pname, sc in pops.items():
+                e = sum(k * s_ for k, s_ in zip(ks, sc)) % oracle.R
+                exp = oracle.g1_packed(oracle.G1.to_affine(oracle.G1.mul_affine(oracle.G1_GEN, e))) if e else bytes(64)
+                arr = _scalars(sc)
+                assert ctx.run(arr) == exp, (wb, bname, pname)
+                assert ctx.run(arr) == exp, (wb, bname, pname, "second run")
+        finally:
+            ctx.close()
+
+
 @pytest.mark.parametrize("group,n", [(1, 200_003), (2, 40_001)])
 def test_msm_grouping_and_combine_edge_cases(cc, oracle, group, n):
     """The entry grouping (two-level counting partition) and the wave-level piece combination on the populations that
