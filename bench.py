@@ -124,11 +124,13 @@ def parse():
                          "the control plane is always gloo")
     ap.add_argument("--allow-shared-gpu", action="store_true",
                     help="N > visible GPUs: let several ranks share a GPU (implied by --backend gloo; RCCL needs a GPU per rank)")
-    ap.add_argument("--inflight", type=int, default=12,
+    ap.add_argument("--inflight", type=int, default=16,
                     help="proofs in flight per GPU: host threads x context proof_slots, one stream each.  Round 4 (70 launches per proof): "
                          "6: 177.5, 8: 188.7, 10: 191.6, 12: 196.8, 16: 196.8 proofs/s on one box (profiles/r04_m_inflight_low.txt) - twelve "
                          "give the rate of sixteen with a quarter less memory and time in the pipeline per proof; round 3 (84 launches) "
-                         "needed sixteen (8: 185, 12: 194, 16: 197)")
+                         "needed sixteen (8: 185, 12: 194, 16: 197).  Round 5, with the witness arriving in HOST memory (the headline): the "
+                         "upload adds to a proof's time in flight and sixteen are worth +1 % again: 10: 192.9, 12: 196.3, 16: 198.2 "
+                         "(profiles/r05_i_inflight_and_tiles.txt; 28.9 GB resident)")
     ap.add_argument("--assignments", type=int, default=4, help="device-resident assignments the timed proofs rotate over")
     ap.add_argument("--no-clock-probe", action="store_true",
                     help="do not sample the shader clock during the timed proofs (profiling runs: under rocprofv3 --pmc kernels "
