@@ -785,6 +785,35 @@ def main():
                                            "witness map (DESIGN.md 6), so sharded proofs cost more GPU time in total than whole ones: "
                                            "sharding buys latency, replicas buy throughput"}
                 assert same_p, "pipelined sharded proof differs from the unsharded one"
+                # the same stream in the other arrangement: ONE witness map per proof, on rank k mod ranks for job k, a scatter
+                # of the coset values, cg_prove_partial_q everywhere (scatters and gathers on two groups, from two threads)
+                if not a.h_coefficient_basis:
+                    try:
+                        pps = ShardedProver(pp_ctx, dev, group=grp, arrangement="scatter", rotate=True, stream_slots=kfl)
+                        pps.prove_stream(mk(2 * kfl), kfl)
+                        barrier_sync(world)
+                        jobs_s = mk(njobs)
+                        times_s = []
+                        s0_, g0_ = pps.scatters, pps.all_gathers
+                        pps.reset_breakdown()
+                        proofs_s = pps.prove_stream(jobs_s, kfl, done_times=times_s)
+                        torch.cuda.synchronize()
+                        barrier_sync(world)
+                        times_s.sort()
+                        win_s = max_over_ranks(times_s[-1] - times_s[skip - 1], world)
+                        rate_s = (njobs - skip) / win_s
+                        same_s2 = proofs_s[0] is not None and proofs_s[0].data == prover.prove_dev(jobs_s[0][0], jobs_s[0][1], jobs_s[0][2]).data
+                        sh["in_flight"]["scatter_rotating"] = {
+                            "proofs_per_s": round(rate_s, 3), "ms_per_proof": round(1e3 / rate_s, 3),
+                            "over_replica_rate_of_the_same_ranks": round(rate_s / value, 4), "over_recompute_in_flight": round(rate_s / rate, 4),
+                            "scatters": pps.scatters - s0_, "all_gathers": pps.all_gathers - g0_, "ms_breakdown_rank0": pps.breakdown_ms(),
+                            "bytes_identical_to_unsharded": bool(same_s2),
+                            "note": "one full witness map per proof on rank (job mod ranks) instead of a partial one on every rank"}
+                        assert same_s2, "the rotating-scatter stream's proof differs from the unsharded one"
+                    except AssertionError:
+                        raise
+                    except Exception as e:
+                        sh["in_flight"]["scatter_rotating"] = {"error": repr(e)}
                 pp_ctx.close()
         except AssertionError:
             raise

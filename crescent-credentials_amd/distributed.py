@@ -183,22 +183,24 @@ def gather_partials(partial: bytes, device, group=None) -> bytes:
 
 
 class HScalarScatter:
-    """The exchange step of the "scatter" arrangement: rank 0 computes every shard's h scalars (witness_map_coset), each rank
+    """The exchange step of the "scatter" arrangement: ONE rank computes every shard's h scalars (witness_map_coset), each rank
     receives its slice.  Chunks are padded to the longest slice (strided shards are all domain_size / world long); buffers are
     allocated once; with RCCL they live on the device - 32 B x domain_size / world per peer, each over its own xGMI link - with
-    gloo on the host."""
+    gloo on the host.  `slots` receive buffers let several proofs' slices be held at once (ShardedProver.prove_stream); with
+    `rotate` any rank may be asked to be the source (it then holds the 32 B x domain_size send buffer too)."""
 
-    def __init__(self, prover, device, group, rank: int, world: int):
-        self.prover, self.group, self.rank, self.world = prover, group, rank, world
+    def __init__(self, prover, device, group, rank: int, world: int, slots: int = 1, rotate: bool = False):
+        self.prover, self.group, self.rank, self.world, self.rotate = prover, group, rank, world, rotate
         self.on_host = (world <= 1) or _on_host(group)
         self.slices = [prover.h_scalars_slice(p) for p in range(world)]
         self.chunk = max(c for _, c in self.slices) * 32
         total = max(o + c for o, c in self.slices)
         dev = torch.device("cpu") if self.on_host else device
-        self._recv = torch.zeros(max(1, self.chunk), dtype=torch.uint8, device=dev)
-        self._all = torch.zeros(total * 32, dtype=torch.uint8, device=dev) if rank == 0 else None
+        self._recv = [torch.zeros(max(1, self.chunk), dtype=torch.uint8, device=dev) for _ in range(max(1, slots))]
+        sends = rank == 0 or rotate
+        self._all = torch.zeros(total * 32, dtype=torch.uint8, device=dev) if sends else None
         # a real context (cg_witness_map_coset) can write into host memory it is handed; page-locked when a GPU is there
-        self._direct_host = self.on_host and rank == 0 and hasattr(prover, "domain_size") and total == getattr(prover, "domain_size", -1)
+        self._direct_host = self.on_host and sends and hasattr(prover, "domain_size") and total == getattr(prover, "domain_size", -1)
         if self._direct_host and torch.cuda.is_available():
             try:
                 self._all = self._all.pin_memory()
@@ -206,15 +208,19 @@ class HScalarScatter:
                 pass
         equal = all(c * 32 == self.chunk for _, c in self.slices)
         # equal slices: the scatter list is views of the one vector; otherwise padded copies
-        self._pad = None if equal or rank != 0 else [torch.zeros(max(1, self.chunk), dtype=torch.uint8, device=dev) for _ in range(world)]
-        self.src = dist.get_global_rank(group, 0) if (world > 1 and group is not None) else 0
+        self._pad = None if equal or not sends else [torch.zeros(max(1, self.chunk), dtype=torch.uint8, device=dev) for _ in range(world)]
 
-    def __call__(self, assignment, on_device: bool, seconds: dict):
-        """-> (this rank's slice: a device address or numpy bytes, whether it is on the device)"""
+    def _global(self, r: int) -> int:
+        return dist.get_global_rank(self.group, r) if (self.world > 1 and self.group is not None) else r
+
+    def exchange(self, assignment, on_device: bool, seconds: dict, src: int = 0, slot: int = 0):
+        """Rank `src` (of the group) runs the witness map on `assignment` and scatters; every rank's slice lands in receive
+        buffer `slot`.  -> (this rank's slice: a device address or numpy bytes, whether it is on the device).  A witness
+        map that fails on the source is raised there AFTER the scatter the other ranks are already waiting in."""
         t0 = time.perf_counter()
         off, cnt = self.slices[self.rank]
         failure = None
-        if self.rank == 0:
+        if self.rank == src:
             try:
                 if self.on_host:
                     if self._direct_host:       # the library writes straight into the (page-locked) tensor the scatter sends from
@@ -224,32 +230,36 @@ class HScalarScatter:
                         self._all.numpy()[:] = got[:self._all.numel()]    # (a stand-in may return more than its shards' slices cover)
                 else:
                     self.prover.witness_map_coset(assignment, on_device=on_device, out_dev=self._all.data_ptr())
-            except BaseException as e:   # noqa: BLE001 - raised after the scatter the other ranks are already waiting in
+            except BaseException as e:   # noqa: BLE001
                 failure = e
         t1 = time.perf_counter()
+        recv = self._recv[slot]
         if self.world > 1:
             lst = None
-            if self.rank == 0:
+            if self.rank == src:
                 if self._pad is None:
                     lst = [self._all[o * 32:o * 32 + self.chunk] for o, _ in self.slices]
                 else:
                     for p, (o, c) in enumerate(self.slices):
                         self._pad[p][:c * 32].copy_(self._all[o * 32:(o + c) * 32])
                     lst = self._pad
-            dist.scatter(self._recv, lst, src=self.src, group=self.group)
+            dist.scatter(recv, lst, src=self._global(src), group=self.group)
             if not self.on_host:
-                torch.cuda.current_stream(self._recv.device).synchronize()
-            mine = self._recv
+                torch.cuda.current_stream(recv.device).synchronize()
+            mine = recv
         else:
             mine = self._all[off * 32:(off + cnt) * 32]
         if failure is not None:
-            raise failure            # ShardedProver._prove turns it into a poison record for the gather that follows
+            raise failure            # the caller turns it into a poison record for the gather that follows
         t2 = time.perf_counter()
         seconds["witness_map"] += t1 - t0
         seconds["scatter"] += t2 - t1
         if self.on_host:
             return mine.numpy()[:cnt * 32], False
         return mine.data_ptr(), True
+
+    def __call__(self, assignment, on_device: bool, seconds: dict):
+        return self.exchange(assignment, on_device, seconds, 0, 0)
 
 
 class ShardedProver:
@@ -265,7 +275,7 @@ class ShardedProver:
     collectives whatever order its partial sums finish in), and the host finish of proof k runs while the partial sums
     of the next proofs are on the GPU."""
 
-    def __init__(self, prover, device, group=None, arrangement: str = "recompute"):
+    def __init__(self, prover, device, group=None, arrangement: str = "recompute", rotate: bool = False, stream_slots: int = 8):
         """arrangement ("run the witness map on GPU 0 and scatter h, or recompute it redundantly on every GPU -
         measure both"):
           "recompute" - every rank runs the witness map for its own share of the h MSM (cg_prove_partial); one collective
@@ -273,7 +283,11 @@ class ShardedProver:
           "scatter"   - rank 0 runs the witness map once for all shards (cg_witness_map_coset: domain_size x 32 B, shard-major),
                         a scatter hands every rank its slice, and the ranks prove with it (cg_prove_partial_q; their contexts
                         may be loaded with CG_FLAG_H_SCALARS_EXTERNAL and then hold no witness-map memory at all); two
-                        collectives per proof.  `prover` needs witness_map_coset / h_scalars_slice / prove_partial_q."""
+                        collectives per proof.  `prover` needs witness_map_coset / h_scalars_slice / prove_partial_q.
+                        `rotate`: in a STREAM of sharded proofs (prove_stream) the rank that runs the witness map of proof k is
+                        k mod world instead of always rank 0 - every rank then needs a context with witness-map resources -
+                        so that the one full witness map per proof is spread over the ranks; `stream_slots` bounds the proofs in
+                        flight of such a stream (a receive buffer each)."""
         if arrangement not in ("recompute", "scatter"):
             raise ValueError("arrangement must be 'recompute' or 'scatter'")
         self.prover = prover
@@ -287,7 +301,17 @@ class ShardedProver:
         self.proofs = 0
         self.seconds = {"partial": 0.0, "gather": 0.0, "assemble": 0.0, "witness_map": 0.0, "scatter": 0.0}
         self._gather = PartialGather(device, group) if self.world > 1 else None
-        self._scatter = HScalarScatter(prover, device, group, self.rank, self.world) if arrangement == "scatter" else None
+        self.rotate = bool(rotate)
+        self._stream_slots = max(1, stream_slots)
+        self._scatter = (HScalarScatter(prover, device, group, self.rank, self.world, slots=self._stream_slots, rotate=self.rotate)
+                         if arrangement == "scatter" else None)
+        # a stream of scatter-arrangement proofs issues scatters from one thread and gathers from another: each sequence on a
+        # group of its own, so that every rank sees both in the same order whatever the threads' interleaving is
+        self._gather_stream = None
+        if arrangement == "scatter" and self.world > 1:
+            g2 = dist.new_group(ranks=[dist.get_global_rank(group, r) for r in range(self.world)] if group is not None else None,
+                                backend=dist.get_backend(group))
+            self._gather_stream = PartialGather(device, g2)
 
     def _prove(self, assignment, on_device: bool, r: int, s: int):
         """one sharded proof.  A shard that fails here does not leave the other ranks waiting in the collective either: the
@@ -346,7 +370,7 @@ class ShardedProver:
         if n == 0:
             return []
         if self._scatter is not None:
-            raise NotImplementedError("prove_stream runs the 'recompute' arrangement; the 'scatter' arrangement is one proof at a time")
+            return self._prove_stream_scatter(jobs, in_flight, on_device, done_times)
         # the poison check below reads one 384-byte record per rank: a batched gather (PartialGather(batch > 1), rank-major
         # world x batch x 384) would be mis-parsed
         assert self._gather is None or self._gather.batch == 1, "prove_stream exchanges one record per collective"
@@ -420,6 +444,130 @@ class ShardedProver:
                     ev.set()
 
         ts = [threading.Thread(target=worker) for _ in range(in_flight)] + [threading.Thread(target=gatherer)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if fatal:
+            raise fatal[0]
+        if mine:
+            raise mine[0][1]
+        if theirs:
+            raise RuntimeError("sharded proof stream: " + ", ".join("rank %d failed on job %d" % (q, k) for k, q in theirs[:8]))
+        return proofs
+
+    def _prove_stream_scatter(self, jobs, in_flight: int, on_device: bool, done_times: Optional[list]):
+        """prove_stream in the "scatter" arrangement.  Three kinds of thread per rank: ONE producer walks the jobs in order -
+        on the job's source rank (k mod world with `rotate`, else rank 0) it runs the witness map, then every rank takes part
+        in the scatter of job k - `in_flight` workers prove with the slices as they arrive (cg_prove_partial_q) and finish the
+        proofs, ONE gatherer exchanges the 384-byte records in job order.  Scatters and gathers run on two groups.  A job whose
+        witness map or partial sums fail on some rank is poisoned for every rank through the gather, as in prove_stream."""
+        n = len(jobs)
+        in_flight = max(1, min(in_flight, n, self._stream_slots))
+        world, rank, sc = self.world, self.rank, self._scatter
+        gather = self._gather_stream
+        src_of = (lambda k: k % world) if self.rotate else (lambda k: 0)
+        parts, gathered, proofs = [None] * n, [None] * n, [None] * n
+        slices = [None] * n
+        if done_times is not None:
+            done_times[:] = [0.0] * n
+        q_ready = [threading.Event() for _ in range(n)]
+        have_part = [threading.Event() for _ in range(n)]
+        have_all = [threading.Event() for _ in range(n)]
+        nxt = [0]
+        lock = threading.Lock()
+        mine, theirs, fatal = [], [], []
+
+        def producer():
+            try:
+                if not sc.on_host:
+                    torch.cuda.set_device(self.device)
+                for k in range(n):
+                    if k >= in_flight:
+                        have_part[k - in_flight].wait()        # its receive buffer is free again
+                    if fatal:
+                        return
+                    a = jobs[k][0]
+                    try:
+                        slices[k] = sc.exchange(a, on_device, self.seconds, src_of(k), k % in_flight)
+                        self.scatters += 1
+                    except BaseException as e:   # noqa: BLE001 - this rank's witness map failed (the scatter itself was done)
+                        self.scatters += 1
+                        mine.append((k, e))
+                        slices[k] = None
+                    q_ready[k].set()
+            except BaseException as e:           # noqa: BLE001 - the transport failed
+                fatal.append(e)
+                for ev in q_ready + have_all:
+                    ev.set()
+
+        def worker():
+            while not fatal:
+                with lock:
+                    k = nxt[0]
+                    nxt[0] += 1
+                if k >= n:
+                    return
+                a, r, s = jobs[k]
+                q_ready[k].wait()
+                if fatal:
+                    return
+                t0 = time.perf_counter()
+                if slices[k] is None:
+                    parts[k] = POISON
+                else:
+                    try:
+                        q, q_dev = slices[k]
+                        parts[k] = self.prover.prove_partial_q(a, q, r, on_device=on_device, q_on_device=q_dev)
+                    except BaseException as e:   # noqa: BLE001
+                        mine.append((k, e))
+                        parts[k] = POISON
+                t1 = time.perf_counter()
+                have_part[k].set()
+                have_all[k].wait()
+                if fatal or gathered[k] is None:
+                    continue
+                try:
+                    t2 = time.perf_counter()
+                    proofs[k] = self.prover.assemble(gathered[k], world, r, s)
+                    t3 = time.perf_counter()
+                except BaseException as e:   # noqa: BLE001
+                    mine.append((k, e))
+                    continue
+                if done_times is not None:
+                    done_times[k] = t3
+                with lock:
+                    self.seconds["partial"] += t1 - t0
+                    self.seconds["assemble"] += t3 - t2
+                    self.proofs += 1
+
+        def gatherer():
+            try:
+                if gather is not None and not gather.on_host:
+                    torch.cuda.set_device(self.device)
+                for k in range(n):
+                    have_part[k].wait()
+                    if fatal:
+                        return
+                    t0 = time.perf_counter()
+                    if world > 1:
+                        allp = gather(parts[k])
+                        self.all_gathers += 1
+                    else:
+                        allp = parts[k]
+                    bad = [q for q in range(world) if allp[PARTIAL_BYTES * q:PARTIAL_BYTES * (q + 1)] == POISON]
+                    if bad:
+                        theirs.extend((k, q) for q in bad)
+                    else:
+                        gathered[k] = allp
+                    self.seconds["gather"] += time.perf_counter() - t0
+                    have_all[k].set()
+            except BaseException as e:           # noqa: BLE001
+                fatal.append(e)
+                for ev in q_ready + have_all + have_part:
+                    ev.set()
+
+        ts = [threading.Thread(target=producer)] + [threading.Thread(target=worker) for _ in range(in_flight)] + [threading.Thread(target=gatherer)]
         for t in ts:
             t.start()
         for t in ts:

@@ -169,6 +169,38 @@ def _worker(rank, world, port, q):
             ok = ok and sps.prove(w, int(case["r"], 16), int(case["s"], 16)).hex() == case["proof"]
         ok = ok and sps.all_gathers == sps.scatters == len(g["proofs"]) and getattr(shard_b, "map_calls", 0) == 0
         ok = ok and getattr(shard_b, "coset_calls", 0) == (len(g["proofs"]) if rank == 0 else 0)
+        # ... and a STREAM of such proofs, the rank that runs the witness map rotating from job to job (k mod world): scatters
+        # from one thread, gathers from another (two groups), three proofs in flight per rank; every proof the golden one, one
+        # scatter + one gather per job, and the witness maps spread over the ranks
+        shard_c = OracleShard(o, pk, _rows(g["matrices"]), g["num_inputs"], g["num_constraints"], g["num_variables"], rank, world)
+        spr = ShardedProver(shard_c, torch.device("cpu"), arrangement="scatter", rotate=True, stream_slots=3)
+        jobs_r = [(w, int(c["r"], 16), int(c["s"], 16)) for c in g["proofs"] * 4]
+        times_r = []
+        got_r = spr.prove_stream(jobs_r, in_flight=3, on_device=False, done_times=times_r)
+        ok = ok and [p_.hex() for p_ in got_r] == [c["proof"] for c in g["proofs"] * 4]
+        ok = ok and spr.scatters == spr.all_gathers == len(jobs_r) and all(t > 0 for t in times_r)
+        mine_maps = len([k for k in range(len(jobs_r)) if k % world == rank])
+        ok = ok and getattr(shard_c, "coset_calls", 0) == mine_maps and getattr(shard_c, "map_calls", 0) == 0
+        # a witness map that fails on its source rank poisons that one job for everybody; the stream goes on
+        class FlakyMap:
+            def __init__(self, inner, fail_on_call):
+                self.inner, self.fail_on_call, self.calls = inner, fail_on_call, 0
+            def witness_map_coset(self, w_, on_device=False, out_dev=None):
+                self.calls += 1
+                if self.calls == self.fail_on_call:
+                    raise ValueError("witness map fault injected on rank %d" % rank)
+                return self.inner.witness_map_coset(w_, on_device=on_device)
+            def __getattr__(self, name):
+                return getattr(self.inner, name)
+        spq = ShardedProver(FlakyMap(shard_c, 1 if rank == 1 else -1), torch.device("cpu"), arrangement="scatter", rotate=True, stream_slots=2)
+        try:
+            spq.prove_stream(jobs_r[:6], in_flight=2, on_device=False)
+            ok = False
+        except ValueError as e:
+            ok = ok and rank == 1 and "injected" in str(e)
+        except RuntimeError as e:
+            ok = ok and rank != 1 and "rank 1 failed on job 1" in str(e)
+        ok = ok and spq.scatters == spq.all_gathers == 6
         from crescent_credentials_amd.distributed import control_group, gather_over_ranks, min_over_ranks
         ok = ok and control_group() is dist.group.WORLD          # gloo default group IS the control plane
         # (collectives are evaluated on every rank whatever `ok` holds: a short-circuit would leave the others waiting)

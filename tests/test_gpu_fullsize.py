@@ -107,6 +107,26 @@ def test_full_size_sharded_contexts_assemble_to_the_same_proof(cc, oracle, shape
         assert shards[0].assemble(parts, n, r, s).data == exp2
         parts = b"".join(p.prove_partial(w, 0) for p in shards)            # r = 0: b1 skipped (prover.rs:102-112)
         got0 = shards[n - 1].assemble(parts, n, 0, 0).data
+        # SURVEY 8e's other arrangement at the same size: ONE witness map for all shards (cg_witness_map_coset on shard 0's
+        # context, the D coset values shard-major), every shard - the other n - 1 as fresh contexts that hold no witness-map
+        # memory (CG_FLAG_H_SCALARS_EXTERNAL) - proves with its slice (cg_prove_partial_q): the same bytes
+        import torch
+        for p in shards[1:]:
+            p.close()
+        del shards[1:]
+        for k in range(1, n):
+            shards.append(cc.Prover(pk, cm, shard_rank=k, shard_count=n, h_scalars_external=True))
+        D = shards[0].domain_size
+        qd = torch.empty(D * 32, dtype=torch.uint8, device="cuda")
+        for wit, want in ((w, exp), (w2, exp2)):
+            wd = torch.from_numpy(np.ascontiguousarray(wit)).cuda()
+            shards[0].witness_map_coset(wd.data_ptr(), on_device=True, out_dev=qd.data_ptr())
+            slices = [shards[0].h_scalars_slice(k) for k in range(n)]
+            assert sum(c for _, c in slices) == D
+            parts = b"".join(p.prove_partial_q(wd.data_ptr(), qd.data_ptr() + o * 32, r, on_device=True, q_on_device=True)
+                             for p, (o, c) in zip(shards, slices))
+            assert shards[-1].assemble(parts, n, r, s).data == want
+        del qd
     finally:
         for p in shards:
             p.close()

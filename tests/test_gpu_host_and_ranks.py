@@ -315,6 +315,12 @@ res["scatter_proofs"] = [(sps.prove(w, r, s) if i == 1 else sps.prove_dev(wd.dat
 res["scatter_counts"] = [sps.scatters, sps.all_gathers]
 res["scatter_breakdown_ms"] = sps.breakdown_ms()
 ctxs.close()
+# ... and a stream of such proofs with the witness-map rank rotating (every rank a full shard context, three in flight)
+ctxr = cc.Prover(pk, cm, device=gpu, shard_rank=rank, shard_count=world, proof_slots=3)
+spr = ShardedProver(ctxr, torch.device("cuda", gpu), arrangement="scatter", rotate=True, stream_slots=3)
+res["rotating_stream"] = [p.data.hex() for p in spr.prove_stream([(wd.data_ptr(), r, s) for r, s in cases * 2], 3)]
+res["rotating_counts"] = [spr.scatters, spr.all_gathers]
+ctxr.close()
 if rank == 0:
     import cpu_ref
     res["want"] = [cpu_ref.prove(pk, (cm.a, cm.b, cm.c), l, m, M, w, r, s, nthreads=16).hex() for r, s in cases]
@@ -348,6 +354,7 @@ def test_two_gloo_ranks_with_real_hip_shards_under_sharded_prover(shape, tmp_pat
         assert r["info"] == 2
         assert r["stream"] == want * 3 and r["stream_gathers"] == 9 and r["stream_latency_mode"] == 0
         assert r["scatter_proofs"] == want and r["scatter_counts"] == [3, 3]       # both arrangements: the same bytes
+        assert r["rotating_stream"] == want * 2 and r["rotating_counts"] == [6, 6]
     assert len(set(want)) == 3
 
 
@@ -395,6 +402,7 @@ def test_two_rccl_ranks_with_real_hip_shards_under_sharded_prover(tmp_path):
         assert r["proofs"] == res[0]["want"] and r["all_gathers"] == r["n"] == 3
         assert r["stream"] == res[0]["want"] * 3 and r["stream_gathers"] == 9
         assert r["scatter_proofs"] == res[0]["want"] and r["scatter_counts"] == [3, 3]
+        assert r["rotating_stream"] == res[0]["want"] * 2 and r["rotating_counts"] == [6, 6]
 
 
 @pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs")
@@ -437,6 +445,8 @@ def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
     fl = sh["in_flight"]
     assert fl["proofs_in_flight"] == 8 and fl["all_gathers"] == fl["proofs"] and fl["bytes_identical_to_unsharded"] is True
     assert fl["proofs_per_s"] > 0
+    sr = fl["scatter_rotating"]                   # the same stream with one witness map per proof, its rank rotating
+    assert sr["bytes_identical_to_unsharded"] is True and sr["scatters"] == sr["all_gathers"] == fl["proofs"] and sr["proofs_per_s"] > 0
     assert len(d["value_per_rank"]) == 2 and abs(sum(d["value_per_rank"]) - d["value"]) < 0.35 * d["value"]
     assert d["proof_verifies"] is True and d["key_check"]["ok"] is True and d["key_check"]["proof_equals_trapdoor_closed_form"] is True
     assert d["timing"]["window_proofs"] == 36 and abs(d["ms_per_step"] * d["value"] / 2 - 1000.0) < 1.0
@@ -478,6 +488,7 @@ def test_bench_gpus_8_as_eight_processes_on_the_one_gpu():
     assert sh["bytes_identical_to_unsharded"] is True and sh["all_gathers"] == sh["proofs"] == 6
     fl = sh["in_flight"]
     assert fl["proofs_in_flight"] == 2 and fl["all_gathers"] == fl["proofs"] == 16 and fl["bytes_identical_to_unsharded"] is True
+    assert fl["scatter_rotating"]["bytes_identical_to_unsharded"] is True and fl["scatter_rotating"]["scatters"] == 16
 
 
 @pytest.mark.skipif(_gpus() != 1, reason="the RCCL failure is provoked by two ranks sharing the one GPU")
