@@ -211,6 +211,10 @@ __global__ void __launch_bounds__(256) k_sell29(const uint32_t* __restrict__ sli
     const uint32_t base = slice_ptr[s], len = (slice_ptr[s + 1] - base) >> 6;
     Fr29 acc = Fr29::zero();
     uint32_t cnt = 0;
+#if !defined(CG_SELL_BATCH)
+#define CG_SELL_BATCH 0
+#endif
+#if CG_SELL_BATCH == 0
     for (uint32_t t = 0; t < len; ++t) {
         const uint32_t ci = cidx[base + t * 64 + lane];
         if (ci == SELL_PAD) continue;
@@ -219,6 +223,51 @@ __global__ void __launch_bounds__(256) k_sell29(const uint32_t* __restrict__ sli
         acc = add(acc, v);
         if ((++cnt & 3u) == 0) acc = normalize(acc);            // limbs stay below 5·2^29
     }
+#else
+    // (experiment, -DCG_SELL_BATCH=2 / 4; measured in round 5 and NOT the default)  A piece has at most SELL_PIECE = 8 terms,
+    // and a term is two DEPENDENT reads (its column index, then the gathered vector element): walked term by term a lane makes
+    // up to sixteen memory round trips one after the other.  Here all index pairs of the piece are requested first, then the
+    // gathers CG_SELL_BATCH at a time: 376 -> 320 us per proof stand-alone (45 -> 120 VGPRs), and no difference in the
+    // pipeline - 201.5 / 202.0 against 202.1 proofs/s over four alternating rounds (profiles/
+    // r05_m_twiddle_ahead_and_sparse_batches.txt): the kernel's waits are filled by the other proofs' kernels.
+    constexpr uint32_t BS = CG_SELL_BATCH;
+    uint32_t ci[SELL_PIECE], cl[SELL_PIECE];
+#pragma unroll
+    for (uint32_t t = 0; t < SELL_PIECE; ++t) {
+        const bool in = t < len;                                // uniform over the slice's 64 lanes
+        ci[t] = in ? cidx[base + t * 64 + lane] : SELL_PAD;
+        cl[t] = in ? col[base + t * 64 + lane] : 0u;
+    }
+#pragma unroll
+    for (uint32_t h = 0; h < SELL_PIECE; h += BS) {
+        if (h >= len) break;
+        uint4 rv[BS][2], rd[BS][2];
+#pragma unroll
+        for (uint32_t u = 0; u < BS; ++u) {
+            const uint32_t t = h + u;
+            if (ci[t] == SELL_PAD) continue;
+            const uint4* pv = reinterpret_cast<const uint4*>(src + (uint64_t)cl[t] * 8);
+            rv[u][0] = pv[0]; rv[u][1] = pv[1];
+            if (ci[t] != 0) {
+                const uint4* pd = reinterpret_cast<const uint4*>(dict + (uint64_t)ci[t] * 8);
+                rd[u][0] = pd[0]; rd[u][1] = pd[1];
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < BS; ++u) {
+            const uint32_t t = h + u;
+            if (ci[t] == SELL_PAD) continue;
+            const uint32_t wv[8] = {rv[u][0].x, rv[u][0].y, rv[u][0].z, rv[u][0].w, rv[u][1].x, rv[u][1].y, rv[u][1].z, rv[u][1].w};
+            Fr29 v = unpack29<Fr29P>(wv);
+            if (ci[t] != 0) {                                   // index 0 is the literal one (is_one() shortcut :31-35)
+                const uint32_t wd[8] = {rd[u][0].x, rd[u][0].y, rd[u][0].z, rd[u][0].w, rd[u][1].x, rd[u][1].y, rd[u][1].z, rd[u][1].w};
+                v = mul(v, unpack29<Fr29P>(wd));
+            }
+            acc = add(acc, v);
+            if ((++cnt & 3u) == 0) acc = normalize(acc);        // limbs stay below 5·2^29
+        }
+    }
+#endif
     const uint32_t d = dst[p];
     const Fr29 r = weak_reduce(normalize(acc));     // below 3N: fits the packed form; nothing downstream needs the canonical value
     if (d & SELL_FINAL) store_packed29(out, brev(d & ~SELL_FINAL, logn), r);
@@ -296,13 +345,37 @@ __global__ void __launch_bounds__(256 << (TSL - 10)) k_ntt29_pass(const uint32_t
         }
         lds_put(sm, e, x);
     }
+    // The FIRST twiddle of the next stage pair is requested ahead (round 5).  A thread takes exactly one radix-4 group per
+    // pair (tsize / 4 <= NT), so its twiddles depend on nothing but indices: the one its first two butterflies need (w1; for
+    // the product-free first pair, the only one there is) is requested as soon as the current pair's results are on their
+    // way to LDS, BEFORE the barrier - its L2 round trip then runs under the barrier and the next pair's LDS reads instead
+    // of after them (31 % of the passes' wave-cycles sat in s_waitcnt) - and the other two are requested at the top of
+    // the pair and arrive under the first two butterflies.  Nine more registers live across the barrier; holding all three
+    // ahead costs 129-152 VGPRs and a block per CU.
+    auto group_of = [&](int jj, uint32_t& k, int& sh1, int& sh2) {
+        const int q = pp.q0 + jj;
+        const int lb = pp.cbits + (q - pp.gbit_lo);
+        const uint32_t lmask = (1u << lb) - 1u;
+        sh1 = pp.logn - 1 - q; sh2 = pp.logn - 2 - q;
+        const uint32_t bb = threadIdx.x;
+        const uint32_t e00 = ((bb & ~lmask) << 2) | (bb & lmask);
+        k = l2g29(e00, tile, pp) & ((1u << q) - 1u);
+    };
+    auto first_twiddle_of = [&](int jj, Fr29& w) {
+        if (jj + 1 >= pp.S || threadIdx.x >= (tsize >> 2)) return;
+        uint32_t k; int sh1, sh2;
+        group_of(jj, k, sh1, sh2);
+        w = (pp.q0 + jj == 0) ? load_tw(tw, (uint64_t)1 << sh2) : load_tw(tw, (uint64_t)k << sh1);
+    };
+    Fr29 w_first;
+    first_twiddle_of(0, w_first);
     __syncthreads();
     int j = 0;
     for (; j + 1 < pp.S; j += 2) {                      // radix-4: stages q and q+1
         const int q = pp.q0 + j;
         const int lb = pp.cbits + (q - pp.gbit_lo);
         const uint32_t lmask = (1u << lb) - 1u;
-        const int sh1 = pp.logn - 1 - q, sh2 = pp.logn - 2 - q;
+        const int sh2 = pp.logn - 2 - q;
         for (uint32_t b = threadIdx.x; b < (tsize >> 2); b += NT) {
             const uint32_t e00 = ((b & ~lmask) << 2) | (b & lmask);
             const uint32_t e01 = e00 | (1u << lb), e10 = e00 | (2u << lb), e11 = e00 | (3u << lb);
@@ -322,13 +395,12 @@ __global__ void __launch_bounds__(256 << (TSL - 10)) k_ntt29_pass(const uint32_t
                 t = x2;
                 x2 = sub<12, 2>(x0, t);
                 x0 = add(x0, t);
-                bfly(x1, x3, load_tw(tw, (uint64_t)1 << sh2));
+                bfly(x1, x3, w_first);
             } else {
-                const Fr29 w1 = load_tw(tw, (uint64_t)k << sh1);
-                bfly(x0, x1, w1);
-                bfly(x2, x3, w1);
-                const Fr29 w2a = load_tw(tw, (uint64_t)k << sh2);
+                const Fr29 w2a = load_tw(tw, (uint64_t)k << sh2);                   // arrive under the two w1 butterflies
                 const Fr29 w2b = load_tw(tw, (uint64_t)(k + (1u << q)) << sh2);
+                bfly(x0, x1, w_first);
+                bfly(x2, x3, w_first);
                 bfly(x0, x2, w2a);
                 bfly(x1, x3, w2b);
             }
@@ -337,6 +409,7 @@ __global__ void __launch_bounds__(256 << (TSL - 10)) k_ntt29_pass(const uint32_t
             lds_put(sm, e10, normalize(x2));
             lds_put(sm, e11, normalize(x3));
         }
+        first_twiddle_of(j + 2, w_first);
         __syncthreads();
     }
     if (j < pp.S) {                                     // odd stage count: one radix-2 stage
@@ -357,6 +430,10 @@ __global__ void __launch_bounds__(256 << (TSL - 10)) k_ntt29_pass(const uint32_t
         __syncthreads();
     }
     const uint32_t smask = (1u << pp.S) - 1u;
+    // (Round 5 also tried requesting all of a thread's four elements - and the last pass's per-element factors - before the
+    // first is used, with the loops unrolled over a constant trip count: +3 % instructions from the predicated unrolled
+    // bodies, every pass 4-7 % slower stand-alone, -0.7 % in the pipeline: profiles/r05_l_ntt_batched_loads.txt.  The two
+    // co-resident blocks of a CU already cover each other's load and store phases.)
     for (uint32_t f = threadIdx.x; f < tsize; f += NT) {
         uint32_t e = f;
         if (store_bitrev) {   // walk the tile so that consecutive lanes hit consecutive bit-reversed destinations
