@@ -1,0 +1,12 @@
+set -u
+O=gpurun_out/r05_n; mkdir -p $O
+(time python -m pytest tests -m gpu -q) > $O/gputests.log 2>&1; tail -3 $O/gputests.log
+tools/profile_pmc.sh $O/pmc "rs256-sd/gates/bits=0.90" > /dev/null 2>&1
+cp $O/pmc/pmc_counters.json profiles/pmc_counters.json && cp profiles/pmc_counters.json $O/pmc_counters.json
+python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 300 $O/bench_default.err; echo
+python bench.py --steps 20 --warmup 5 > $O/bench_driver_args.json 2> $O/bench_driver_args.err
+for f in bench_default bench_driver_args; do python tools/line_value.py $f < $O/$f.json; done
+tools/profile_serial.sh $O/serial > /dev/null 2>&1; tail -1 $O/serial/efficiency.md
+tools/profile_pipelined.sh $O/pipelined > /dev/null 2>&1; head -3 $O/pipelined/kernel_stats.md | cut -c1-150
+python tools/soak.py 8000 16 > $O/soak.txt 2>&1; tail -1 $O/soak.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
