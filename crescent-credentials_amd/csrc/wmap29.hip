@@ -410,7 +410,22 @@ __global__ void __launch_bounds__(256 << (TSL - 10)) k_ntt29_pass(const uint32_t
             lds_put(sm, e11, normalize(x3));
         }
         first_twiddle_of(j + 2, w_first);
+        // (experiment, -DCG_NTT_WAVE_LOCAL; measured in round 5 and NOT the default)  Between two stage pairs whose radix-4 groups
+        // both lie inside the 256 consecutive elements a WAVE owns (64 lanes x one group of four; a group of the pair at bit lb
+        // spans 4 << lb elements, so this holds while the NEXT pair's span is at most 256), the elements a wave reads next are
+        // exactly the ones it has just written: no other wave's data is involved, the wave's own LDS operations complete in
+        // order, and the block-wide barrier - three of the six of a 2048-element first pass - can be a wavefront-scope fence.
+        // Parity-green, the first pass 443 -> 436 us per proof stand-alone, and -0.6 % in the pipeline in four of four
+        // alternating pairs (196.8 -> 195.6, profiles/r05_o_ntt_wave_local_barriers.txt): waves that drift apart inside a
+        // block make its remaining barriers longer.
+#if defined(CG_NTT_WAVE_LOCAL)
+        const int lb_next = lb + 2;
+        const bool wave_local = (j + 3 < pp.S) && ((4u << lb_next) <= 256u) && (tsize >> 2) >= 64u;
+        if (wave_local) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        else __syncthreads();
+#else
         __syncthreads();
+#endif
     }
     if (j < pp.S) {                                     // odd stage count: one radix-2 stage
         const int q = pp.q0 + j;
