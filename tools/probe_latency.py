@@ -20,4 +20,19 @@ for _ in range(4):
 ws, ts = [], []
 for _ in range(10):
     t0 = time.perf_counter(); _, tm = f(True); ws.append((time.perf_counter() - t0) * 1e3); ts.append(tm["total_ms"])
+if shard > 1:
+    # SURVEY 8e's other arrangement, its two pieces alone on the GPU: the one witness map for all shards (cg_witness_map_coset,
+    # device in / device out) and a shard that proves with its slice (cg_prove_partial_q on a context without witness-map memory)
+    q = torch.empty(p.domain_size * 32, dtype=torch.uint8, device="cuda")
+    ext = cc.Prover(pk, cm, shard_rank=1, shard_count=shard, h_scalars_external=True)
+    off, cnt = p.h_scalars_slice(1)
+    for _ in range(3):
+        p.witness_map_coset(wd.data_ptr(), on_device=True, out_dev=q.data_ptr())
+        ext.prove_partial_q(wd.data_ptr(), q.data_ptr() + off * 32, 5, on_device=True, q_on_device=True)
+    tw, tq = [], []
+    for _ in range(10):
+        t0 = time.perf_counter(); p.witness_map_coset(wd.data_ptr(), on_device=True, out_dev=q.data_ptr()); tw.append((time.perf_counter() - t0) * 1e3)
+        t0 = time.perf_counter(); ext.prove_partial_q(wd.data_ptr(), q.data_ptr() + off * 32, 5, on_device=True, q_on_device=True); tq.append((time.perf_counter() - t0) * 1e3)
+    print("shards", shard, "scatter arrangement: witness map for all shards", round(float(np.median(tw)), 3), "ms; a shard with its slice", round(float(np.median(tq)), 3), "ms")
+    ext.close()
 print("shards", shard, "wall ms", round(float(np.median(ws)), 3), "library total_ms", round(float(np.median(ts)), 3), {k: round(v, 3) for k, v in tm.items() if k.endswith("_ms")})
