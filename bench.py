@@ -319,7 +319,7 @@ def main():
     ranks_per_gpu = max(1, math.ceil(int(os.environ.get("LOCAL_WORLD_SIZE", world)) / ndev))
     # (eight plumbing ranks on one GPU get two queues each: 8 x 4 = 32 user queues would be above the ~24 at which the hardware
     # scheduler starts time-slicing)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(16 if ranks_per_gpu == 1 else max(2, 16 // ranks_per_gpu)))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(20 if ranks_per_gpu == 1 else max(2, 16 // ranks_per_gpu)))
     # the RCCL group of the sharded leg must never take the process down: no asynchronous tear-down on a failed or
     # timed-out collective, no heartbeat monitor (the leg has its own deadline and falls back to gloo)
     os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")

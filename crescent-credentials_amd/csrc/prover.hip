@@ -156,17 +156,20 @@ struct ProofSlot {
 struct Upload {
     std::mutex busy;
     DevBuf<Fr> w;
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr;          // one of the context's few copy-only streams (cg_ctx::up_streams: owned there)
     hipEvent_t ev[2] = {nullptr, nullptr};
     hipEvent_t ev_done = nullptr;      // recorded behind the copy and polled (wait_sleeping)
     ~Upload() {
-        if (st) (void)hipStreamDestroy(st);
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         if (ev_done) (void)hipEventDestroy(ev_done);
     }
 };
 
 struct cg_ctx {
+    ~cg_ctx() {
+        uploads.clear();
+        for (hipStream_t us : up_streams) if (us) (void)hipStreamDestroy(us);
+    }
     int device = 0;
     uint64_t l = 0, m = 0, M = 0, D = 0;
     int logD = 0;
@@ -192,6 +195,12 @@ struct cg_ctx {
     bool h_strided = false;
     Wm29Strided wstr;
     std::vector<std::unique_ptr<ProofSlot>> slots;
+    // The upload buffers share a FEW copy-only streams (round 5).  With a stream per buffer a context held proof_slots + 2 of
+    // them next to its proof streams - 34 streams on 16 hardware queues - so an upload's barrier packet (the copy engine's
+    // completion, ~1 ms) sat in a hardware queue in front of some other proof's kernels: the 2 % between the host-memory and
+    // the device-resident rate.  Four streams carry 200 uploads of 1 ms a second with room to spare, and with the proof
+    // streams they fit the hardware queues one each (cg_init asks for 20).
+    std::vector<hipStream_t> up_streams;
     std::vector<std::unique_ptr<Upload>> uploads;
     std::mutex up_mu;
     std::condition_variable up_cv;
@@ -329,10 +338,10 @@ extern "C" const char* cg_version(void) {
 extern "C" int cg_init(int n_devices, const int* device_ids) {
     // The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); kernels of streams that share a
     // queue cannot overlap, and a process with more than ~24 user queues is time-sliced by the hardware scheduler (a
-    // lone proof then meets 15 ms stalls: profiles/r03_a_streams_and_queues.txt).  16 holds twelve one-stream proofs in
-    // flight plus a five-stream latency context without either effect.  Effective only if HIP has not initialised yet in
+    // lone proof then meets 15 ms stalls: profiles/r03_a_streams_and_queues.txt).  20 holds sixteen one-stream proofs in
+    // flight and a context's four copy-only upload streams one queue each (round 5), without either effect.  Effective only if HIP has not initialised yet in
     // this process; a host that initialises HIP earlier should export the variable itself.
-    (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    (void)setenv("GPU_MAX_HW_QUEUES", "20", 0);
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count == 0) return fail(CG_ERR_NO_DEVICE, "no HIP device visible (%s)", hipGetErrorString(e));
@@ -552,10 +561,21 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
             }
             c->slots.push_back(std::move(sl));
         }
+        // Four shared copy-only streams when the runtime's hardware queues hold them beside the proof streams one each
+        // (GPU_MAX_HW_QUEUES is the HIP runtime's own variable; cg_init asks for 20); with fewer queues four shared streams
+        // would only concentrate the blocking (measured -5 % on 16 queues), so every buffer keeps a stream of its own there.
+        const char* hwq_env = getenv("GPU_MAX_HW_QUEUES");
+        const int hwq = hwq_env ? atoi(hwq_env) : 4;
+        const size_t n_copy_streams = hwq >= n_slots + 4 ? 4 : (size_t)n_slots + 2;
         for (int k = 0; k < n_slots + 2; ++k) {
+            if (c->up_streams.size() < n_copy_streams) {
+                hipStream_t us = nullptr;
+                CG_HIP(hipStreamCreateWithFlags(&us, hipStreamNonBlocking));
+                c->up_streams.push_back(us);
+            }
             std::unique_ptr<Upload> u(new Upload());
             u->w.alloc(M);
-            CG_HIP(hipStreamCreateWithFlags(&u->st, hipStreamNonBlocking));
+            u->st = c->up_streams[(size_t)k % c->up_streams.size()];
             for (auto& e : u->ev) CG_HIP(hipEventCreate(&e));
             CG_HIP(hipEventCreateWithFlags(&u->ev_done, hipEventDisableTiming));
             c->uploads.push_back(std::move(u));

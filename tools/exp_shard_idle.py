@@ -1,7 +1,7 @@
 """one 1/2-shard context: wall time of consecutive cg_prove_partial calls after an idle gap (clock ramp?), and with a
 second, idle, 12-slot context alive in the process"""
 import os, sys, time, random
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 import crescent_credentials_amd as cc

@@ -1,6 +1,6 @@
 """wall-clock of one cg_prove_dev call at a time vs the library's own total_ms (host overhead outside the timed region)"""
 import os, sys, time, random
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 import crescent_credentials_amd as cc

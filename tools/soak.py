@@ -5,7 +5,7 @@ proofs take their assignment from page-locked HOST memory (cg_prove: the upload 
 load), even ones from device memory.  Catches rare order-dependence in the grouping / accumulation / upload under load.
 usage: python tools/soak.py [N=4000] [T=16]"""
 import os, random, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from concurrent.futures import ThreadPoolExecutor
 import numpy as np, torch
