@@ -1712,12 +1712,16 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
         }
         if (!ba_done)
 #endif
+        // tuning builds: KNOCK_ACCUM leaves the accumulation AND the combine levels out (the pieces would be stale),
+        // KNOCK_COMBINE the combine levels, KNOCK_TAIL the bucket reduction - wrong sums, the time of the rest
+        static const bool knock_accum = CG_TUNE_ENV("KNOCK_ACCUM") != nullptr, knock_combine = CG_TUNE_ENV("KNOCK_COMBINE") != nullptr;
+        if (!knock_accum)
         launch_accum_affine<F29T>(grouped, plan, max_segments, bases->table.p, bucket_sums.p, mem().part_keys_a.p, mem().part_pts_a.p, latency_mode, st);
         CG_KERNEL_CHECK();
         CG_HIP(hipEventRecord(ev_t[4], st));
         // combine the segments' pieces wave by wave until one wave covers them all (k_combine_wave); the grids cover the
         // largest plan this engine can see, waves beyond the actual one return at once
-        if (max_segments > 1) {
+        if (max_segments > 1 && !knock_accum && !knock_combine) {
             MsmScratch& S = mem();
             uint32_t segs = max_segments;
             for (int level = 0; segs > 1; ++level) {
@@ -1747,6 +1751,8 @@ void MsmEngine<F>::enqueue_reduction(hipStream_t st) {
     const uint32_t C = 1u << red_cbits(bases->c), R = nb / C;
     const size_t lds = (size_t)256 * ACC * 4;
     static const bool force_tree = CG_TUNE_ENV("RED_TREE") != nullptr;      // A/B aid (tuning builds)
+    static const bool knock_tail = CG_TUNE_ENV("KNOCK_TAIL") != nullptr;
+    if (knock_tail) return;             // buckets_clean / counters_clean stay false: the next MSM fills them
     if (latency_mode || force_tree) {   // a block per row / column with an LDS tree: depth log, more additions
         k_bucket_rows_cols<F29T><<<dim3(R + C, wins), 256, lds, st>>>(bucket_sums.p, R, C, rows_buf.p, cols_buf.p);
         CG_KERNEL_CHECK();

@@ -133,6 +133,7 @@ struct ProofSlot {
     MsmEngine<Fq> eh, el, ea, eb1;
     MsmEngine<Fq2> eb2;
     DevBuf<Fr> h_canon;
+    const Fr* knock_h = nullptr;       // tuning builds (KNOCK & 16): the h scalars of this slot's first proof, reused
     Wm29Buffers wm;
     hipStream_t st[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // 0: witness map + h, 1: l, 2: a, 3: b1, 4: b2
     hipEvent_t ev_w = nullptr;
@@ -723,8 +724,25 @@ static int prove_partial_impl(cg_ctx* c, ProofSlot* S, const Fr* w_dev, bool ski
     // b1 and b2 take the same scalars against bases that vanish together: with equal windows the grouped entry list of
     // one IS the other's, so the G2 MSM skips its own grouping (five launches, ~0.9 % of a proof's instructions)
     static const bool no_share = CG_TUNE_ENV("NO_SHARE_B") != nullptr;        // A/B aid (tuning builds)
-    const bool b2_adopts = !skip_b1 && !no_share && c->b_same_identities && S->eb2.can_adopt(S->eb1) && n_a > 0;
-    if (S->one_stream) {
+    // tuning builds: KNOCK is a mask of parts of a proof to leave out (1 l, 2 a, 4 b1, 8 b2, 16 the witness map after a slot's
+    // first proof, 32 h) - the proof is wrong, the time is what the rest costs in the pipeline (profiles/r05_w_knock_outs.md)
+    static const int knock = [] { const char* e = CG_TUNE_ENV("KNOCK"); return e ? atoi(e) : 0; }();
+    if (knock & 4) skip_b1 = true;
+    if (knock && tm) { memset(tm, 0, sizeof(*tm)); tm = nullptr; }       // an engine left out has no events to read
+    const bool b2_adopts = !skip_b1 && !no_share && c->b_same_identities && S->eb2.can_adopt(S->eb1) && n_a > 0 && !(knock & 8);
+    if (knock && S->one_stream) {
+        if (!(knock & 1)) { S->el.digits(w_l, n_l, s0); S->el.accumulate(s0); }
+        if (!(knock & 2)) { S->ea.digits(w_a, n_a, s0); S->ea.accumulate(s0); }
+        if (!skip_b1) S->eb1.digits(w_a, n_a, s0);
+        if (b2_adopts) S->eb2.adopt(S->eb1.grouped(), S->eb1.counters.p, n_a, s0);
+        if (!skip_b1) S->eb1.accumulate(s0);
+        if (!(knock & 8)) { if (!b2_adopts) S->eb2.digits(w_a, n_a, s0); S->eb2.accumulate(s0); }
+        if (tm) CG_HIP(hipEventRecord(S->ev_t[0], s0));
+        const Fr* h_scalars = (knock & 16) && S->knock_h ? S->knock_h : witness_map_or_check(c, S, w_dev, q_dev, s0);
+        S->knock_h = h_scalars;
+        if (tm) CG_HIP(hipEventRecord(S->ev_t[1], s0));
+        if (!(knock & 32)) { S->eh.digits(h_scalars, c->rh.hi - c->rh.lo, s0); S->eh.accumulate(s0); }
+    } else if (S->one_stream) {
         // everything on one stream, every MSM grouped and accumulated before the next one starts: the engines share the
         // slot's scratch (entry lists, segment pieces), which is what a slot's memory mostly is
         S->el.digits(w_l, n_l, s0); S->el.accumulate(s0);
