@@ -1079,7 +1079,11 @@ static void launch_accum_affine(const uint64_t* entries, const uint32_t* plan, u
         else {
 #ifdef CG_TUNING      // CG_FLUSH=0 / 1 / 2: how a flushed record leaves (curve29.hpp store_acc_signed)
             static const int how = [] { const char* e = CG_TUNE_ENV("FLUSH"); return e ? atoi(e) : CG_FLUSH_HOW; }();
-            if (how == 1) k_accum_affine_g1s<1><<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
+            // CG_ACCUM_BLOCK=64 / 128: the kernel has no barrier, so any workgroup size is legal - smaller ones measure -3.5 % in the
+            // pipeline (profiles/r05_ab_accum_workgroup_size.txt: a 256-thread workgroup puts one wave on each SIMD of a CU)
+            static const uint32_t blk = [] { const char* e = CG_TUNE_ENV("ACCUM_BLOCK"); const int v = e ? atoi(e) : 0; return (uint32_t)(v == 64 || v == 128 ? v : 0); }();
+            if (blk) k_accum_affine_g1s<0><<<ceil_div(T_max, blk), blk, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
+            else if (how == 1) k_accum_affine_g1s<1><<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
             else if (how == 2) k_accum_affine_g1s<2><<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
             else k_accum_affine_g1s<0><<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
 #else
