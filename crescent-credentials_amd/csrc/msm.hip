@@ -1065,6 +1065,21 @@ static bool g2_pair_kernel(bool latency_mode) {
 #include "batchaff.hpp"
 #endif
 namespace cg {
+// threads per workgroup of the wave-per-unit kernels around the accumulation (k_combine_wave, k_bucket_chunks,
+// k_bucket_chunk_sums: no barrier, no LDS - any multiple of 64 is legal).  FOUR waves, not one (round 5): a 256-thread
+// workgroup lands one wave on each SIMD of a CU, single-wave workgroups are placed unevenly and their long dependent chains
+// then sit on a quarter of the SIMDs - +1.8 % on the rate in three of three alternating rounds
+// (profiles/r05_ac_tail_workgroups.txt; the same effect the other way round: the accumulation in 64-thread workgroups,
+// -3.5 %).  (Tuning builds: CG_TAIL_BLOCK / CG_TAIL_BLOCK_G2 = 64 | 128 | 256.)
+template <class F29T>
+static uint32_t tail_block() {
+    static const uint32_t v = [] {
+        const char* e = Words29<F29T>::NF == 2 ? CG_TUNE_ENV("TAIL_BLOCK_G2") : CG_TUNE_ENV("TAIL_BLOCK");
+        const int x = e ? atoi(e) : 0;
+        return (uint32_t)(x == 64 || x == 128 || x == 256 ? x : 256);
+    }();
+    return v;
+}
 // T_max: the largest segment count the plan can hold for this engine (lanes beyond the plan's T return at once)
 template <class F29T>
 static void launch_accum_affine(const uint64_t* entries, const uint32_t* plan, uint32_t T_max, const uint32_t* table, uint32_t* bucket_sums,
@@ -1172,14 +1187,15 @@ __device__ __forceinline__ XYZZ29<F29T> shfl_up_acc(const XYZZ29<F29T>& a, unsig
 // L2 write-back + invalidate on a chip whose eight XCDs have an L2 each (profiles/r04_f_fold_ab.txt).  Cross-workgroup
 // hand-offs inside a kernel are not free on MI355X; a kernel boundary does the same flush once.)
 template <class F29T>
-__global__ void __launch_bounds__(64) k_combine_wave(const uint32_t* __restrict__ keys_a, const uint32_t* __restrict__ pts_a,
+__global__ void __launch_bounds__(256) k_combine_wave(const uint32_t* __restrict__ keys_a, const uint32_t* __restrict__ pts_a,
                                                        const uint32_t* __restrict__ plan, uint32_t* bucket_sums,
                                                        uint32_t* keys_b, uint32_t* pts_b, int level) {
     constexpr int ACC = Words29<F29T>::ACC;
     uint32_t T = plan[PLAN_T];
     if (T <= 1) return;                            // nothing to combine: the accumulation wrote the buckets itself
-    const uint32_t lane = threadIdx.x;
-    const uint32_t wv = blockIdx.x;
+    // a wave per 64 segments; a workgroup is 1 or 4 such waves (no barrier, no LDS: tail_block())
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t* in_keys = keys_a;
     const uint32_t* in_pts = pts_a;
     uint32_t out_rec = 0;                          // first record of this level's output region
@@ -1324,15 +1340,15 @@ static constexpr uint32_t RED_CHUNK = 32;
 // else reads it, so the wave then ZEROES the tile (zero_after): the bucket array is left empty for the next MSM and the
 // fill launch that opened every accumulation is gone.
 template <class F29T>
-__global__ void __launch_bounds__(64) k_bucket_chunks(uint32_t* __restrict__ buckets, uint32_t R, uint32_t C,
+__global__ void __launch_bounds__(256) k_bucket_chunks(uint32_t* __restrict__ buckets, uint32_t R, uint32_t C,
                                                       uint32_t* __restrict__ rowp, uint32_t* __restrict__ colp, int zero_after) {
     constexpr int ACC = Words29<F29T>::ACC;
     const uint32_t w = blockIdx.y;
     const uint32_t KC = (C + RED_CHUNK - 1) / RED_CHUNK, KR = (R + RED_CHUNK - 1) / RED_CHUNK;
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // a wave per tile, 1 or 4 waves per workgroup
     if (tile >= KR * KC) return;
     const uint32_t tr = tile / KC, tc = tile - tr * KC;
-    const uint32_t lane = threadIdx.x, i = lane & 31u;
+    const uint32_t lane = threadIdx.x & 63u, i = lane & 31u;
     const bool row_lane = lane < 32u;
     uint32_t* src = buckets + (size_t)w * R * C * ACC;
     const uint32_t r0 = tr * RED_CHUNK, c0 = tc * RED_CHUNK;
@@ -1365,13 +1381,13 @@ __global__ void __launch_bounds__(64) k_bucket_chunks(uint32_t* __restrict__ buc
 }
 // Row_r = Σ_k rowp[r][k] (KC chunks), Col_col = Σ_k colp[k][col] (KR chunks): one lane each
 template <class F29T>
-__global__ void __launch_bounds__(64) k_bucket_chunk_sums(const uint32_t* __restrict__ rowp, const uint32_t* __restrict__ colp, uint32_t R,
+__global__ void __launch_bounds__(256) k_bucket_chunk_sums(const uint32_t* __restrict__ rowp, const uint32_t* __restrict__ colp, uint32_t R,
                                                           uint32_t C, uint32_t* __restrict__ rows, uint32_t* __restrict__ cols) {
     constexpr int ACC = Words29<F29T>::ACC;
     const uint32_t w = blockIdx.y;
     const uint32_t KC = (C + RED_CHUNK - 1) / RED_CHUNK, KR = (R + RED_CHUNK - 1) / RED_CHUNK;
     const uint32_t n_row = (R + 63u) & ~63u;
-    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     XYZZ29<F29T> acc;
     bool inf = true;
     if (t < n_row) {
@@ -1730,7 +1746,7 @@ void MsmEngine<F>::accumulate(hipStream_t st) {
             uint32_t segs = max_segments;
             for (int level = 0; segs > 1; ++level) {
                 const uint32_t waves = ceil_div(segs, 64u);
-                k_combine_wave<F29T><<<waves, 64, 0, st>>>(S.part_keys_a.p, S.part_pts_a.p, plan, bucket_sums.p, S.part_keys_b.p, S.part_pts_b.p, level);
+                k_combine_wave<F29T><<<ceil_div(waves, tail_block<F29T>() / 64u), tail_block<F29T>(), 0, st>>>(S.part_keys_a.p, S.part_pts_a.p, plan, bucket_sums.p, S.part_keys_b.p, S.part_pts_b.p, level);
                 CG_KERNEL_CHECK();
                 segs = waves;
             }
@@ -1763,10 +1779,11 @@ void MsmEngine<F>::enqueue_reduction(hipStream_t st) {
     } else {                     // a lane per chunk of 32 buckets, then a lane per row / column: fewest additions
         const uint32_t KC = ceil_div(C, RED_CHUNK), KR = ceil_div(R, RED_CHUNK);
         const uint32_t lanes_b = ((R + 63u) & ~63u) + C;
-        k_bucket_chunks<F29T><<<dim3(KR * KC, wins), 64, 0, st>>>(bucket_sums.p, R, C, rowp_buf.p, colp_buf.p, zero_at_end ? 1 : 0);
+        const uint32_t tb = tail_block<F29T>();
+        k_bucket_chunks<F29T><<<dim3(ceil_div(KR * KC, tb / 64u), wins), tb, 0, st>>>(bucket_sums.p, R, C, rowp_buf.p, colp_buf.p, zero_at_end ? 1 : 0);
         CG_KERNEL_CHECK();
         buckets_clean = zero_at_end;
-        k_bucket_chunk_sums<F29T><<<dim3(ceil_div(lanes_b, 64), wins), 64, 0, st>>>(rowp_buf.p, colp_buf.p, R, C, rows_buf.p, cols_buf.p);
+        k_bucket_chunk_sums<F29T><<<dim3(ceil_div(lanes_b, tb), wins), tb, 0, st>>>(rowp_buf.p, colp_buf.p, R, C, rows_buf.p, cols_buf.p);
         CG_KERNEL_CHECK();
     }
     const uint32_t nbits = (uint32_t)(red_rbits + red_cbits1);

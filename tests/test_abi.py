@@ -501,7 +501,16 @@ def test_stream_order_audit_of_the_kernel_sources():
             m = re.search(bad, code)
             assert not m, "%s: %s" % (f, code[m.start():m.start() + 60] if m else "")
         for m in re.finditer(r"<<<(.*?)>>>", code, flags=re.S):
-            parts = [p.strip() for p in re.split(r",(?![^()]*\))", m.group(1))]
+            parts, depth, cur = [], 0, ""
+            for ch in m.group(1):            # split the launch configuration at its top-level commas
+                depth += ch == "("
+                depth -= ch == ")"
+                if ch == "," and depth == 0:
+                    parts.append(cur.strip())
+                    cur = ""
+                else:
+                    cur += ch
+            parts.append(cur.strip())
             assert len(parts) == 4 and parts[3] not in ("0", "nullptr", "NULL", "hipStreamDefault"), "%s: launch without a stream: <<<%s>>>" % (f, m.group(1)[:80])
         for m in re.finditer(r"hipStreamCreateWithFlags\s*\(([^;]*?)\)\s*\)?;", code):
             assert "hipStreamNonBlocking" in m.group(1), "%s: blocking stream" % f
