@@ -814,14 +814,14 @@ __global__ void __launch_bounds__(256) CG_ACCUM_ATTR k_accum_affine(const uint64
 #if !defined(CG_FLUSH_HOW)
 #define CG_FLUSH_HOW 0
 #endif
-template <int FLUSH>
-__global__ void __launch_bounds__(256) CG_ACCUM_ATTR k_accum_affine_g1s(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ plan,
+template <int FLUSH, int BLOCK = 256>
+__global__ void __launch_bounds__(BLOCK) CG_ACCUM_ATTR k_accum_affine_g1s(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ plan,
                                                           const uint32_t* __restrict__ table,
                                                           uint32_t* __restrict__ bucket_sums, uint32_t* __restrict__ part_keys,
                                                           uint32_t* __restrict__ part_pts) {
     typedef Fq29 F29T;
     constexpr int ACC = Words29<F29T>::ACC;
-    __shared__ __attribute__((aligned(16))) uint32_t flush_slots[FLUSH == 2 ? 4 * 36 : 4];       // one 144-byte slot per wave
+    __shared__ __attribute__((aligned(16))) uint32_t flush_slots[FLUSH == 2 ? (BLOCK / 64) * 36 : 4];       // one 144-byte slot per wave
     uint32_t* const wave_slot = flush_slots + (FLUSH == 2 ? (threadIdx.x >> 6) * 36 : 0);
     const uint32_t N = plan[PLAN_N], L = plan[PLAN_L], T = plan[PLAN_T];
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1094,10 +1094,13 @@ static void launch_accum_affine(const uint64_t* entries, const uint32_t* plan, u
         else {
 #ifdef CG_TUNING      // CG_FLUSH=0 / 1 / 2: how a flushed record leaves (curve29.hpp store_acc_signed)
             static const int how = [] { const char* e = CG_TUNE_ENV("FLUSH"); return e ? atoi(e) : CG_FLUSH_HOW; }();
-            // CG_ACCUM_BLOCK=64 / 128: the kernel has no barrier, so any workgroup size is legal - smaller ones measure -3.5 % in the
-            // pipeline (profiles/r05_ab_accum_workgroup_size.txt: a 256-thread workgroup puts one wave on each SIMD of a CU)
-            static const uint32_t blk = [] { const char* e = CG_TUNE_ENV("ACCUM_BLOCK"); const int v = e ? atoi(e) : 0; return (uint32_t)(v == 64 || v == 128 ? v : 0); }();
-            if (blk) k_accum_affine_g1s<0><<<ceil_div(T_max, blk), blk, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
+            // CG_ACCUM_BLOCK=64 / 128 / 512 / 1024: the kernel has no barrier, so any workgroup size is legal - smaller ones measure
+            // -3.5 % in the pipeline, 512 -0.6 %, 1024 -2 % (profiles/r05_ab_accum_workgroup_size.txt: a 256-thread workgroup puts one
+            // wave on each SIMD of a CU)
+            static const uint32_t blk = [] { const char* e = CG_TUNE_ENV("ACCUM_BLOCK"); const int v = e ? atoi(e) : 0; return (uint32_t)(v == 64 || v == 128 || v == 512 || v == 1024 ? v : 0); }();
+            if (blk == 512) k_accum_affine_g1s<0, 512><<<ceil_div(T_max, 512u), 512, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
+            else if (blk == 1024) k_accum_affine_g1s<0, 1024><<<ceil_div(T_max, 1024u), 1024, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
+            else if (blk) k_accum_affine_g1s<0><<<ceil_div(T_max, blk), blk, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
             else if (how == 1) k_accum_affine_g1s<1><<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
             else if (how == 2) k_accum_affine_g1s<2><<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
             else k_accum_affine_g1s<0><<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
