@@ -534,3 +534,21 @@ def test_rust_shim_prints_the_reference_phases_under_print_trace():
     hdr_fields = set(_c_struct_fields("cg_timings"))
     for field in re.findall(r"tm\.(\w+)", body[:body.index("impl GpuCircuit")]):
         assert field in hdr_fields, field
+
+
+def test_launch_shapes_found_in_round_5_stay():
+    """Two measured launch-shape findings of round 5, guarded on the sources (profiles/r05_ac_tail_workgroups.txt,
+    r05_u_copy_streams_and_queues.txt): the wave-per-unit kernels around the accumulation go out as FOUR waves per workgroup
+    (one per SIMD of a CU; single-wave workgroups cost 1.8 % of the rate), and a context's upload buffers share four copy-only
+    streams when the runtime's hardware queues hold them beside the proof streams (cg_init asks for twenty)."""
+    csrc = os.path.join(ROOT, "crescent-credentials_amd", "csrc")
+    msm = open(os.path.join(csrc, "msm.hip")).read()
+    m = re.search(r"static uint32_t tail_block\(\) \{.*?\n\}", msm, flags=re.S)
+    assert m and re.search(r"\? x : 256\)", m.group(0)), "tail_block() no longer defaults to 256 threads"
+    for kernel in ("k_combine_wave", "k_bucket_chunks", "k_bucket_chunk_sums"):
+        launches = re.findall(kernel + r"<F29T><<<(.*?)>>>", msm, flags=re.S)
+        assert launches and all("tail_block<F29T>()" in l or ", tb," in l for l in launches), kernel
+        assert re.search(r"__launch_bounds__\(256\) " + kernel + r"\(", msm), kernel
+    prover = open(os.path.join(csrc, "prover.hip")).read()
+    assert 'setenv("GPU_MAX_HW_QUEUES", "20", 0)' in prover
+    assert re.search(r"hwq >= n_slots \+ 4 \? 4 :", prover), "the copy-stream rule changed"
