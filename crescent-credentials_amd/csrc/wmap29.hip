@@ -289,9 +289,14 @@ __device__ __forceinline__ uint32_t l2g29(uint32_t e, uint32_t tile, const Pass2
     uint32_t Thi = T >> lo_bits;
     return colv | (Tlo << pp.cbits) | (g << pp.gbit_lo) | (Thi << (pp.gbit_lo + pp.S));
 }
-// element e of the tile sits at word e*9 + e/16: the odd stride keeps both the linear and the
-// column-major (bit-reversing store) access patterns spread over the LDS banks
-__device__ __forceinline__ uint32_t lds_off(uint32_t e) { return e * 9u + (e >> 4); }
+// element e of the tile sits at word e*9 + e/32.  ds_read2_b32 / ds_write_b32 are serviced a 32-lane half at a time over
+// 32 banks ((address / 4) mod 32): the odd stride spreads 32 consecutive elements over all of them, and the extra word per
+// 32 elements separates the four 32-element runs a half-wave touches when its radix-4 groups are 4 or 16 elements apart.
+// Rounds 1-5 padded a word per SIXTEEN elements - right for a 64-bank picture of the LDS and wrong for this one: lanes l + 9 and
+// 16 + l of every half then met on one bank in EVERY phase, and SQ_LDS_BANK_CONFLICT read half of SQ_LDS_IDX_ACTIVE on all
+// four passes (profiles/r05_am_lds_bank_conflicts.md).  Modelled over the stage pairs of both pass shapes (tools/lds_model.py):
+// 1.0 extra cycle per access before, 0.29-0.33 now (two-way conflicts left at the pairs 2-4 / 1-3 bits up).
+__device__ __forceinline__ uint32_t lds_off(uint32_t e) { return e * 9u + (e >> 5); }
 __device__ __forceinline__ Fr29 lds_get(const uint32_t* s, uint32_t e) {
     Fr29 r;
     const uint32_t o = lds_off(e);
