@@ -25,6 +25,7 @@ FR_MODULUS = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 CG_FORM_CANONICAL, CG_FORM_MONTGOMERY = 0, 1
 CG_FLAG_H_COEFFICIENT_BASIS = 1
 CG_FLAG_LATENCY_MODE, CG_FLAG_THROUGHPUT_MODE, CG_FLAG_SPIN_WAIT, CG_FLAG_CONTIGUOUS_H_SHARDS, CG_FLAG_H_SCALARS_EXTERNAL = 2, 4, 8, 16, 32
+CG_FLAG_STAGED_LOAD = 64
 
 
 class CrescentGpuError(RuntimeError):
@@ -77,8 +78,15 @@ class CgCtxInfo(C.Structure):
                 ("device_free_bytes", C.c_uint64), ("device_total_bytes", C.c_uint64), ("proof_slots", C.c_int32),
                 ("window_bits", C.c_int32 * 5), ("tuned", C.c_int32), ("retune_skipped_for_memory", C.c_int32),
                 ("retune_attempts", C.c_int32), ("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("latency_mode", C.c_int32),
-                ("reserved", C.c_int32 * 4), ("slot_entry_bytes", C.c_uint64), ("slot_piece_bytes", C.c_uint64),
+                ("warmup", C.c_int32), ("reserved", C.c_int32 * 3), ("slot_entry_bytes", C.c_uint64), ("slot_piece_bytes", C.c_uint64),
                 ("slot_bucket_bytes", C.c_uint64), ("slot_transform_bytes", C.c_uint64), ("slot_upload_bytes", C.c_uint64)]
+
+
+class CgLoadTimings(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("total_ms", "matrices_ms", "domain_ms", "key_copy_ms", "fold_ms", "window_tables_ms", "slots_ms",
+                                         "final_slots_ms", "background_ms", "swap_wait_ms", "ready_after_ms")] + \
+               [(n, C.c_int32) for n in ("staged", "ready", "windows_from_proof", "warmup_proofs", "background_status")] + \
+               [("reserved", C.c_int32 * 3)]
 
 
 class _CgProverParamsView(C.Structure):
@@ -123,6 +131,8 @@ _SIGNATURES = {
     "cg_host_register": (C.c_int, [C.c_void_p, C.c_uint64]),
     "cg_host_unregister": (C.c_int, [C.c_void_p]),
     "cg_ctx_get_info": (C.c_int, [C.c_void_p, C.POINTER(CgCtxInfo)]),
+    "cg_ctx_get_load_timings": (C.c_int, [C.c_void_p, C.POINTER(CgLoadTimings)]),
+    "cg_ctx_wait_ready": (C.c_int, [C.c_void_p, C.c_int32]),
     "cg_probe_shader_clock": (C.c_int, [C.c_int32, C.c_uint32, C.POINTER(C.c_double)]),
     "cg_witness_map": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cg_domain_size": (C.c_uint64, [C.c_void_p]),
@@ -347,8 +357,10 @@ class Prover:
     def __init__(self, pk: ProvingKey, matrices: ConstraintMatrices, device: int = -1, window_bits: int = 0,
                  shard_rank: int = 0, shard_count: int = 1, proof_slots: int = 1, h_coefficient_basis: bool = False,
                  mode: Optional[str] = None, spin_wait: bool = False, contiguous_h_shards: bool = False,
-                 h_scalars_external: bool = False, flags: int = 0):
+                 h_scalars_external: bool = False, flags: int = 0, staged_load: bool = False):
         """h_coefficient_basis=True keeps the h query as loaded (seven transforms per proof, CG_FLAG_H_COEFFICIENT_BASIS).
+        staged_load: CG_FLAG_STAGED_LOAD - the call returns as soon as the context can prove (warm-up arrangement) and a worker
+        thread of the library finishes the load behind the first proofs (wait_ready(), load_timings()).
         mode: None (proof_slots decides), "latency" or "throughput" (CG_FLAG_LATENCY_MODE / CG_FLAG_THROUGHPUT_MODE);
         spin_wait: CG_FLAG_SPIN_WAIT; contiguous_h_shards: CG_FLAG_CONTIGUOUS_H_SHARDS; h_scalars_external:
         CG_FLAG_H_SCALARS_EXTERNAL (a shard that never runs the witness map: prove_partial_q only); flags: further raw bits."""
@@ -356,7 +368,8 @@ class Prover:
             raise ValueError("mode must be None, 'latency' or 'throughput'")
         flags |= (CG_FLAG_H_COEFFICIENT_BASIS if h_coefficient_basis else 0) | (CG_FLAG_LATENCY_MODE if mode == "latency" else 0) | \
                  (CG_FLAG_THROUGHPUT_MODE if mode == "throughput" else 0) | (CG_FLAG_SPIN_WAIT if spin_wait else 0) | \
-                 (CG_FLAG_CONTIGUOUS_H_SHARDS if contiguous_h_shards else 0) | (CG_FLAG_H_SCALARS_EXTERNAL if h_scalars_external else 0)
+                 (CG_FLAG_CONTIGUOUS_H_SHARDS if contiguous_h_shards else 0) | (CG_FLAG_H_SCALARS_EXTERNAL if h_scalars_external else 0) | \
+                 (CG_FLAG_STAGED_LOAD if staged_load else 0)
         L = lib()
         self.num_inputs = matrices.num_instance_variables
         self.num_constraints = matrices.num_constraints
@@ -408,6 +421,21 @@ class Prover:
         d = {k: getattr(ci, k) for k, _ in ci._fields_ if k not in ("window_bits", "reserved")}
         d["window_bits"] = dict(zip(("h", "l", "a", "b_g1", "b_g2"), list(ci.window_bits)))
         return d
+
+    def load_timings(self) -> dict:
+        """cg_ctx_get_load_timings: where the time of cg_circuit_load went; for a staged load also the background part"""
+        lt = CgLoadTimings()
+        _check(lib().cg_ctx_get_load_timings(self._h, C.byref(lt)))
+        return {k: (round(getattr(lt, k), 3) if isinstance(getattr(lt, k), float) else getattr(lt, k)) for k, _ in lt._fields_ if k != "reserved"}
+
+    def wait_ready(self, timeout_ms: int = -1) -> bool:
+        """cg_ctx_wait_ready: True once the final arrangement is in force, False when the time ran out first; raises when the
+        background part of a staged load failed"""
+        rc = lib().cg_ctx_wait_ready(self._h, timeout_ms)
+        if rc == 1:
+            return False
+        _check(rc)
+        return True
 
     def prove_host_ptr(self, ptr: int, r: int, s: int, timings: bool = False):
         """cg_prove on a raw host address (num_variables x 32 B canonical): pageable or page-locked (HostBuffer)"""

@@ -138,7 +138,7 @@ def build(verbose: bool = False, jobs: int = int(os.environ.get("CG_BUILD_JOBS",
     if os.path.exists(CALLER_SRC) and (todo or not os.path.exists(CALLER_BIN) or
                                        os.path.getmtime(CALLER_BIN) < max(os.path.getmtime(CALLER_SRC), hdr_t)):
         rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(_hipcc()))), "lib")
-        cmd = ["gcc", "-std=c11", "-D_POSIX_C_SOURCE=200809L", "-O2", "-Wall", "-Wextra", "-Werror", "-pedantic",
+        cmd = ["gcc", "-std=c11", "-D_POSIX_C_SOURCE=200809L", "-O2", "-Wall", "-Wextra", "-Werror", "-pedantic", "-pthread",
                "-I", os.path.join(HERE, "..", "include"), CALLER_SRC, "-o", CALLER_BIN, "-L", HERE, "-lcrescent_gpu",
                "-Wl,-rpath,$ORIGIN/../../crescent-credentials_amd", "-Wl,-rpath-link," + rocm_lib, "-Wl,-rpath," + rocm_lib]
         r = subprocess.run(cmd, capture_output=True, text=True)

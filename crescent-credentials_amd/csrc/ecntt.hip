@@ -194,6 +194,17 @@ __global__ void __launch_bounds__(256) k_ec_fold_l(const uint32_t* __restrict__ 
 void ec_fold_c_into_l(const uint32_t* h_row0, const uint8_t* h_valid, uint64_t n_h, int logn, const Fr& vanishing_inv,
                       const cg_csr& c_matrix, uint64_t num_constraints, uint64_t num_inputs, uint64_t M,
                       const uint32_t* l_row0, const uint8_t* l_valid, uint32_t* row0_out, uint8_t* valid_out, hipStream_t st) {
+    HostCsc t;
+    if (c_matrix.nnz && num_constraints) csr_transpose(c_matrix, num_constraints, M, t);
+    else { t.ptr.assign(M + 1, 0); t.view = cg_csr{t.ptr.data(), nullptr, nullptr, 0}; }
+    ec_fold_ct_into_l(h_row0, h_valid, n_h, logn, vanishing_inv, t, num_constraints, num_inputs, M, l_row0, l_valid, row0_out, valid_out, st);
+}
+
+// the same with the transpose of C already made (a staged load makes it while the caller's arrays are still there and
+// folds later, on its worker thread)
+void ec_fold_ct_into_l(const uint32_t* h_row0, const uint8_t* h_valid, uint64_t n_h, int logn, const Fr& vanishing_inv,
+                       const HostCsc& t, uint64_t num_constraints, uint64_t num_inputs, uint64_t M,
+                       const uint32_t* l_row0, const uint8_t* l_valid, uint32_t* row0_out, uint8_t* valid_out, hipStream_t st) {
     const uint64_t n = 1ull << logn;
     // G'_j = −vinv/n · Σ_i ω^{-ij} H_i : the h query in the Lagrange basis of the domain, times −1/Z(g)
     DevBuf<uint32_t> g_row0(n * AFF1);
@@ -202,10 +213,8 @@ void ec_fold_c_into_l(const uint32_t* h_row0, const uint8_t* h_valid, uint64_t n
     // P_k = Σ_j C_jk · G'_j : the terms of C^T, summed per wire
     DevBuf<uint32_t> p_sums(M * ACC1);
     fill_zero(p_sums.p, p_sums.bytes(), st);
-    const uint64_t nnz = c_matrix.nnz;
+    const uint64_t nnz = t.view.nnz;
     if (nnz && num_constraints) {
-        HostCsc t;
-        csr_transpose(c_matrix, num_constraints, M, t);
         DevCsr ct;
         ct.upload(t.view, M, num_constraints, st, false);
         std::vector<uint32_t> keys_h(nnz);

@@ -21,6 +21,7 @@
 #include "msm.hpp"
 #include "g2pair.hpp"
 
+#include <chrono>
 #include <cstring>
 #include <type_traits>
 
@@ -1927,45 +1928,73 @@ __global__ void __launch_bounds__(256) k_gather_points(const uint32_t* __restric
     out_valid[k] = valid[j];
 }
 
-// h query -> coset evaluation basis, C matrix -> l query (ecntt.hip), then the usual window rows over each slice
-// (h: the points h_first + k·h_stride, k < h_count; l: a contiguous range)
+static float ms_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// h query -> coset evaluation basis (ecntt.hip), then the usual window rows over the slice h_first + k·h_stride, k < h_count
+void build_h_bases_folded(MsmBases<Fq>& out_h, const uint32_t* h_row0, const uint8_t* h_valid, uint64_t n_h, int logn, uint64_t h_first,
+                          uint64_t h_stride, uint64_t h_count, int c_h, hipStream_t st, float* ms_fold, float* ms_tables) {
+    constexpr int AFF = MsmBases<Fq>::AFF;
+    const uint64_t n = 1ull << logn;
+    if (!h_stride || (h_count && h_first + (h_count - 1) * h_stride >= n)) throw HipError(CG_ERR_INVALID_ARGUMENT, "range outside the query");
+    auto t0 = std::chrono::steady_clock::now();
+    DevBuf<uint32_t> row0t(n * AFF);
+    DevBuf<uint8_t> validt(n);
+    ec_transform_h_bases(h_row0, h_valid, n_h, logn, row0t.p, validt.p, st);       // synchronises st
+    if (ms_fold) *ms_fold += ms_since(t0);
+    t0 = std::chrono::steady_clock::now();
+    if (h_stride == 1) {
+        out_h.build_from_row0(row0t.p + h_first * AFF, validt.p + h_first, h_count, c_h, st);
+    } else {
+        DevBuf<uint32_t> row0s(h_count ? h_count * AFF : 4);
+        DevBuf<uint8_t> valids(h_count ? h_count : 1);
+        if (h_count) k_gather_points<<<ceil_div(h_count, 256), 256, 0, st>>>(row0t.p, validt.p, h_first, h_stride, h_count, row0s.p, valids.p);
+        CG_KERNEL_CHECK();
+        out_h.build_from_row0(row0s.p, valids.p, h_count, c_h, st);
+        CG_HIP(hipStreamSynchronize(st));   // the gathered copies are released at the end of this scope
+    }
+    CG_HIP(hipStreamSynchronize(st));
+    if (ms_tables) *ms_tables += ms_since(t0);
+}
+
+// C matrix -> l query (ecntt.hip), then the window rows over [l_first, l_first + l_count) of the M folded bases
+void build_l_bases_folded(MsmBases<Fq>& out_l, const uint32_t* h_row0, const uint8_t* h_valid, uint64_t n_h, int logn,
+                          const uint32_t* l_row0, const uint8_t* l_valid, uint64_t num_inputs, uint64_t M, const HostCsc& c_transposed,
+                          uint64_t num_constraints, const Fr& vanishing_inv, uint64_t l_first, uint64_t l_count,
+                          const std::function<int()>& pick_c_l, hipStream_t st, float* ms_fold, float* ms_tables) {
+    constexpr int AFF = MsmBases<Fq>::AFF;
+    if (l_first + l_count > M) throw HipError(CG_ERR_INVALID_ARGUMENT, "range outside the query");
+    auto t0 = std::chrono::steady_clock::now();
+    DevBuf<uint32_t> row0f(M * AFF);
+    DevBuf<uint8_t> validf(M);
+    ec_fold_ct_into_l(h_row0, h_valid, n_h, logn, vanishing_inv, c_transposed, num_constraints, num_inputs, M, l_row0, l_valid,
+                      row0f.p, validf.p, st);                                                // synchronises st
+    if (ms_fold) *ms_fold += ms_since(t0);
+    t0 = std::chrono::steady_clock::now();
+    out_l.build_from_row0(row0f.p + l_first * AFF, validf.p + l_first, l_count, pick_c_l(), st);
+    CG_HIP(hipStreamSynchronize(st));
+    if (ms_tables) *ms_tables += ms_since(t0);
+}
+
+// both, from the key's affine points (the synchronous load)
 void build_hl_bases_folded(MsmBases<Fq>& out_h, MsmBases<Fq>& out_l, const Affine<Fq>* h_bases_dev, uint64_t n_h, int logn,
                            const Affine<Fq>* l_bases_dev, uint64_t num_inputs, uint64_t M, const cg_csr& c_matrix,
                            uint64_t num_constraints, const Fr& vanishing_inv, uint64_t h_first, uint64_t h_stride, uint64_t h_count, int c_h,
-                           uint64_t l_first, uint64_t l_count, int c_l, hipStream_t st) {
+                           uint64_t l_first, uint64_t l_count, int c_l, hipStream_t st, float* ms_fold, float* ms_tables) {
     constexpr int AFF = MsmBases<Fq>::AFF;
-    const uint64_t n = 1ull << logn, n_l = M - num_inputs;
-    if (!h_stride || (h_count && h_first + (h_count - 1) * h_stride >= n) || l_first + l_count > M)
-        throw HipError(CG_ERR_INVALID_ARGUMENT, "range outside the query");
+    const uint64_t n_l = M - num_inputs;
     DevBuf<uint32_t> h_row0(n_h ? n_h * AFF : 4), l_row0(n_l ? n_l * AFF : 4);
     DevBuf<uint8_t> h_valid(n_h ? n_h : 1), l_valid(n_l ? n_l : 1);
     if (n_h) k_table_first<Fq><<<ceil_div(n_h, 256), 256, 0, st>>>(h_bases_dev, h_row0.p, h_valid.p, n_h);
     if (n_l) k_table_first<Fq><<<ceil_div(n_l, 256), 256, 0, st>>>(l_bases_dev, l_row0.p, l_valid.p, n_l);
     CG_KERNEL_CHECK();
-    {
-        DevBuf<uint32_t> row0t(n * AFF);
-        DevBuf<uint8_t> validt(n);
-        ec_transform_h_bases(h_row0.p, h_valid.p, n_h, logn, row0t.p, validt.p, st);
-        if (h_stride == 1) {
-            out_h.build_from_row0(row0t.p + h_first * AFF, validt.p + h_first, h_count, c_h, st);
-        } else {
-            DevBuf<uint32_t> row0s(h_count ? h_count * AFF : 4);
-            DevBuf<uint8_t> valids(h_count ? h_count : 1);
-            if (h_count) k_gather_points<<<ceil_div(h_count, 256), 256, 0, st>>>(row0t.p, validt.p, h_first, h_stride, h_count, row0s.p, valids.p);
-            CG_KERNEL_CHECK();
-            out_h.build_from_row0(row0s.p, valids.p, h_count, c_h, st);
-            CG_HIP(hipStreamSynchronize(st));   // the gathered copies are released at the end of this scope
-        }
-        CG_HIP(hipStreamSynchronize(st));
-    }
-    {
-        DevBuf<uint32_t> row0f(M * AFF);
-        DevBuf<uint8_t> validf(M);
-        ec_fold_c_into_l(h_row0.p, h_valid.p, n_h, logn, vanishing_inv, c_matrix, num_constraints, num_inputs, M, l_row0.p, l_valid.p,
-                         row0f.p, validf.p, st);
-        out_l.build_from_row0(row0f.p + l_first * AFF, validf.p + l_first, l_count, c_l, st);
-        CG_HIP(hipStreamSynchronize(st));
-    }
+    HostCsc t;
+    if (c_matrix.nnz && num_constraints) csr_transpose(c_matrix, num_constraints, M, t);
+    else { t.ptr.assign(M + 1, 0); t.view = cg_csr{t.ptr.data(), nullptr, nullptr, 0}; }
+    build_h_bases_folded(out_h, h_row0.p, h_valid.p, n_h, logn, h_first, h_stride, h_count, c_h, st, ms_fold, ms_tables);
+    build_l_bases_folded(out_l, h_row0.p, h_valid.p, n_h, logn, l_row0.p, l_valid.p, num_inputs, M, t, num_constraints, vanishing_inv,
+                         l_first, l_count, [c_l] { return c_l; }, st, ms_fold, ms_tables);
 }
 
 template struct MsmBases<Fq>;

@@ -6,6 +6,8 @@
 #include "curve29.hpp"
 #include "ntt.hpp"
 
+#include <functional>
+
 namespace cg {
 
 // Fixed bases of one query, expanded for every window: row j holds 2^(c*j) * P_i.  With all windows
@@ -165,13 +167,28 @@ void ec_transform_h_bases(const uint32_t* row0_in, const uint8_t* valid_in, uint
 void ec_fold_c_into_l(const uint32_t* h_row0, const uint8_t* h_valid, uint64_t n_h, int logn, const Fr& vanishing_inv,
                       const cg_csr& c_matrix, uint64_t num_constraints, uint64_t num_inputs, uint64_t M,
                       const uint32_t* l_row0, const uint8_t* l_valid, uint32_t* row0_out, uint8_t* valid_out, hipStream_t st);
+void ec_fold_ct_into_l(const uint32_t* h_row0, const uint8_t* h_valid, uint64_t n_h, int logn, const Fr& vanishing_inv,
+                       const HostCsc& c_transposed, uint64_t num_constraints, uint64_t num_inputs, uint64_t M,
+                       const uint32_t* l_row0, const uint8_t* l_valid, uint32_t* row0_out, uint8_t* valid_out, hipStream_t st);
 void sum_xyzz_by_key(const uint32_t* keys, const uint32_t* pts, uint64_t count, uint32_t* sums, hipStream_t st);
 // window tables of the transformed h query over the points h_first + k·h_stride, k < h_count, of 2^logn and of the folded
 // l query over [l_first, l_first + l_count) of M
 void build_hl_bases_folded(MsmBases<Fq>& out_h, MsmBases<Fq>& out_l, const Affine<Fq>* h_bases_dev, uint64_t n_h, int logn,
                            const Affine<Fq>* l_bases_dev, uint64_t num_inputs, uint64_t M, const cg_csr& c_matrix,
                            uint64_t num_constraints, const Fr& vanishing_inv, uint64_t h_first, uint64_t h_stride, uint64_t h_count,
-                           int c_h, uint64_t l_first, uint64_t l_count, int c_l, hipStream_t st);
+                           int c_h, uint64_t l_first, uint64_t l_count, int c_l, hipStream_t st, float* ms_fold = nullptr,
+                           float* ms_tables = nullptr);
+
+// The two halves of the above from ROW-0 TABLE POINTS already on the device (a staged load keeps every query as its row 0
+// and folds on a worker thread).  ms_fold / ms_tables (optional) accumulate the host-clock milliseconds spent in the
+// change of basis and in the expansion of the window rows.  pick_c_l is asked for the l query's window AFTER the fold (the
+// caller may have learnt a proof's digit statistics by then).
+void build_h_bases_folded(MsmBases<Fq>& out_h, const uint32_t* h_row0, const uint8_t* h_valid, uint64_t n_h, int logn, uint64_t h_first,
+                          uint64_t h_stride, uint64_t h_count, int c_h, hipStream_t st, float* ms_fold, float* ms_tables);
+void build_l_bases_folded(MsmBases<Fq>& out_l, const uint32_t* h_row0, const uint8_t* h_valid, uint64_t n_h, int logn,
+                          const uint32_t* l_row0, const uint8_t* l_valid, uint64_t num_inputs, uint64_t M, const HostCsc& c_transposed,
+                          uint64_t num_constraints, const Fr& vanishing_inv, uint64_t l_first, uint64_t l_count,
+                          const std::function<int()>& pick_c_l, hipStream_t st, float* ms_fold, float* ms_tables);
 
 // import packed affine points (64 B / 128 B each, `coord_form`) into Montgomery Affine<F> on the device
 template <class F>

@@ -166,6 +166,47 @@ struct Upload {
     }
 };
 
+// The context's reader / writer gate: proofs hold it shared from slot acquisition to their last stream synchronisation; a
+// window re-tune, the swap that ends a staged load and cg_circuit_free hold it exclusively.  WRITER-PREFERRING, unlike
+// std::shared_mutex on glibc: with a dozen callers proving back to back some proof always holds the gate shared, and a
+// writer that only gets in when no reader is there would wait for as long as the host keeps the context busy.  A waiting
+// writer stops new readers; the readers in flight (one proof each, a few tens of ms) drain; the writer runs.
+// (No thread takes it twice: every entry point takes it once, and the re-tune check runs after its proof has let go.)
+class TuneGate {
+    std::mutex mu;
+    std::condition_variable cv;
+    int readers = 0, writers_waiting = 0;
+    bool writer = false;
+public:
+    void lock_shared() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !writer && writers_waiting == 0; });
+        ++readers;
+    }
+    void unlock_shared() {
+        std::lock_guard<std::mutex> lk(mu);
+        if (--readers == 0) cv.notify_all();
+    }
+    void lock() {
+        std::unique_lock<std::mutex> lk(mu);
+        ++writers_waiting;
+        cv.wait(lk, [&] { return !writer && readers == 0; });
+        --writers_waiting;
+        writer = true;
+    }
+    void unlock() {
+        std::lock_guard<std::mutex> lk(mu);
+        writer = false;
+        cv.notify_all();
+    }
+};
+
+// statistics of one finished proof's assignment-driven MSMs (window re-tune; the window choice of a staged load)
+struct TuneStats {
+    bool valid = false;
+    struct Q { uint64_t n_scalars = 0; double nonzero = 0, entries = 0; int W0 = 0; } l, a, b1, b2;
+};
+
 struct cg_ctx {
     ~cg_ctx() {
         uploads.clear();
@@ -228,7 +269,25 @@ struct cg_ctx {
     // a re-tune that failed AFTER a table was rebuilt, while the slots' engines were being re-sized for it: some engines
     // are cut for the old window, the table is the new one.  Every later proof is refused (reload the circuit)
     std::atomic<bool> broken{false};
-    std::shared_mutex tune_mu;   // proofs hold it shared; a retune (and cg_circuit_free) holds it exclusively
+    TuneGate tune_mu;            // proofs hold it shared; a retune, the staged load's swap and cg_circuit_free hold it exclusively
+    // ---- staged load (CG_FLAG_STAGED_LOAD): the context proves in the warm-up arrangement (coefficient basis, row-0
+    // tables, one bucket set per window) while `worker` builds the final one and swaps it in (staged_worker) ----
+    std::atomic<bool> warmup{false};          // the warm-up arrangement is in force
+    std::thread worker;
+    std::atomic<bool> cancel{false};          // cg_circuit_free: the worker stops at its next step
+    int n_slots_final = 1;
+    int window_opt = 0;                       // cg_options.window_bits
+    HostCsc c_transposed;                     // C^T for the fold, made while the caller's arrays were still there
+    std::mutex ready_mu;
+    std::condition_variable ready_cv;
+    bool ready = true;                        // the final arrangement is in force (guarded by ready_mu)
+    int bg_status = 0;
+    std::string bg_error;
+    std::mutex warm_mu;                       // warm_stats
+    TuneStats warm_stats;                     // the first representative warm-up proof's digit statistics
+    std::atomic<int> warmup_proofs{0};
+    cg_load_timings lt{};
+    std::chrono::steady_clock::time_point t_load0;
     // entry points that are still somewhere inside this context (CallGuard): a call lets go of tune_mu before its re-tune
     // check and its host finish, both of which read the context, so cg_circuit_free waits for this count as well
     std::atomic<int> calls_inside{0};
@@ -364,15 +423,206 @@ extern "C" int cg_set_device(int32_t device) {
 
 extern "C" uint64_t cg_domain_size(const cg_ctx* ctx) { return ctx ? ctx->D : 0; }
 
+static float ms_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// one query of the key -> its tables.  precompute = false keeps row 0 only (the warm-up arrangement of a staged load: keys
+// carry the window, one bucket set per window).  ms_copy / ms_tables: host-clock milliseconds of the copy + import and of
+// the table rows.
 template <class F>
-static void load_query(MsmBases<F>& bases, const uint8_t* bytes, uint32_t form, uint64_t first,
-                       uint64_t count, int window_bits, hipStream_t st) {
+static void load_query(MsmBases<F>& bases, const uint8_t* bytes, uint32_t form, uint64_t first, uint64_t count, int window_bits,
+                       bool precompute, hipStream_t st, float* ms_copy, float* ms_tables) {
     constexpr size_t PT = sizeof(Affine<F>);
+    auto t0 = std::chrono::steady_clock::now();
     DevBuf<Affine<F>> tmp(count ? count : 1);
     import_bases<F>(bytes + first * PT, form, count, tmp.p, st);
-    int c = window_bits > 0 ? window_bits : msm_default_window(count ? count : 1, true);
-    bases.build(tmp.p, count, c, true, st);
+    if (ms_copy) *ms_copy += ms_since(t0);
+    t0 = std::chrono::steady_clock::now();
+    int c = window_bits > 0 ? window_bits : msm_default_window(count ? count : 1, precompute);
+    bases.build(tmp.p, count, c, precompute, st);
     CG_HIP(hipStreamSynchronize(st));
+    if (ms_tables) *ms_tables += ms_since(t0);
+}
+
+// One proof slot (working set + streams) over the given tables.  Everything else it is cut for - the domain, the matrices'
+// scratch, the mode - is the context's.
+static std::unique_ptr<ProofSlot> make_slot(cg_ctx* c, const MsmBases<Fq>* bh, const MsmBases<Fq>* bl, const MsmBases<Fq>* ba,
+                                            const MsmBases<Fq>* bb1, const MsmBases<Fq2>* bb2) {
+    CG_HIP(hipSetDevice(c->device));
+    std::unique_ptr<ProofSlot> sl(new ProofSlot());
+    // A throughput context runs every proof on ONE stream: with a dozen proofs in flight the overlap comes from the
+    // other proofs, and twelve streams fit the hardware queues one each, where 60 share them (and anything above
+    // ~24 user queues per process is time-sliced by the hardware scheduler in 15 ms quanta): 192 proofs/s on 16
+    // queues against 188 with five streams per proof on 32 (profiles/r03_a_streams_and_queues.txt).  A latency
+    // context (one proof at a time, or a shard of one) spreads its five MSMs and the witness map over five streams.
+    // (CG_FLAG_THROUGHPUT_MODE with one slot is the profiling arrangement: a kernel trace of one proof at a time on one
+    // stream shows stand-alone durations of the kernels the pipelined run launches.  Tuning builds: CG_SERIAL_STREAMS=1 / 0
+    // decouples the stream count from the mode.)
+    bool serial = !c->latency;
+    if (const char* e = CG_TUNE_ENV("SERIAL_STREAMS")) serial = e[0] == '1';
+    // tuning builds, CG_CHAIN_PRIORITY=1 (experiment): the witness-map -> h-MSM chain, which sets a lone proof's latency,
+    // on a high-priority stream
+    const bool chain_prio = CG_TUNE_ENV("CHAIN_PRIORITY") && CG_TUNE_ENV("CHAIN_PRIORITY")[0] == '1';
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    for (int i = 0; i < 5; ++i) {
+        if (serial && i) sl->st[i] = sl->st[0];
+        else if (chain_prio && i == 0) CG_HIP(hipStreamCreateWithPriority(&sl->st[i], hipStreamNonBlocking, prio_hi));
+        else CG_HIP(hipStreamCreateWithFlags(&sl->st[i], hipStreamNonBlocking));
+    }
+    CG_HIP(hipEventCreateWithFlags(&sl->ev_w, hipEventDisableTiming));
+    CG_HIP(hipEventCreateWithFlags(&sl->ev_b1, hipEventDisableTiming));
+    CG_HIP(hipEventCreateWithFlags(&sl->ev_done, hipEventDisableTiming));
+    sl->one_stream = serial;
+    for (auto& e : sl->ev_t) CG_HIP(hipEventCreate(&e));
+    const bool latency = c->latency;
+    sl->eh.latency_mode = sl->el.latency_mode = sl->ea.latency_mode = sl->eb1.latency_mode = sl->eb2.latency_mode = latency;
+#ifdef CG_WITH_BATCH_AFFINE
+    if (CG_TUNE_ENV("BA_H_ONLY")) sl->el.ba_allowed = sl->ea.ba_allowed = sl->eb1.ba_allowed = false;   // experiment switch
+#endif
+    if (serial) {
+        sl->eh.shared_mem = sl->el.shared_mem = sl->ea.shared_mem = sl->eb1.shared_mem = sl->eb2.shared_mem = &sl->scratch;
+        const bool zero_at_end = !(CG_TUNE_ENV("NO_ZERO_AT_END") && CG_TUNE_ENV("NO_ZERO_AT_END")[0] == '1');     // A/B aid (tuning builds)
+        sl->eh.zero_at_end = sl->el.zero_at_end = sl->ea.zero_at_end = sl->eb1.zero_at_end = sl->eb2.zero_at_end = zero_at_end;
+    }
+    sl->eh.init(bh); sl->el.init(bl); sl->ea.init(ba); sl->eb1.init(bb1); sl->eb2.init(bb2);
+    if (c->external_q) {      // only the landing buffer of a slice that arrives in host memory, and the input flag
+        sl->h_canon.alloc(c->rh.hi - c->rh.lo ? c->rh.hi - c->rh.lo : 1);
+        sl->wm.h_bad_input.alloc(1);
+    } else {
+        sl->h_canon.alloc(c->D);
+        sl->wm.alloc(c->M, c->D, std::max(c->A.sell_scratch, std::max(c->B.sell_scratch, c->C.sell_scratch)));
+    }
+    return sl;
+}
+
+// threads of a loader that are joined on every way out of its scope
+struct JoinAll {
+    std::vector<std::thread> th;
+    ~JoinAll() { for (auto& t : th) if (t.joinable()) t.join(); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// staged load: the worker that builds the final arrangement behind the first proofs
+// ---------------------------------------------------------------------------------------------
+struct WorkerCancelled {};
+static void staged_worker(cg_ctx* c) {
+    const auto t0 = std::chrono::steady_clock::now();
+    int status = 0;
+    std::string err;
+    bool done = false, from_proof = false;
+    float ms_fold = 0.f, ms_tables = 0.f, ms_slots = 0.f, ms_wait = 0.f;
+    try {
+        CG_HIP(hipSetDevice(c->device));
+        // The final arrangement under construction; after the swap these hold the WARM-UP tables and slots, which are
+        // released when this scope ends - outside the gate.
+        MsmBases<Fq> bh, bl, ba, bb1;
+        MsmBases<Fq2> bb2;
+        std::vector<std::unique_ptr<ProofSlot>> slots;
+        int64_t table_bytes = 0;
+        auto stop = [&] { if (c->cancel.load()) throw WorkerCancelled(); };
+        const uint64_t D = c->D, M = c->M, l = c->l;
+        const int wb = c->window_opt;
+        TuneStats ts;
+        bool all_from_proof = true;
+        // the window of an assignment-driven query: from a finished warm-up proof's digit statistics when one is there
+        // (msm_best_window, as the one-time re-tune of a synchronous load chooses it), else by size
+        auto window_for = [&](uint64_t n, int which) {
+            if (wb > 0) return wb;
+            if (!ts.valid) {
+                std::lock_guard<std::mutex> lk(c->warm_mu);
+                ts = c->warm_stats;
+            }
+            // a proof with r = 0 skips b1 (prover.rs:102-112): same scalars and identity pattern as b2
+            const TuneStats::Q& q = which == 0 ? ts.l : which == 1 ? ts.a : (which == 2 && ts.b1.n_scalars) ? ts.b1 : ts.b2;
+            if (!ts.valid) all_from_proof = false;
+            if (ts.valid && q.n_scalars && q.W0 > 0) {
+                double nz = q.nonzero, nz_full = q.W0 > 1 ? (q.entries - nz) / (double)(q.W0 - 1) : 0.0;
+                if (nz_full < 0) nz_full = 0;
+                if (nz_full > nz) nz_full = nz;
+                return msm_best_window(n ? n : 1, nz - nz_full, nz_full);
+            }
+            return msm_default_window(n ? n : 1, true);
+        };
+        {
+            AllocScope booking(&table_bytes);
+            ScopedStream st;
+            // The h query first.  Its scalars are the quotient's values - uniform whatever the witness - so its window is the
+            // size-based one; and its change of basis is the longest step: by the time it is done the first warm-up proof
+            // has normally finished and the other four windows can be chosen from it.
+            build_h_bases_folded(bh, c->bh.table.p, c->bh.valid.p, D - 1, c->logD, 0, 1, D, wb > 0 ? wb : msm_default_window(D, true), st,
+                                 &ms_fold, &ms_tables);
+            stop();
+            build_l_bases_folded(bl, c->bh.table.p, c->bh.valid.p, D - 1, c->logD, c->bl.table.p, c->bl.valid.p, l, M, c->c_transposed, c->m,
+                                 c->dom.vanishing_inv, 0, M,
+                                 [&] { return window_for(M, 0); }, st, &ms_fold, &ms_tables);
+            stop();
+            const auto tt = std::chrono::steady_clock::now();
+            ba.build_from_row0(c->ba.table.p, c->ba.valid.p, c->ba.n, window_for(c->ba.n, 1), st);
+            CG_HIP(hipStreamSynchronize(st));
+            stop();
+            bb1.build_from_row0(c->bb1.table.p, c->bb1.valid.p, c->bb1.n, window_for(c->bb1.n, 2), st);
+            CG_HIP(hipStreamSynchronize(st));
+            stop();
+            bb2.build_from_row0(c->bb2.table.p, c->bb2.valid.p, c->bb2.n, window_for(c->bb2.n, 3), st);
+            CG_HIP(hipStreamSynchronize(st));
+            ms_tables += ms_since(tt);
+            from_proof = wb == 0 && ts.valid && all_from_proof;
+        }
+        stop();
+        {
+            const auto tt = std::chrono::steady_clock::now();
+            for (int k = 0; k < c->n_slots_final; ++k) {
+                slots.push_back(make_slot(c, &bh, &bl, &ba, &bb1, &bb2));
+                stop();
+            }
+            ms_slots = ms_since(tt);
+        }
+        {
+            const auto tw = std::chrono::steady_clock::now();
+            std::unique_lock<TuneGate> lk(c->tune_mu);       // the proofs in flight drain; new ones wait for the swap
+            ms_wait = ms_since(tw);
+            std::swap(c->bh, bh); std::swap(c->bl, bl); std::swap(c->ba, ba); std::swap(c->bb1, bb1); std::swap(c->bb2, bb2);
+            c->slots.swap(slots);
+            for (auto& sl : c->slots) {       // the engines were cut for the tables where they were built
+                sl->eh.bases = &c->bh; sl->el.bases = &c->bl; sl->ea.bases = &c->ba; sl->eb1.bases = &c->bb1; sl->eb2.bases = &c->bb2;
+            }
+            c->folded = true;
+            c->rh = {0, D};
+            c->rl = {0, M};
+            c->table_bytes = table_bytes;
+            c->tuned = from_proof;             // windows already chosen from a proof: no re-tune follows
+            account_slot(c);
+            c->warmup = false;
+            {
+                std::lock_guard<std::mutex> pl(c->pick_mu);
+                c->pick_cv.notify_all();
+            }
+        }
+        std::vector<uint64_t>().swap(c->c_transposed.ptr);
+        std::vector<uint32_t>().swap(c->c_transposed.row);
+        std::vector<uint8_t>().swap(c->c_transposed.coeff);
+        done = true;
+        // (the warm-up slots and row-0 tables go here, with this scope: hipFree waits for the device, not for the gate)
+    } catch (const WorkerCancelled&) {
+        status = 0;
+    } catch (...) {
+        status = cg::translate_current_exception();
+        err = last_error();
+        (void)hipGetLastError();
+    }
+    {
+        std::lock_guard<std::mutex> lk(c->ready_mu);
+        c->lt.fold_ms = ms_fold; c->lt.window_tables_ms += ms_tables; c->lt.final_slots_ms = ms_slots; c->lt.swap_wait_ms = ms_wait;
+        c->lt.background_ms = ms_since(t0);
+        c->lt.ready_after_ms = ms_since(c->t_load0);
+        c->lt.windows_from_proof = from_proof ? 1 : 0;
+        c->ready = done;
+        c->bg_status = status;
+        c->bg_error = err;
+    }
+    c->ready_cv.notify_all();
 }
 
 extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_csr abc[3], uint64_t num_inputs,
@@ -398,7 +648,7 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
     if (wb < 0 || wb == 1 || wb > 22) return fail(CG_ERR_INVALID_ARGUMENT, "window_bits must be 0 (automatic) or in [2, 22]");
     if (opt && opt->proof_slots < 0) return fail(CG_ERR_INVALID_ARGUMENT, "proof_slots must not be negative");
     constexpr int32_t KNOWN_FLAGS = CG_FLAG_H_COEFFICIENT_BASIS | CG_FLAG_LATENCY_MODE | CG_FLAG_THROUGHPUT_MODE | CG_FLAG_SPIN_WAIT |
-                                    CG_FLAG_CONTIGUOUS_H_SHARDS | CG_FLAG_H_SCALARS_EXTERNAL;
+                                    CG_FLAG_CONTIGUOUS_H_SHARDS | CG_FLAG_H_SCALARS_EXTERNAL | CG_FLAG_STAGED_LOAD;
     if (opt && (opt->flags & ~KNOWN_FLAGS)) return fail(CG_ERR_INVALID_ARGUMENT, "unknown bits in flags");
     if (opt && (opt->flags & CG_FLAG_H_SCALARS_EXTERNAL) && ((opt->flags & CG_FLAG_H_COEFFICIENT_BASIS) || shard_count <= 1))
         return fail(CG_ERR_INVALID_ARGUMENT, "flags: CG_FLAG_H_SCALARS_EXTERNAL needs a sharded context over the folded key");
@@ -414,98 +664,154 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
     for (int k = 0; k < 3; ++k)
         if (const char* why = csr_view_problem(abc[k])) return fail(CG_ERR_INVALID_ARGUMENT, "matrix %d: %s", k, why);
     try {
+        const auto T0 = std::chrono::steady_clock::now();
         int dev = (opt && opt->device >= 0) ? opt->device : -1;
         if (dev < 0) CG_HIP(hipGetDevice(&dev));
         CG_HIP(hipSetDevice(dev));
         std::unique_ptr<cg_ctx> c(new cg_ctx());
+        c->t_load0 = T0;
         c->device = dev;
         c->l = l; c->m = m; c->M = M; c->D = D; c->logD = logD;
         c->shard_count = shard_count;
         c->shard_rank = shard_rank;
         c->fixed_window = wb > 0;
+        c->window_opt = wb;
         int n_slots = (opt && opt->proof_slots > 0) ? opt->proof_slots : 1;
         if (n_slots > 16) n_slots = 16;
-        // the loader's stream: every load-time copy and kernel runs on it; destroyed on every way out of this function - a
-        // load that runs out of device memory half-way gives back its stream with everything else (the context's buffers
-        // are RAII members of `c`, the temporaries are scoped DevBufs)
+        c->n_slots_final = n_slots;
+        c->folded = !(opt && (opt->flags & CG_FLAG_H_COEFFICIENT_BASIS));
+        c->external_q = opt && (opt->flags & CG_FLAG_H_SCALARS_EXTERNAL);
+        // a staged load proves in the reference's arrangement first (see CG_FLAG_STAGED_LOAD); sharded contexts and contexts
+        // that keep that arrangement for good load synchronously
+        const bool staged = opt && (opt->flags & CG_FLAG_STAGED_LOAD) && c->folded && shard_count == 1;
+        // the loader's stream: every load-time copy and kernel of THIS thread runs on it; destroyed on every way out of this
+        // function - a load that runs out of device memory half-way gives back its stream with everything else (the
+        // context's buffers are RAII members of `c`, the temporaries are scoped DevBufs)
         ScopedStream s0_guard;
         const hipStream_t s0 = s0_guard;
         const uint32_t form = pk->coord_form;
-        c->alpha_g1 = g1_import(pk->alpha_g1, form);
-        c->beta_g1 = g1_import(pk->beta_g1, form);
-        c->delta_g1 = g1_import(pk->delta_g1, form);
-        c->beta_g2 = g2_import(pk->beta_g2, form);
-        c->delta_g2 = g2_import(pk->delta_g2, form);
-        c->a0 = g1_import(pk->a_query, form);            // query[0] of calculate_coeff (prover.rs:265)
-        c->b1_0 = g1_import(pk->b_g1_query, form);
-        c->b2_0 = g2_import(pk->b_g2_query, form);
-        c->fb_delta_g1.build(c->delta_g1);
-        c->fb_delta_g2.build(c->delta_g2);
-        c->folded = !(opt && (opt->flags & CG_FLAG_H_COEFFICIENT_BASIS));
-        c->external_q = opt && (opt->flags & CG_FLAG_H_SCALARS_EXTERNAL);
+        // ---- the three matrices on host threads of their own (validation, coefficient dictionary, sliced layout: host
+        // work, 17 M terms at the rs256 size), next to the key on this thread.  Every thread books what it leaves resident.
+        struct MatJob { std::exception_ptr err; int64_t bytes = 0; float ms = 0.f; } mj[4];
+        DevCsr* mats[3] = {&c->A, &c->B, &c->C};
+        cg_ctx* cp = c.get();
         {
-            const int logs = ilog2_ceil((uint64_t)c->shard_count);
-            c->h_strided = c->folded && c->shard_count > 1 && (1 << logs) == c->shard_count && logD - logs >= 4 &&
-                           !(opt && (opt->flags & CG_FLAG_CONTIGUOUS_H_SHARDS));
-        }
-        c->rh = shard_range(c->folded ? D : D - 1, c->shard_rank, c->shard_count);
-        if (c->h_strided) c->rh = {0, D / (uint64_t)c->shard_count};     // positions in the shard's own list of points
-        c->rl = shard_range(c->folded ? M : M - l, c->shard_rank, c->shard_count);
-        c->ra = shard_range(M - 1, c->shard_rank, c->shard_count);
-        // what stays resident is booked per kind as it is allocated (cg_ctx_get_info)
-        std::unique_ptr<AllocScope> booking;
-        auto book = [&](int64_t* counter) { booking.reset(); if (counter) booking.reset(new AllocScope(counter)); };
-        book(&c->matrix_bytes);
-        // validates the CSR views (monotone row_ptr, column range, canonical coefficients); a context that never runs the
-        // witness map skips the sliced layout
-        c->A.upload(abc[0], m, M, s0, !c->external_q);
-        c->B.upload(abc[1], m, M, s0, !c->external_q);
-        c->C.upload(abc[2], m, M, s0, !c->external_q);
-        c->dom.build(logD, true, s0);
-        CG_HIP(hipStreamSynchronize(s0));
-        book(&c->table_bytes);
-        if (c->folded) {
-            // every shard transforms the whole queries (the DFT mixes all points) and keeps its own ranges of the results
-            DevBuf<G1Affine> th(D), tl(M - l ? M - l : 1);
-            import_bases<Fq>(pk->h_query, form, D - 1, th.p, s0);
-            import_bases<Fq>(pk->l_query, form, M - l, tl.p, s0);
-            const uint64_t nh = c->rh.hi - c->rh.lo, nl = c->rl.hi - c->rl.lo;
-            build_hl_bases_folded(c->bh, c->bl, th.p, D - 1, logD, tl.p, l, M, abc[2], m, c->dom.vanishing_inv,
-                                  c->h_strided ? (uint64_t)c->shard_rank : c->rh.lo, c->h_strided ? (uint64_t)c->shard_count : 1, nh,
-                                  wb > 0 ? wb : msm_default_window(nh ? nh : 1, true), c->rl.lo, nl,
-                                  wb > 0 ? wb : msm_default_window(nl ? nl : 1, true), s0);
-        } else {
-            load_query<Fq>(c->bh, pk->h_query, form, c->rh.lo, c->rh.hi - c->rh.lo, wb, s0);
-            load_query<Fq>(c->bl, pk->l_query, form, c->rl.lo, c->rl.hi - c->rl.lo, wb, s0);
-        }
-        load_query<Fq>(c->ba, pk->a_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, s0);    // query[1..] (prover.rs:266)
-        load_query<Fq>(c->bb1, pk->b_g1_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, s0);
-        load_query<Fq2>(c->bb2, pk->b_g2_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, s0);
-        {   // the G2 MSM may take over b1's grouped entries only if the two queries vanish together (generator.rs:162,168
-            // makes them b_i(τ)·G1 and b_i(τ)·G2; a key from elsewhere is not trusted to)
-            const uint64_t nb = c->bb1.n;
-            c->b_same_identities = nb == c->bb2.n;
-            if (c->b_same_identities && nb) {
-                std::vector<uint8_t> v1(nb), v2(nb);
-                CG_HIP(hipMemcpyAsync(v1.data(), c->bb1.valid.p, nb, hipMemcpyDeviceToHost, s0));
-                CG_HIP(hipMemcpyAsync(v2.data(), c->bb2.valid.p, nb, hipMemcpyDeviceToHost, s0));
-                CG_HIP(hipStreamSynchronize(s0));
-                c->b_same_identities = v1 == v2;
+            JoinAll jobs;
+            for (int k = 0; k < 3; ++k)
+                jobs.th.emplace_back([&, k] {
+                    try {
+                        const auto t = std::chrono::steady_clock::now();
+                        CG_HIP(hipSetDevice(dev));
+                        AllocScope booking(&mj[k].bytes);
+                        ScopedStream st;
+                        // validates the CSR view (monotone row_ptr, column range, canonical coefficients); a context that
+                        // never runs the witness map skips the sliced layout
+                        mats[k]->upload(abc[k], m, M, st, !cp->external_q);
+                        mj[k].ms = ms_since(t);
+                    } catch (...) {
+                        mj[k].err = std::current_exception();
+                    }
+                });
+            if (staged)      // C^T for the fold, made now: the worker must not read the caller's arrays after this call returns
+                jobs.th.emplace_back([&] {
+                    try {
+                        if (abc[2].nnz && m) csr_transpose(abc[2], m, M, cp->c_transposed);
+                        else { cp->c_transposed.ptr.assign(M + 1, 0); cp->c_transposed.view = cg_csr{cp->c_transposed.ptr.data(), nullptr, nullptr, 0}; }
+                    } catch (...) {
+                        mj[3].err = std::current_exception();
+                    }
+                });
+            // ---- this thread: the single points, the domain, the five queries
+            c->alpha_g1 = g1_import(pk->alpha_g1, form);
+            c->beta_g1 = g1_import(pk->beta_g1, form);
+            c->delta_g1 = g1_import(pk->delta_g1, form);
+            c->beta_g2 = g2_import(pk->beta_g2, form);
+            c->delta_g2 = g2_import(pk->delta_g2, form);
+            c->a0 = g1_import(pk->a_query, form);            // query[0] of calculate_coeff (prover.rs:265)
+            c->b1_0 = g1_import(pk->b_g1_query, form);
+            c->b2_0 = g2_import(pk->b_g2_query, form);
+            c->fb_delta_g1.build(c->delta_g1);
+            c->fb_delta_g2.build(c->delta_g2);
+            {
+                const int logs = ilog2_ceil((uint64_t)c->shard_count);
+                c->h_strided = c->folded && c->shard_count > 1 && (1 << logs) == c->shard_count && logD - logs >= 4 &&
+                               !(opt && (opt->flags & CG_FLAG_CONTIGUOUS_H_SHARDS));
             }
+            const bool folded_now = c->folded && !staged;     // the arrangement this call leaves in force
+            c->rh = shard_range(folded_now ? D : D - 1, c->shard_rank, c->shard_count);
+            if (c->h_strided) c->rh = {0, D / (uint64_t)c->shard_count};     // positions in the shard's own list of points
+            c->rl = shard_range(folded_now ? M : M - l, c->shard_rank, c->shard_count);
+            c->ra = shard_range(M - 1, c->shard_rank, c->shard_count);
+            {
+                const auto t = std::chrono::steady_clock::now();
+                AllocScope booking(&c->matrix_bytes);
+                c->dom.build(logD, true, s0);
+                CG_HIP(hipStreamSynchronize(s0));
+                c->lt.domain_ms = ms_since(t);
+            }
+            AllocScope booking(&c->table_bytes);
+            if (staged) {
+                // every query as its row-0 table: what the warm-up arrangement proves on and what the worker expands
+                load_query<Fq>(c->bh, pk->h_query, form, 0, D - 1, 0, false, s0, &c->lt.key_copy_ms, &c->lt.key_copy_ms);
+                load_query<Fq>(c->bl, pk->l_query, form, 0, M - l, 0, false, s0, &c->lt.key_copy_ms, &c->lt.key_copy_ms);
+                load_query<Fq>(c->ba, pk->a_query, form, 1, M - 1, 0, false, s0, &c->lt.key_copy_ms, &c->lt.key_copy_ms);
+                load_query<Fq>(c->bb1, pk->b_g1_query, form, 1, M - 1, 0, false, s0, &c->lt.key_copy_ms, &c->lt.key_copy_ms);
+                load_query<Fq2>(c->bb2, pk->b_g2_query, form, 1, M - 1, 0, false, s0, &c->lt.key_copy_ms, &c->lt.key_copy_ms);
+            } else {
+                if (c->folded) {
+                    // every shard transforms the whole queries (the DFT mixes all points) and keeps its own ranges of the results
+                    const auto t = std::chrono::steady_clock::now();
+                    DevBuf<G1Affine> th(D), tl(M - l ? M - l : 1);
+                    import_bases<Fq>(pk->h_query, form, D - 1, th.p, s0);
+                    import_bases<Fq>(pk->l_query, form, M - l, tl.p, s0);
+                    c->lt.key_copy_ms += ms_since(t);
+                    const uint64_t nh = c->rh.hi - c->rh.lo, nl = c->rl.hi - c->rl.lo;
+                    build_hl_bases_folded(c->bh, c->bl, th.p, D - 1, logD, tl.p, l, M, abc[2], m, c->dom.vanishing_inv,
+                                          c->h_strided ? (uint64_t)c->shard_rank : c->rh.lo, c->h_strided ? (uint64_t)c->shard_count : 1, nh,
+                                          wb > 0 ? wb : msm_default_window(nh ? nh : 1, true), c->rl.lo, nl,
+                                          wb > 0 ? wb : msm_default_window(nl ? nl : 1, true), s0, &c->lt.fold_ms, &c->lt.window_tables_ms);
+                } else {
+                    load_query<Fq>(c->bh, pk->h_query, form, c->rh.lo, c->rh.hi - c->rh.lo, wb, true, s0, &c->lt.key_copy_ms, &c->lt.window_tables_ms);
+                    load_query<Fq>(c->bl, pk->l_query, form, c->rl.lo, c->rl.hi - c->rl.lo, wb, true, s0, &c->lt.key_copy_ms, &c->lt.window_tables_ms);
+                }
+                load_query<Fq>(c->ba, pk->a_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, true, s0, &c->lt.key_copy_ms, &c->lt.window_tables_ms);    // query[1..] (prover.rs:266)
+                load_query<Fq>(c->bb1, pk->b_g1_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, true, s0, &c->lt.key_copy_ms, &c->lt.window_tables_ms);
+                load_query<Fq2>(c->bb2, pk->b_g2_query, form, 1 + c->ra.lo, c->ra.hi - c->ra.lo, wb, true, s0, &c->lt.key_copy_ms, &c->lt.window_tables_ms);
+            }
+            {   // the G2 MSM may take over b1's grouped entries only if the two queries vanish together (generator.rs:162,168
+                // makes them b_i(τ)·G1 and b_i(τ)·G2; a key from elsewhere is not trusted to)
+                const uint64_t nb = c->bb1.n;
+                c->b_same_identities = nb == c->bb2.n;
+                if (c->b_same_identities && nb) {
+                    std::vector<uint8_t> v1(nb), v2(nb);
+                    CG_HIP(hipMemcpyAsync(v1.data(), c->bb1.valid.p, nb, hipMemcpyDeviceToHost, s0));
+                    CG_HIP(hipMemcpyAsync(v2.data(), c->bb2.valid.p, nb, hipMemcpyDeviceToHost, s0));
+                    CG_HIP(hipStreamSynchronize(s0));
+                    c->b_same_identities = v1 == v2;
+                }
+            }
+        }   // the matrix threads are joined here
+        for (const MatJob& j : mj)
+            if (j.err) std::rethrow_exception(j.err);
+        for (int k = 0; k < 3; ++k) {
+            c->matrix_bytes += mj[k].bytes;
+            c->lt.matrices_ms = std::max(c->lt.matrices_ms, mj[k].ms);
         }
-        book(&c->matrix_bytes);
-        if (!c->external_q) {
-            c->wdom.build(c->dom, s0);
-            if (c->h_strided) c->wstr.build(c->dom, ilog2_ceil((uint64_t)c->shard_count), c->shard_rank, s0);
-            c->dA.build(c->A, s0); c->dB.build(c->B, s0); c->dC.build(c->C, s0);
+        {
+            AllocScope booking(&c->matrix_bytes);
+            if (!c->external_q) {
+                c->wdom.build(c->dom, s0);
+                if (c->h_strided) c->wstr.build(c->dom, ilog2_ceil((uint64_t)c->shard_count), c->shard_rank, s0);
+                c->dA.build(c->A, s0); c->dB.build(c->B, s0); c->dC.build(c->C, s0);
+            }
+            CG_HIP(hipStreamSynchronize(s0));
+            if (c->external_q) {      // the matrices were uploaded for their validation and for the load-time fold only
+                c->A = DevCsr(); c->B = DevCsr(); c->C = DevCsr();
+            }
+            // the saturated-form tables were only the source of the packed ones
+            c->dom.tw_fwd.release(); c->dom.tw_inv.release(); c->dom.coset_br.release(); c->dom.icoset_br.release();
+            c->A.dict.release(); c->B.dict.release(); c->C.dict.release();
         }
-        CG_HIP(hipStreamSynchronize(s0));
-        if (c->external_q) {      // the matrices were uploaded for their validation and for the load-time fold only
-            c->A = DevCsr(); c->B = DevCsr(); c->C = DevCsr();
-        }
-        // the saturated-form tables were only the source of the packed ones
-        c->dom.tw_fwd.release(); c->dom.tw_inv.release(); c->dom.coset_br.release(); c->dom.icoset_br.release();
-        c->A.dict.release(); c->B.dict.release(); c->C.dict.release();
         // a context that proves one proof at a time (whole, or its shard of one) is a latency job; several proofs in
         // flight - whole proofs, or this rank's shards of several proofs (distributed.ShardedProver, proofs_in_flight) -
         // are a throughput job
@@ -514,54 +820,13 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         if (opt && (opt->flags & CG_FLAG_THROUGHPUT_MODE)) c->latency = false;
         c->spin_wait = opt && (opt->flags & CG_FLAG_SPIN_WAIT);
         if (const char* e = CG_TUNE_ENV("LATENCY_MODE")) c->latency = e[0] == '1';    // tuning builds: force either segment length
-        book(nullptr);                                    // slots are accounted by kind from their buffers (account_slot)
-        for (int k = 0; k < n_slots; ++k) {
-            std::unique_ptr<ProofSlot> sl(new ProofSlot());
-            // A throughput context runs every proof on ONE stream: with a dozen proofs in flight the overlap comes from the
-            // other proofs, and twelve streams fit the hardware queues one each, where 60 share them (and anything above
-            // ~24 user queues per process is time-sliced by the hardware scheduler in 15 ms quanta): 192 proofs/s on 16
-            // queues against 188 with five streams per proof on 32 (profiles/r03_a_streams_and_queues.txt).  A latency
-            // context (one proof at a time, or a shard of one) spreads its five MSMs and the witness map over five streams.
-            // (CG_FLAG_THROUGHPUT_MODE with one slot is the profiling arrangement: a kernel trace of one proof at a time on one
-            // stream shows stand-alone durations of the kernels the pipelined run launches.  Tuning builds: CG_SERIAL_STREAMS=1 / 0
-            // decouples the stream count from the mode.)
-            bool serial = !c->latency;
-            if (const char* e = CG_TUNE_ENV("SERIAL_STREAMS")) serial = e[0] == '1';
-            // tuning builds, CG_CHAIN_PRIORITY=1 (experiment): the witness-map -> h-MSM chain, which sets a lone proof's latency,
-            // on a high-priority stream
-            const bool chain_prio = CG_TUNE_ENV("CHAIN_PRIORITY") && CG_TUNE_ENV("CHAIN_PRIORITY")[0] == '1';
-            int prio_lo = 0, prio_hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-            for (int i = 0; i < 5; ++i) {
-                if (serial && i) sl->st[i] = sl->st[0];
-                else if (chain_prio && i == 0) CG_HIP(hipStreamCreateWithPriority(&sl->st[i], hipStreamNonBlocking, prio_hi));
-                else CG_HIP(hipStreamCreateWithFlags(&sl->st[i], hipStreamNonBlocking));
-            }
-            CG_HIP(hipEventCreateWithFlags(&sl->ev_w, hipEventDisableTiming));
-            CG_HIP(hipEventCreateWithFlags(&sl->ev_b1, hipEventDisableTiming));
-            CG_HIP(hipEventCreateWithFlags(&sl->ev_done, hipEventDisableTiming));
-            sl->one_stream = serial;
-            for (auto& e : sl->ev_t) CG_HIP(hipEventCreate(&e));
-            const bool latency = c->latency;
-            sl->eh.latency_mode = sl->el.latency_mode = sl->ea.latency_mode = sl->eb1.latency_mode = sl->eb2.latency_mode = latency;
-#ifdef CG_WITH_BATCH_AFFINE
-            if (CG_TUNE_ENV("BA_H_ONLY")) sl->el.ba_allowed = sl->ea.ba_allowed = sl->eb1.ba_allowed = false;   // experiment switch
-#endif
-            if (serial) {
-                sl->eh.shared_mem = sl->el.shared_mem = sl->ea.shared_mem = sl->eb1.shared_mem = sl->eb2.shared_mem = &sl->scratch;
-                const bool zero_at_end = !(CG_TUNE_ENV("NO_ZERO_AT_END") && CG_TUNE_ENV("NO_ZERO_AT_END")[0] == '1');     // A/B aid (tuning builds)
-                sl->eh.zero_at_end = sl->el.zero_at_end = sl->ea.zero_at_end = sl->eb1.zero_at_end = sl->eb2.zero_at_end = zero_at_end;
-            }
-            sl->eh.init(&c->bh); sl->el.init(&c->bl); sl->ea.init(&c->ba); sl->eb1.init(&c->bb1); sl->eb2.init(&c->bb2);
-            if (c->external_q) {      // only the landing buffer of a slice that arrives in host memory, and the input flag
-                sl->h_canon.alloc(c->rh.hi - c->rh.lo ? c->rh.hi - c->rh.lo : 1);
-                sl->wm.h_bad_input.alloc(1);
-            } else {
-                sl->h_canon.alloc(D);
-                sl->wm.alloc(M, D, std::max(c->A.sell_scratch, std::max(c->B.sell_scratch, c->C.sell_scratch)));
-            }
-            c->slots.push_back(std::move(sl));
-        }
+        const auto t_slots = std::chrono::steady_clock::now();
+        // (slots are accounted by kind from their buffers: account_slot.)  A staged load starts with a few warm-up slots -
+        // callers beyond them wait their turn, as with any context whose slots are all busy - and the worker makes the
+        // final ones.
+        const int n_now = staged ? std::min(n_slots, 4) : n_slots;
+        if (staged) c->folded = false;                    // the arrangement in force until the swap
+        for (int k = 0; k < n_now; ++k) c->slots.push_back(make_slot(c.get(), &c->bh, &c->bl, &c->ba, &c->bb1, &c->bb2));
         // Four shared copy-only streams when the runtime's hardware queues hold them beside the proof streams one each
         // (GPU_MAX_HW_QUEUES is the HIP runtime's own variable; cg_init asks for 20); with fewer queues four shared streams
         // would only concentrate the blocking (measured -5 % on 16 queues), so every buffer keeps a stream of its own there.
@@ -581,7 +846,15 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
             CG_HIP(hipEventCreateWithFlags(&u->ev_done, hipEventDisableTiming));
             c->uploads.push_back(std::move(u));
         }
+        c->lt.slots_ms = ms_since(t_slots);
         account_slot(c.get());
+        c->lt.staged = staged ? 1 : 0;
+        c->lt.total_ms = ms_since(T0);
+        if (staged) {
+            c->ready = false;
+            c->warmup = true;
+            c->worker = std::thread(staged_worker, c.get());
+        }
         *out = c.release();
         return CG_OK;
     } catch (...) {
@@ -589,11 +862,35 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
     }
 }
 
+extern "C" int cg_ctx_get_load_timings(cg_ctx* ctx, cg_load_timings* out) {
+    if (!ctx || !out) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lk(ctx->ready_mu);
+    *out = ctx->lt;
+    out->ready = ctx->ready ? 1 : 0;
+    out->warmup_proofs = ctx->warmup_proofs.load();
+    out->background_status = ctx->bg_status;
+    return CG_OK;
+}
+
+extern "C" int cg_ctx_wait_ready(cg_ctx* ctx, int32_t timeout_ms) {
+    if (!ctx) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
+    std::unique_lock<std::mutex> lk(ctx->ready_mu);
+    auto settled = [&] { return ctx->ready || ctx->bg_status != 0; };
+    if (timeout_ms < 0) ctx->ready_cv.wait(lk, settled);
+    else if (!ctx->ready_cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), settled)) return 1;
+    if (ctx->bg_status != 0) return fail(ctx->bg_status, "the background part of the staged load failed (the context keeps proving in the warm-up arrangement): %s", ctx->bg_error.c_str());
+    return CG_OK;
+}
+
 extern "C" void cg_circuit_free(cg_ctx* ctx) {
     if (!ctx) return;
+    // a staged load's worker stops at its next step (between two table builds at the latest) and is waited for: it works on
+    // the context's row-0 tables
+    ctx->cancel = true;
+    if (ctx->worker.joinable()) ctx->worker.join();
     {   // proofs hold tune_mu shared from slot acquisition to their last stream synchronisation: taking it exclusively
         // waits for the GPU part of every cg_prove* still inside this context ...
-        std::unique_lock<std::shared_mutex> drain(ctx->tune_mu);
+        std::unique_lock<TuneGate> drain(ctx->tune_mu);
     }
     // ... and the count of calls inside covers their tails, which run without the lock (the re-tune check takes it
     // exclusively itself; the host finish reads the context's fixed points).  A caller must not START a call after this
@@ -889,14 +1186,10 @@ static void partials_to_bytes(const Partials& P, uint8_t out[384]) {
 // stream of unrepresentative assignments never drains the pipeline, and after RETUNE_MAX_ATTEMPTS looks the context keeps
 // its size-based windows for good.
 static constexpr int RETUNE_MAX_ATTEMPTS = 8;
-struct TuneStats {
-    bool valid = false;
-    struct Q { uint64_t n_scalars = 0; double nonzero = 0, entries = 0; } l, a, b1, b2;
-};
 template <class F>
 static TuneStats::Q tune_stats_of(const MsmEngine<F>& e) {
     TuneStats::Q q;
-    q.n_scalars = e.n_scalars; q.nonzero = e.n_nonzero(); q.entries = e.n_entries();
+    q.n_scalars = e.n_scalars; q.nonzero = e.n_nonzero(); q.entries = e.n_entries(); q.W0 = e.bases->W;
     return q;
 }
 static void snapshot_tune_stats(const cg_ctx* c, const ProofSlot* S, bool skip_b1, TuneStats& ts) {
@@ -926,7 +1219,7 @@ static int rebuild_booked(cg_ctx* c, MsmBases<F>& bases, int window, hipStream_t
 template <class F>
 static void retune_query(cg_ctx* c, MsmBases<F>& bases, MsmEngine<F> ProofSlot::*eng, const TuneStats::Q& q, hipStream_t st) {
     if (!q.n_scalars || !bases.n) return;
-    const int W0 = bases.W;
+    const int W0 = q.W0 > 0 ? q.W0 : bases.W;      // the window count of the tables the statistics were taken on
     double nz = q.nonzero, N = q.entries;
     double nz_full = W0 > 1 ? (N - nz) / (double)(W0 - 1) : 0.0;
     if (nz_full < 0) nz_full = 0;
@@ -938,13 +1231,23 @@ static void retune_query(cg_ctx* c, MsmBases<F>& bases, MsmEngine<F> ProofSlot::
     if (rc > 0) reinit_engines(c, eng, bases);
 }
 static void maybe_retune(cg_ctx* c, const TuneStats& ts) {
+    if (c->warmup.load()) {
+        // a staged load's warm-up arrangement: nothing to re-tune (its tables are row 0 only).  The first representative
+        // proof's statistics go to the worker, which chooses the FINAL windows from them before it expands those tables.
+        c->warmup_proofs++;
+        if (ts.valid && ts.a.nonzero * 64 >= (double)ts.a.n_scalars) {
+            std::lock_guard<std::mutex> lk(c->warm_mu);
+            if (!c->warm_stats.valid) c->warm_stats = ts;
+        }
+        return;
+    }
     if (!ts.valid || c->fixed_window || c->tuned) return;
     if (!ts.l.n_scalars && !ts.a.n_scalars) return;
     // A degenerate assignment (all zero, or next to it) says nothing about the proofs to come: its statistics would pick
     // the narrowest window and the widest tables for good.  Keep the size-based windows and wait for a representative
     // proof - a bounded number of times.
     if (ts.a.nonzero * 64 < (double)ts.a.n_scalars) { c->retune_attempts++; return; }
-    std::unique_lock<std::shared_mutex> lk(c->tune_mu);     // waits for the proofs in flight to drain
+    std::unique_lock<TuneGate> lk(c->tune_mu);     // waits for the proofs in flight to drain
     if (c->tuned) return;
     c->retune_attempts++;
     try {
@@ -991,7 +1294,7 @@ static int prove_common(cg_ctx* ctx, const void* assignment, bool on_device, con
         const std::function<void()> overlap = [&]() { pre = delta_multiples(ctx, r, s); };
         int e;
         {
-            std::shared_lock<std::shared_mutex> tl(ctx->tune_mu);
+            std::shared_lock<TuneGate> tl(ctx->tune_mu);
             // a caller that passed the check above can have waited here for another thread's re-tune, and that re-tune can
             // have failed half-way: the engines of the slots are then cut for the old window against the rebuilt table
             if (ctx->broken) return fail(CG_ERR_OUT_OF_MEMORY, "%s", BROKEN_CONTEXT);
@@ -1046,7 +1349,7 @@ static int prove_partial_common(cg_ctx* ctx, const void* full_assignment, int as
         TuneStats ts;
         int e;
         {
-            std::shared_lock<std::shared_mutex> tl(ctx->tune_mu);
+            std::shared_lock<TuneGate> tl(ctx->tune_mu);
             if (ctx->broken) return fail(CG_ERR_OUT_OF_MEMORY, "%s", BROKEN_CONTEXT);     // as in prove_common
             UploadGuard up;
             float upload_ms = 0.f;
@@ -1113,7 +1416,7 @@ extern "C" int cg_witness_map_coset(cg_ctx* ctx, const void* full_assignment, in
     CallGuard inside(ctx);
     try {
         CG_HIP(hipSetDevice(ctx->device));
-        std::shared_lock<std::shared_mutex> tl(ctx->tune_mu);
+        std::shared_lock<TuneGate> tl(ctx->tune_mu);
         if (ctx->broken) return fail(CG_ERR_OUT_OF_MEMORY, "%s", BROKEN_CONTEXT);
         UploadGuard up;
         const Fr* w_dev = (const Fr*)full_assignment;
@@ -1173,7 +1476,7 @@ extern "C" int cg_witness_map(cg_ctx* ctx, const uint8_t* full_assignment, uint8
     CallGuard inside(ctx);
     try {
         CG_HIP(hipSetDevice(ctx->device));
-        std::shared_lock<std::shared_mutex> tl(ctx->tune_mu);
+        std::shared_lock<TuneGate> tl(ctx->tune_mu);
         if (ctx->broken) return fail(CG_ERR_OUT_OF_MEMORY, "%s", BROKEN_CONTEXT);
         UploadGuard up;
         up.take(ctx);
@@ -1224,7 +1527,7 @@ extern "C" int cg_ctx_get_info(cg_ctx* ctx, cg_ctx_info* out) {
     if (!ctx || !out) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
     try {
         memset(out, 0, sizeof(*out));
-        std::shared_lock<std::shared_mutex> tl(ctx->tune_mu);     // not in the middle of a re-tune
+        std::shared_lock<TuneGate> tl(ctx->tune_mu);     // not in the middle of a re-tune
         out->table_bytes = (uint64_t)ctx->table_bytes;
         out->matrix_bytes = (uint64_t)ctx->matrix_bytes;
         out->slot_bytes = (uint64_t)ctx->slot_bytes;
@@ -1243,6 +1546,7 @@ extern "C" int cg_ctx_get_info(cg_ctx* ctx, cg_ctx_info* out) {
         out->shard_rank = ctx->shard_rank;
         out->shard_count = ctx->shard_count;
         out->latency_mode = ctx->latency ? 1 : 0;
+        out->warmup = ctx->warmup.load() ? 1 : 0;
         out->slot_entry_bytes = ctx->slot_part[0]; out->slot_piece_bytes = ctx->slot_part[1]; out->slot_bucket_bytes = ctx->slot_part[2];
         out->slot_transform_bytes = ctx->slot_part[3]; out->slot_upload_bytes = ctx->slot_part[4];
         return CG_OK;

@@ -11,6 +11,7 @@
 #include <memory>
 
 #include "common.hpp"
+#include "host_parallel.hpp"
 
 namespace cg {
 int translate_current_exception();
@@ -19,7 +20,7 @@ using namespace cg;
 
 struct cg_pk {
     std::vector<uint8_t> alpha_g1, beta_g2, gamma_g2, delta_g1, delta_g2, gamma_abc_g1, beta_g1, delta_g1_pk;
-    std::vector<uint8_t> a_query, b_g1_query, b_g2_query, h_query, l_query;
+    RawArray<uint8_t> a_query, b_g1_query, b_g2_query, h_query, l_query;    // 0.6 GB at the rs256 size: filled by worker threads
 };
 struct cg_prover_params {
     cg_pk pk;
@@ -82,31 +83,59 @@ struct Rd {
         dst.reserve(dst.size() + n * sz);
         for (uint64_t i = 0; i < n; ++i) point(dst, sz);
     }
+    // a query of the key: the same as points(), on all host threads (a straight copy, then the flag byte of every point)
+    void query(RawArray<uint8_t>& dst, uint64_t sz) {
+        const uint64_t n = u64();
+        if (n > (len - off) / sz) throw HipError(CG_ERR_PARSE, "vector length exceeds the remaining data");
+        dst.alloc(n * sz);
+        const uint8_t* src = p + off;
+        uint8_t* out = dst.p;
+        parallel_ranges(n, 1u << 14, [&](uint64_t lo, uint64_t hi) {
+            memcpy(out + lo * sz, src + lo * sz, (hi - lo) * sz);
+            for (uint64_t i = lo; i < hi; ++i) {
+                uint8_t* last = out + i * sz + sz - 1;
+                const uint8_t flags = *last & 0xC0;
+                *last &= 0x3F;
+                if (flags & 0x40) memset(out + i * sz, 0, sz);
+            }
+        });
+        off += n * sz;
+    }
 };
 
-bool gt(const Fq& a, const Fq& b) {   // canonical integers
+// y > -y for a canonical y, i.e. y > q - y, i.e. y > (q - 1) / 2 (q is odd; y = 0 is its own negative and not "greater"):
+// one comparison with a constant instead of a modular negation per point (a key has 8 M of them)
+bool gt_half_q(const uint8_t* y32) {
+    static const Fq HALF = [] {
+        Fq h;
+        uint32_t carry = 0;
+        for (int i = 7; i >= 0; --i) {          // (q - 1) >> 1; q - 1 only clears bit 0
+            const uint32_t w = i == 0 ? FqP::N[0] - 1u : FqP::N[i];
+            h.l[i] = (w >> 1) | (carry << 31);
+            carry = w & 1u;
+        }
+        return h;
+    }();
+    const Fq y = fp_from_bytes<Fq>(y32);
     for (int i = 7; i >= 0; --i) {
-        if (a.l[i] > b.l[i]) return true;
-        if (a.l[i] < b.l[i]) return false;
+        if (y.l[i] > HALF.l[i]) return true;
+        if (y.l[i] < HALF.l[i]) return false;
     }
     return false;
 }
+bool all_zero(const uint8_t* p, int n) {
+    for (int i = 0; i < n; ++i) if (p[i]) return false;
+    return true;
+}
 // y of a packed canonical point -> SWFlags
 uint8_t g1_flags(const uint8_t* pt) {
-    bool zero = true;
-    for (int i = 0; i < 64; ++i) if (pt[i]) { zero = false; break; }
-    if (zero) return 0x40;
-    Fq y = fp_from_bytes<Fq>(pt + 32);
-    Fq ny = from_mont(neg(to_mont(y)));
-    return gt(y, ny) ? 0x80 : 0x00;
+    if (all_zero(pt, 64)) return 0x40;
+    return gt_half_q(pt + 32) ? 0x80 : 0x00;
 }
 uint8_t g2_flags(const uint8_t* pt) {
-    bool zero = true;
-    for (int i = 0; i < 128; ++i) if (pt[i]) { zero = false; break; }
-    if (zero) return 0x40;
-    Fq y0 = fp_from_bytes<Fq>(pt + 64), y1 = fp_from_bytes<Fq>(pt + 96);
-    Fq n0 = from_mont(neg(to_mont(y0))), n1 = from_mont(neg(to_mont(y1)));
-    bool g = gt(y1, n1) || (y1 == n1 && gt(y0, n0));   // QuadExtField order: c1 first, then c0 [ark-mem]
+    if (all_zero(pt, 128)) return 0x40;
+    // QuadExtField order: c1 first, then c0 [ark-mem]; c1 and -c1 differ unless c1 = 0
+    const bool g = all_zero(pt + 96, 32) ? gt_half_q(pt + 64) : gt_half_q(pt + 96);
     return g ? 0x80 : 0x00;
 }
 struct Wr {
@@ -121,8 +150,25 @@ struct Wr {
     void raw(const uint8_t* b, uint64_t n) { need(n); if (n) memcpy(p + off, b, n); off += n; }
     void bytes(const uint8_t* b, uint64_t n) { u64(n); raw(b, n); }
     void byte(uint8_t v) { need(1); p[off++] = v; }
-    void g1s(const uint8_t* pts, uint64_t n) { u64(n); for (uint64_t i = 0; i < n; ++i) g1(pts + 64 * i); }
-    void g2s(const uint8_t* pts, uint64_t n) { u64(n); for (uint64_t i = 0; i < n; ++i) g2(pts + 128 * i); }
+    // a query: the points are copied and flagged on all host threads
+    void g1s(const uint8_t* pts, uint64_t n) {
+        u64(n); need(64 * n);
+        uint8_t* dst = p + off;
+        parallel_ranges(n, 1u << 14, [&](uint64_t lo, uint64_t hi) {
+            memcpy(dst + 64 * lo, pts + 64 * lo, 64 * (hi - lo));
+            for (uint64_t i = lo; i < hi; ++i) dst[64 * i + 63] |= g1_flags(pts + 64 * i);
+        });
+        off += 64 * n;
+    }
+    void g2s(const uint8_t* pts, uint64_t n) {
+        u64(n); need(128 * n);
+        uint8_t* dst = p + off;
+        parallel_ranges(n, 1u << 13, [&](uint64_t lo, uint64_t hi) {
+            memcpy(dst + 128 * lo, pts + 128 * lo, 128 * (hi - lo));
+            for (uint64_t i = lo; i < hi; ++i) dst[128 * i + 127] |= g2_flags(pts + 128 * i);
+        });
+        off += 128 * n;
+    }
 };
 
 }  // namespace
@@ -138,11 +184,11 @@ static void read_pk(Rd& r, cg_pk* k) {
     // ProvingKey (data_structures.rs:101-118)
     r.point(k->beta_g1, 64);
     r.point(k->delta_g1_pk, 64);
-    r.points(k->a_query, 64);
-    r.points(k->b_g1_query, 64);
-    r.points(k->b_g2_query, 128);
-    r.points(k->h_query, 64);
-    r.points(k->l_query, 64);
+    r.query(k->a_query, 64);
+    r.query(k->b_g1_query, 64);
+    r.query(k->b_g2_query, 128);
+    r.query(k->h_query, 64);
+    r.query(k->l_query, 64);
 }
 static void pk_view(const cg_pk* k, cg_proving_key* view) {
     view->coord_form = CG_FORM_CANONICAL;

@@ -124,7 +124,20 @@ enum {
      * shard never runs the witness map - its h scalars arrive with every proof (cg_prove_partial_q), computed once for all
      * shards by cg_witness_map_coset on a context loaded WITHOUT this flag.  The context then holds no witness-map vectors
      * and no matrices; cg_prove_partial / cg_witness_map on it are CG_ERR_INVALID_ARGUMENT. */
-    CG_FLAG_H_SCALARS_EXTERNAL = 32
+    CG_FLAG_H_SCALARS_EXTERNAL = 32,
+    /* Staged load: cg_circuit_load returns as soon as the context can PROVE, and finishes loading behind the first proofs.
+     * The reference's caller reads its two files and proves once (`create_client_state`, creds/src/lib.rs:255-301; the sample
+     * client does so per credential, sample/client_helper/src/main.rs:177-216), so what it waits for is load + ONE proof, and
+     * two thirds of a synchronous load are spent on tables that only pay off over many proofs (the change of basis of the
+     * h query, ~1.5 s at 2^21, and the per-window tables, ~0.6 s).  With this flag the load copies the key and the matrices,
+     * keeps every query as its row-0 table and returns; proofs then run in the WARM-UP arrangement - the reference's own
+     * (seven transforms, plain h query, r1cs_to_qap.rs:179-210) over classic Pippenger with one bucket set per window - while
+     * a worker thread of the library builds the final arrangement (folded key, per-window tables, windows chosen from the
+     * first finished proof's digit statistics when there is one) and swaps it in between two proofs.  Proof bytes are the
+     * same in both arrangements (they are the same group elements).  cg_ctx_wait_ready blocks until the swap; a host that
+     * never calls it loses nothing but the first seconds' throughput.  Honoured for unsharded contexts over the folded key;
+     * sharded contexts and CG_FLAG_H_COEFFICIENT_BASIS load synchronously as before. */
+    CG_FLAG_STAGED_LOAD = 64
 };
 
 /* Per-phase wall/GPU times of one cg_prove call, mirroring the reference's `print-trace` phases
@@ -230,7 +243,8 @@ typedef struct cg_ctx_info {
     int32_t shard_rank;
     int32_t shard_count;
     int32_t latency_mode;        /* 1: short accumulation segments + tree reductions (one proof at a time); 0: throughput */
-    int32_t reserved[4];
+    int32_t warmup;              /* 1: a staged load (CG_FLAG_STAGED_LOAD) whose final arrangement is not in force yet */
+    int32_t reserved[3];
     /* slot_bytes by kind (they add up to it).  In a throughput context the five MSMs of a proof run one after another and
      * share one set of entry lists and segment pieces, sized for the largest of them; a latency context (proof_slots = 1)
      * runs them concurrently and holds a set per MSM. */
@@ -241,6 +255,36 @@ typedef struct cg_ctx_info {
     uint64_t slot_upload_bytes;    /* one device copy of an assignment arriving from the host (the context holds proof_slots + 2) */
 } cg_ctx_info;
 int cg_ctx_get_info(cg_ctx* ctx, cg_ctx_info* out);
+
+/* Where the time of cg_circuit_load went, by the reference's own timer names where it has them ("Reading ProverParams",
+ * "Reading R1CS", creds/src/lib.rs:257,266 - there the cost is deserialisation; here it is the copy into HBM and the tables).
+ * Milliseconds on the host clock.  With CG_FLAG_STAGED_LOAD, fold_ms / window_tables_ms / final_slots_ms belong to the
+ * background part and are 0 until it is done (ready = 1). */
+typedef struct cg_load_timings {
+    float total_ms;           /* cg_circuit_load, call to return */
+    float matrices_ms;        /* the three matrices: validation, coefficient dictionary, sliced layout, copy (host threads) */
+    float domain_ms;          /* twiddle and coset tables of the evaluation domain */
+    float key_copy_ms;        /* the five queries: host -> device copy, Montgomery import, row-0 table points */
+    float fold_ms;            /* h query -> coset evaluation basis, C matrix folded into the l query (two DFTs over G1) */
+    float window_tables_ms;   /* rows 1.. of the per-window tables of the five queries */
+    float slots_ms;           /* proof slots and upload buffers (the warm-up slots of a staged load) */
+    float final_slots_ms;     /* staged load: the proof slots of the final arrangement */
+    float background_ms;      /* staged load: the worker's whole run, return of cg_circuit_load -> swap done */
+    float swap_wait_ms;       /* staged load: how long the swap waited for the proofs in flight to drain */
+    float ready_after_ms;     /* staged load: call of cg_circuit_load -> final arrangement in force */
+    int32_t staged;           /* 1: the load was staged */
+    int32_t ready;            /* 1: the final arrangement is in force (always 1 for a synchronous load) */
+    int32_t windows_from_proof; /* staged load: 1 = the final windows were chosen from a warm-up proof's digit statistics (no re-tune follows) */
+    int32_t warmup_proofs;    /* proofs finished in the warm-up arrangement */
+    int32_t background_status; /* 0, or the cg_status the worker failed with (the context keeps proving in the warm-up arrangement) */
+    int32_t reserved[3];
+} cg_load_timings;
+int cg_ctx_get_load_timings(cg_ctx* ctx, cg_load_timings* out);
+
+/* Staged load: wait until the final arrangement is in force.  timeout_ms < 0 waits without limit.
+ * Returns CG_OK when it is (at once for a synchronous load), 1 when the time ran out first, or the negative cg_status the
+ * background part failed with (cg_last_error says why; the context keeps working in the warm-up arrangement). */
+int cg_ctx_wait_ready(cg_ctx* ctx, int32_t timeout_ms);
 
 /* Multi-GPU: a context loaded with shard_count > 1 owns a contiguous range of the l, a and b
  * queries and, of the h query, a contiguous range or — for a power-of-two shard_count — the coset points

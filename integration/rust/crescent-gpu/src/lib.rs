@@ -131,7 +131,29 @@ unsafe impl Sync for GpuCircuit {}
 impl GpuCircuit {
     /// One-time: pack the key and the matrices and copy them to the GPU (`cg_circuit_load`).
     /// `proof_slots` = proofs that may be in flight on this circuit at once (one per calling thread).
+    /// The load is STAGED (`CG_FLAG_STAGED_LOAD`): it returns as soon as the circuit can prove and the library finishes its
+    /// tables behind the first proofs - what `create_client_state` (creds/src/lib.rs:255-301), which loads and proves once,
+    /// wants.  A host that is about to stream proofs may call `wait_ready` first.
     pub fn load(pk: &ProvingKey<Bn254>, m: &ConstraintMatrices<Fr>, device: i32, proof_slots: i32) -> Result<Self, SynthesisError> {
+        Self::load_with_flags(pk, m, device, proof_slots, sys::CG_FLAG_STAGED_LOAD)
+    }
+
+    /// `load` with the context's flags spelt out (`sys::CG_FLAG_*`; 0 = the synchronous load).
+    pub fn load_with_flags(pk: &ProvingKey<Bn254>, m: &ConstraintMatrices<Fr>, device: i32, proof_slots: i32, flags: i32)
+                           -> Result<Self, SynthesisError> {
+        Self::load_opt(pk, m, sys::cg_options { device, proof_slots, flags, ..Default::default() })
+    }
+
+    /// One shard of a proof split over `shard_count` GPUs (`cg_options.shard_rank / shard_count`): the context
+    /// owns its ranges of the five queries and answers `prove_partial` (or, loaded with `CG_FLAG_H_SCALARS_EXTERNAL`,
+    /// `prove_partial_q` only).  `assemble` on any shard finishes the gathered partial sums into the proof.
+    pub fn load_shard(pk: &ProvingKey<Bn254>, m: &ConstraintMatrices<Fr>, device: i32, proof_slots: i32, shard_rank: i32,
+                      shard_count: i32, flags: i32) -> Result<Self, SynthesisError> {
+        Self::load_opt(pk, m, sys::cg_options { device, proof_slots, shard_rank, shard_count, flags, ..Default::default() })
+    }
+
+    fn load_opt(pk: &ProvingKey<Bn254>, m: &ConstraintMatrices<Fr>, opt: sys::cg_options) -> Result<Self, SynthesisError> {
+        let proof_slots = opt.proof_slots;
         let rc = unsafe { sys::cg_init(0, std::ptr::null()) };
         if rc != 0 {
             return Err(map_err(rc));
@@ -160,7 +182,6 @@ impl GpuCircuit {
         };
         let (ca, cb, cc) = (to_csr(&m.a), to_csr(&m.b), to_csr(&m.c));
         let abc = [ca.view(), cb.view(), cc.view()];
-        let opt = sys::cg_options { device, proof_slots, ..Default::default() };
         let num_variables = m.num_instance_variables + m.num_witness_variables;
         let mut ctx: *mut sys::cg_ctx = std::ptr::null_mut();
         let rc = unsafe {
@@ -236,7 +257,98 @@ fn print_trace(tm: &sys::cg_timings) {
     line(0, "Groth16::Prover", tm.total_ms);                                               // :48
 }
 
+fn canonical_bytes(xs: &[Fr]) -> Vec<u8> {
+    let mut out = vec![0u8; xs.len() * 32];
+    for (i, x) in xs.iter().enumerate() {
+        out[i * 32..i * 32 + 32].copy_from_slice(&x.into_bigint().to_bytes_le());
+    }
+    out
+}
+
+/// One proof over several GPUs, on contexts made by `GpuCircuit::load_shard`.  The 384-byte partial records
+/// are what the host gathers (one per shard); nothing else crosses between the shards.
 impl GpuCircuit {
+    /// This shard's five partial sums h ‖ l ‖ a ‖ b1 ‖ b2 (`cg_prove_partial`; prover.rs:66,74,266 over the shard's ranges).
+    pub fn prove_partial(&self, r: Fr, full_assignment: &[Fr]) -> Result<[u8; 384], SynthesisError> {
+        if full_assignment.len() != self.num_variables {
+            return Err(SynthesisError::AssignmentMissing);
+        }
+        let (w, rb) = (canonical_bytes(full_assignment), r.into_bigint().to_bytes_le());
+        let mut out = [0u8; 384];
+        let rc = unsafe { sys::cg_prove_partial(self.ctx, w.as_ptr() as *const _, 0, rb.as_ptr(), out.as_mut_ptr(), std::ptr::null_mut()) };
+        if rc != 0 { Err(map_err(rc)) } else { Ok(out) }
+    }
+
+    /// The gathered partial sums of all shards -> the proof (`cg_assemble`; prover.rs:76-135).
+    pub fn assemble(&self, partials: &[[u8; 384]], r: Fr, s: Fr) -> Result<Proof<Bn254>, SynthesisError> {
+        let flat: Vec<u8> = partials.iter().flat_map(|p| p.iter().copied()).collect();
+        let (rb, sb) = (r.into_bigint().to_bytes_le(), s.into_bigint().to_bytes_le());
+        let mut out = [0u8; 256];
+        let rc = unsafe { sys::cg_assemble(self.ctx, flat.as_ptr(), partials.len() as u32, rb.as_ptr(), sb.as_ptr(), out.as_mut_ptr()) };
+        if rc != 0 {
+            return Err(map_err(rc));
+        }
+        Proof::deserialize_uncompressed_unchecked(&out[..]).map_err(|_| SynthesisError::MalformedVerifyingKey)
+    }
+
+    /// SURVEY 8e's other arrangement, step 1 (`cg_witness_map_coset`): the witness map ONCE, on a context loaded without
+    /// `CG_FLAG_H_SCALARS_EXTERNAL`; all `domain_size` coset values as 32-byte canonical scalars, laid out shard-major so
+    /// that shard p's share is the contiguous range `h_scalars_slice(p)` - what a scatter sends.
+    pub fn witness_map_coset(&self, full_assignment: &[Fr]) -> Result<Vec<u8>, SynthesisError> {
+        if full_assignment.len() != self.num_variables {
+            return Err(SynthesisError::AssignmentMissing);
+        }
+        let w = canonical_bytes(full_assignment);
+        let mut q = vec![0u8; unsafe { sys::cg_domain_size(self.ctx) } as usize * 32];
+        let rc = unsafe { sys::cg_witness_map_coset(self.ctx, w.as_ptr() as *const _, 0, q.as_mut_ptr() as *mut _, 0) };
+        if rc != 0 { Err(map_err(rc)) } else { Ok(q) }
+    }
+
+    /// (offset, count), in scalars, of shard `shard`'s share of `witness_map_coset`'s output (`cg_h_scalars_slice`).
+    pub fn h_scalars_slice(&self, shard: u32) -> Result<(u64, u64), SynthesisError> {
+        let (mut off, mut cnt) = (0u64, 0u64);
+        let rc = unsafe { sys::cg_h_scalars_slice(self.ctx, shard, &mut off, &mut cnt) };
+        if rc != 0 { Err(map_err(rc)) } else { Ok((off, cnt)) }
+    }
+
+    /// Step 2 (`cg_prove_partial_q`): this shard's partial sums with its slice of the coset values supplied; the only way a
+    /// context loaded with `CG_FLAG_H_SCALARS_EXTERNAL` proves.
+    pub fn prove_partial_q(&self, r: Fr, full_assignment: &[Fr], q_slice: &[u8]) -> Result<[u8; 384], SynthesisError> {
+        if full_assignment.len() != self.num_variables {
+            return Err(SynthesisError::AssignmentMissing);
+        }
+        let (w, rb) = (canonical_bytes(full_assignment), r.into_bigint().to_bytes_le());
+        let mut out = [0u8; 384];
+        let rc = unsafe {
+            sys::cg_prove_partial_q(self.ctx, w.as_ptr() as *const _, 0, q_slice.as_ptr() as *const _, 0, rb.as_ptr(), out.as_mut_ptr(),
+                                    std::ptr::null_mut())
+        };
+        if rc != 0 { Err(map_err(rc)) } else { Ok(out) }
+    }
+}
+
+impl GpuCircuit {
+    /// Blocks until a staged load's final arrangement is in force (`cg_ctx_wait_ready`); `Ok(false)` = the time ran out
+    /// first.  `timeout_ms < 0` waits without limit.  Proofs made before that are the same bytes, only slower.
+    pub fn wait_ready(&self, timeout_ms: i32) -> Result<bool, SynthesisError> {
+        match unsafe { sys::cg_ctx_wait_ready(self.ctx, timeout_ms) } {
+            0 => Ok(true),
+            1 => Ok(false),
+            rc => Err(map_err(rc)),
+        }
+    }
+
+    /// Where the load's time went (`cg_ctx_get_load_timings`): the counterpart of the reference's "Reading ProverParams" /
+    /// "Reading R1CS" timers (creds/src/lib.rs:257,266).
+    pub fn load_timings(&self) -> Result<sys::cg_load_timings, SynthesisError> {
+        let mut t = sys::cg_load_timings::default();
+        let rc = unsafe { sys::cg_ctx_get_load_timings(self.ctx, &mut t) };
+        if rc != 0 {
+            return Err(map_err(rc));
+        }
+        Ok(t)
+    }
+
     /// What the circuit occupies on the GPU and how its MSMs are configured (`cg_ctx_get_info`).
     pub fn info(&self) -> Result<sys::cg_ctx_info, SynthesisError> {
         let mut i = sys::cg_ctx_info::default();

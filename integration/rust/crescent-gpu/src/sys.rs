@@ -10,6 +10,7 @@ pub const CG_FLAG_THROUGHPUT_MODE: i32 = 4;
 pub const CG_FLAG_SPIN_WAIT: i32 = 8;
 pub const CG_FLAG_CONTIGUOUS_H_SHARDS: i32 = 16;
 pub const CG_FLAG_H_SCALARS_EXTERNAL: i32 = 32;
+pub const CG_FLAG_STAGED_LOAD: i32 = 64;
 pub const CG_ERR_POLY_DEGREE_TOO_LARGE: c_int = -5;
 pub const CG_ERR_MALFORMED_KEY: c_int = -6;
 
@@ -94,12 +95,35 @@ pub struct cg_ctx_info {
     pub shard_rank: i32,
     pub shard_count: i32,
     pub latency_mode: i32,
-    pub reserved: [i32; 4],
+    pub warmup: i32,
+    pub reserved: [i32; 3],
     pub slot_entry_bytes: u64,
     pub slot_piece_bytes: u64,
     pub slot_bucket_bytes: u64,
     pub slot_transform_bytes: u64,
     pub slot_upload_bytes: u64,
+}
+
+#[repr(C)]
+#[derive(Default, Clone, Copy, Debug)]
+pub struct cg_load_timings {
+    pub total_ms: f32,
+    pub matrices_ms: f32,
+    pub domain_ms: f32,
+    pub key_copy_ms: f32,
+    pub fold_ms: f32,
+    pub window_tables_ms: f32,
+    pub slots_ms: f32,
+    pub final_slots_ms: f32,
+    pub background_ms: f32,
+    pub swap_wait_ms: f32,
+    pub ready_after_ms: f32,
+    pub staged: i32,
+    pub ready: i32,
+    pub windows_from_proof: i32,
+    pub warmup_proofs: i32,
+    pub background_status: i32,
+    pub reserved: [i32; 3],
 }
 
 pub enum cg_ctx {}
@@ -130,6 +154,44 @@ extern "C" {
     pub fn cg_host_alloc(bytes: u64) -> *mut c_void;
     pub fn cg_host_free(p: *mut c_void);
     pub fn cg_ctx_get_info(ctx: *mut cg_ctx, out: *mut cg_ctx_info) -> c_int;
+    pub fn cg_ctx_get_load_timings(ctx: *mut cg_ctx, out: *mut cg_load_timings) -> c_int;
+    pub fn cg_ctx_wait_ready(ctx: *mut cg_ctx, timeout_ms: i32) -> c_int;
+    // one proof over several GPUs: this shard's five partial sums; the gathered partials finished into a proof
+    pub fn cg_prove_partial(
+        ctx: *mut cg_ctx,
+        full_assignment: *const c_void,
+        assignment_on_device: c_int,
+        r: *const u8,
+        out_partials: *mut u8,
+        timings: *mut cg_timings,
+    ) -> c_int;
+    pub fn cg_assemble(
+        ctx: *mut cg_ctx,
+        partials: *const u8,
+        n_shards: u32,
+        r: *const u8,
+        s: *const u8,
+        proof_out: *mut u8,
+    ) -> c_int;
+    // the other arrangement: the witness map once, its values scattered, every shard proves with its slice
+    pub fn cg_witness_map_coset(
+        ctx: *mut cg_ctx,
+        full_assignment: *const c_void,
+        assignment_on_device: c_int,
+        q_out: *mut c_void,
+        q_on_device: c_int,
+    ) -> c_int;
+    pub fn cg_h_scalars_slice(ctx: *const cg_ctx, shard: u32, offset: *mut u64, count: *mut u64) -> c_int;
+    pub fn cg_prove_partial_q(
+        ctx: *mut cg_ctx,
+        full_assignment: *const c_void,
+        assignment_on_device: c_int,
+        q_slice: *const c_void,
+        q_on_device: c_int,
+        r: *const u8,
+        out_partials: *mut u8,
+        timings: *mut cg_timings,
+    ) -> c_int;
     pub fn cg_witness_map(ctx: *mut cg_ctx, full_assignment: *const u8, h_out: *mut u8) -> c_int;
     pub fn cg_domain_size(ctx: *const cg_ctx) -> u64;
     pub fn cg_qap_load(

@@ -763,3 +763,189 @@ int ref_prove(const ref_pk* pk, const csr_t abc[3], uint64_t l, uint64_t m, uint
     free(aq); free(b1q); free(hq); free(lq); free(b2q); free(w); free(h); free(h_big);
     return 0;
 }
+
+/* ================================================================================================
+ * The files either side of the prove step, at full size (TEST INFRASTRUCTURE, as everything here).
+ *
+ * oracle/ark_files.py writes and reads the same formats in pure Python for the small fixtures; a
+ * 0.6 GB main_c.r1cs / prover_params.bin (creds/test-vectors/README.md:5-10) needs a compiled writer
+ * and, for the CPU side of bench.py's `cold_start` record, a compiled reader.  Written from the format
+ * descriptions, independently of the product's parsers (csrc/r1cs.hip, csrc/serialize.hip):
+ *   - iden3 .r1cs container: forks/circom-compat/src/circom/r1cs_reader.rs:54-148 (sections), :162-202
+ *     (header), :205-236 (constraints), :238-256 (wire map); section 3 directly after section 2 (:125)
+ *   - ark-serialize uncompressed ProvingKey: forks/groth16/src/data_structures.rs:31-44,101-118,
+ *     Vec<T> = u64 LE length + items, SWFlags in the two top bits of a point's last byte [ark-mem]
+ * ================================================================================================ */
+static const uint8_t FR_MODULUS_BYTES[32] = { /* r1cs_reader.rs:183 */
+    0x01, 0x00, 0x00, 0xf0, 0x93, 0xf5, 0xe1, 0x43, 0x91, 0x70, 0xb9, 0x79, 0x48, 0xe8, 0x33, 0x28,
+    0x5d, 0x58, 0x81, 0x81, 0xb6, 0x45, 0x50, 0xb8, 0x29, 0xa0, 0x31, 0xe1, 0x72, 0x4e, 0x64, 0x30};
+
+static void put32(uint8_t** p, uint32_t v) { memcpy(*p, &v, 4); *p += 4; }
+static void put64(uint8_t** p, uint64_t v) { memcpy(*p, &v, 8); *p += 8; }
+
+uint64_t ref_r1cs_file_size(const csr_t abc[3], uint64_t m, uint64_t n_wires) {
+    uint64_t cons = 12 * m + 36 * (abc[0].nnz + abc[1].nnz + abc[2].nnz);
+    return 4 + 4 + 4 + 3 * 12 + 64 + cons + 8 * n_wires;
+}
+/* sections in circom's order: header (1), constraints (2), wire map (3) */
+int ref_r1cs_write(const csr_t abc[3], uint64_t m, uint32_t n_wires, uint32_t n_pub_out, uint32_t n_pub_in, uint32_t n_prv_in,
+                   uint8_t* out, uint64_t cap) {
+    if (cap < ref_r1cs_file_size(abc, m, n_wires)) return -1;
+    uint8_t* p = out;
+    memcpy(p, "r1cs", 4); p += 4;
+    put32(&p, 1); put32(&p, 3);
+    put32(&p, 1); put64(&p, 64);                                   /* header section: 4 + 32 + 4*4 + 8 + 4 */
+    put32(&p, 32); memcpy(p, FR_MODULUS_BYTES, 32); p += 32;
+    put32(&p, n_wires); put32(&p, n_pub_out); put32(&p, n_pub_in); put32(&p, n_prv_in);
+    put64(&p, n_wires); put32(&p, (uint32_t)m);
+    put32(&p, 2); put64(&p, 12 * m + 36 * (abc[0].nnz + abc[1].nnz + abc[2].nnz));
+    for (uint64_t i = 0; i < m; ++i)
+        for (int k = 0; k < 3; ++k) {
+            const uint64_t b = abc[k].row_ptr[i], e = abc[k].row_ptr[i + 1];
+            put32(&p, (uint32_t)(e - b));
+            for (uint64_t t = b; t < e; ++t) { put32(&p, abc[k].col[t]); memcpy(p, abc[k].coeff + 32 * t, 32); p += 32; }
+        }
+    put32(&p, 3); put64(&p, 8 * (uint64_t)n_wires);
+    for (uint64_t i = 0; i < n_wires; ++i) put64(&p, i);
+    return (uint64_t)(p - out) == ref_r1cs_file_size(abc, m, n_wires) ? 0 : -2;
+}
+
+/* Sequential reader, as `R1CSFile::new` reads: one pass over the constraint section appending to growing arrays
+ * (read_constraints, r1cs_reader.rs:205-236, pushes every term onto a Vec).  Two calls: sizes, then fill. */
+typedef struct { uint32_t n_wires, n_pub_out, n_pub_in, n_prv_in, n_constraints; uint64_t nnz[3]; uint64_t cons_off; } ref_r1cs_info;
+int ref_r1cs_scan(const uint8_t* data, uint64_t len, ref_r1cs_info* info) {
+    if (len < 12 || memcmp(data, "r1cs", 4)) return -1;
+    uint32_t ver, nsec; memcpy(&ver, data + 4, 4); memcpy(&nsec, data + 8, 4);
+    if (ver != 1) return -2;
+    uint64_t off = 12, hdr = 0, cons = 0, cons_size = 0;
+    for (uint32_t s = 0; s < nsec; ++s) {
+        if (off + 12 > len) return -3;
+        uint32_t ty; uint64_t sz; memcpy(&ty, data + off, 4); memcpy(&sz, data + off + 4, 8);
+        off += 12;
+        if (ty == 1) hdr = off;
+        if (ty == 2) { cons = off; cons_size = sz; }
+        if (sz > len - off) return -3;
+        off += sz;
+    }
+    if (!hdr || !cons) return -4;
+    uint32_t fs; memcpy(&fs, data + hdr, 4);
+    if (fs != 32 || memcmp(data + hdr + 4, FR_MODULUS_BYTES, 32)) return -5;
+    memcpy(&info->n_wires, data + hdr + 36, 4); memcpy(&info->n_pub_out, data + hdr + 40, 4);
+    memcpy(&info->n_pub_in, data + hdr + 44, 4); memcpy(&info->n_prv_in, data + hdr + 48, 4);
+    memcpy(&info->n_constraints, data + hdr + 60, 4);
+    info->cons_off = cons;
+    info->nnz[0] = info->nnz[1] = info->nnz[2] = 0;
+    uint64_t p = cons, end = cons + cons_size;
+    for (uint32_t i = 0; i < info->n_constraints; ++i)
+        for (int k = 0; k < 3; ++k) {
+            if (p + 4 > end) return -6;
+            uint32_t n; memcpy(&n, data + p, 4);
+            p += 4 + 36ull * n;
+            if (p > end) return -6;
+            info->nnz[k] += n;
+        }
+    return 0;
+}
+int ref_r1cs_fill(const uint8_t* data, const ref_r1cs_info* info, uint64_t* row_ptr[3], uint32_t* col[3], uint8_t* coeff[3]) {
+    uint64_t p = info->cons_off, t[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k) row_ptr[k][0] = 0;
+    for (uint32_t i = 0; i < info->n_constraints; ++i)
+        for (int k = 0; k < 3; ++k) {
+            uint32_t n; memcpy(&n, data + p, 4); p += 4;
+            for (uint32_t j = 0; j < n; ++j, p += 36) {
+                memcpy(&col[k][t[k]], data + p, 4);
+                memcpy(coeff[k] + 32 * t[k], data + p + 4, 32);
+                uint64_t c[4]; memcpy(c, data + p + 4, 32);
+                if (ge_mod(c, FR.n)) return -7;                     /* deserialize rejects a non-canonical element */
+                ++t[k];
+            }
+            row_ptr[k][i + 1] = t[k];
+        }
+    return 0;
+}
+
+/* ark-serialize SWFlags of a packed canonical point, from its bytes: y > -y decided by computing q - y */
+static void neg_canonical_q(uint8_t out[32], const uint8_t y[32]) {
+    uint64_t a[4], r[4]; memcpy(a, y, 32);
+    u128 br = 0;
+    for (int i = 0; i < 4; ++i) { u128 d = (u128)FQ.n[i] - a[i] - (uint64_t)br; r[i] = (uint64_t)d; br = (d >> 64) & 1; }
+    memcpy(out, r, 32);
+}
+static int bytes_zero(const uint8_t* b, int n) { for (int i = 0; i < n; ++i) if (b[i]) return 0; return 1; }
+static uint8_t flags_g1(const uint8_t pt[64]) {
+    if (bytes_zero(pt, 64)) return 0x40;
+    uint8_t ny[32]; neg_canonical_q(ny, pt + 32);
+    return canon_gt(pt + 32, ny) ? 0x80 : 0;
+}
+static uint8_t flags_g2(const uint8_t pt[128]) {
+    if (bytes_zero(pt, 128)) return 0x40;
+    uint8_t n0[32], n1[32];
+    if (bytes_zero(pt + 96, 32)) memset(n1, 0, 32); else neg_canonical_q(n1, pt + 96);      /* -0 = 0 */
+    if (bytes_zero(pt + 64, 32)) memset(n0, 0, 32); else neg_canonical_q(n0, pt + 64);
+    int gt = canon_gt(pt + 96, n1) || (!memcmp(pt + 96, n1, 32) && canon_gt(pt + 64, n0));   /* c1 first, then c0 */
+    return gt ? 0x80 : 0;
+}
+static void put_g1(uint8_t** p, const uint8_t* pt) { memcpy(*p, pt, 64); (*p)[63] |= flags_g1(pt); *p += 64; }
+static void put_g2(uint8_t** p, const uint8_t* pt) { memcpy(*p, pt, 128); (*p)[127] |= flags_g2(pt); *p += 128; }
+static void put_g1s(uint8_t** p, const uint8_t* pts, uint64_t n, int nt) {
+    put64(p, n);
+    uint8_t* base = *p;
+    _Pragma("omp parallel for num_threads(nt)")
+    for (uint64_t i = 0; i < n; ++i) { uint8_t* q = base + 64 * i; put_g1(&q, pts + 64 * i); }
+    *p += 64 * n;
+}
+static void put_g2s(uint8_t** p, const uint8_t* pts, uint64_t n, int nt) {
+    put64(p, n);
+    uint8_t* base = *p;
+    _Pragma("omp parallel for num_threads(nt)")
+    for (uint64_t i = 0; i < n; ++i) { uint8_t* q = base + 128 * i; put_g2(&q, pts + 128 * i); }
+    *p += 128 * n;
+}
+uint64_t ref_pk_file_size(const ref_pk* pk, uint64_t n_abc) {
+    return 64 + 128 + 128 + 64 + 128 + 8 + 64 * n_abc + 64 + 64 + 8 + 64 * pk->a_len + 8 + 64 * pk->b_g1_len + 8 + 128 * pk->b_g2_len +
+           8 + 64 * pk->h_len + 8 + 64 * pk->l_len;
+}
+/* ProvingKey { vk { alpha_g1, beta_g2, gamma_g2, delta_g1, delta_g2, gamma_abc_g1 }, beta_g1, delta_g1, a_query, b_g1_query,
+ * b_g2_query, h_query, l_query } (data_structures.rs:31-44: the fork's vk carries delta_g1; :101-118) */
+int ref_pk_write(const ref_pk* pk, const uint8_t* gamma_g2, const uint8_t* gamma_abc, uint64_t n_abc, uint8_t* out, uint64_t cap, int nt) {
+    if (cap < ref_pk_file_size(pk, n_abc)) return -1;
+    uint8_t* p = out;
+    put_g1(&p, pk->alpha_g1); put_g2(&p, pk->beta_g2); put_g2(&p, gamma_g2); put_g1(&p, pk->delta_g1); put_g2(&p, pk->delta_g2);
+    put_g1s(&p, gamma_abc, n_abc, 1);
+    put_g1(&p, pk->beta_g1); put_g1(&p, pk->delta_g1);
+    put_g1s(&p, pk->a_query, pk->a_len, nt); put_g1s(&p, pk->b_g1_query, pk->b_g1_len, nt); put_g2s(&p, pk->b_g2_query, pk->b_g2_len, nt);
+    put_g1s(&p, pk->h_query, pk->h_len, nt); put_g1s(&p, pk->l_query, pk->l_len, nt);
+    return (uint64_t)(p - out) == ref_pk_file_size(pk, n_abc) ? 0 : -2;
+}
+/* reader: offsets and lengths of the five queries inside a serialized ProvingKey, then a flag-stripping copy
+ * (deserialize_uncompressed_unchecked: no curve checks, creds/src/utils.rs:186) */
+typedef struct { uint64_t n_abc, off_abc, off_beta_g1, off_a, n_a, off_b1, n_b1, off_b2, n_b2, off_h, n_h, off_l, n_l, end; } ref_pk_layout;
+int ref_pk_scan(const uint8_t* data, uint64_t len, ref_pk_layout* L) {
+    uint64_t off = 64 + 128 + 128 + 64 + 128;
+    if (off + 8 > len) return -1;
+    memcpy(&L->n_abc, data + off, 8); off += 8; L->off_abc = off;
+    if (L->n_abc > (len - off) / 64) return -1;
+    off += 64 * L->n_abc;
+    L->off_beta_g1 = off; off += 128;
+    uint64_t* fields[5][2] = {{&L->off_a, &L->n_a}, {&L->off_b1, &L->n_b1}, {&L->off_b2, &L->n_b2}, {&L->off_h, &L->n_h}, {&L->off_l, &L->n_l}};
+    for (int q = 0; q < 5; ++q) {
+        const uint64_t sz = q == 2 ? 128 : 64;
+        if (off + 8 > len) return -1;
+        memcpy(fields[q][1], data + off, 8); off += 8;
+        *fields[q][0] = off;
+        if (*fields[q][1] > (len - off) / sz) return -1;
+        off += sz * *fields[q][1];
+    }
+    L->end = off;
+    return 0;
+}
+void ref_points_strip(const uint8_t* src, uint64_t n, uint64_t sz, uint8_t* dst, int nt) {
+    _Pragma("omp parallel for num_threads(nt)")
+    for (uint64_t i = 0; i < n; ++i) {
+        uint8_t* d = dst + sz * i;
+        memcpy(d, src + sz * i, sz);
+        const uint8_t f = d[sz - 1] & 0xC0;
+        d[sz - 1] &= 0x3F;
+        if (f & 0x40) memset(d, 0, sz);
+    }
+}

@@ -216,3 +216,124 @@ def prove(pk, mats, l, m, M, witness, r: int, s: int, nthreads=1, timings=False)
     rc = lib().ref_prove(C.byref(k), arr, l, m, M, w.ctypes.data, rb.ctypes.data, sb.ctypes.data, out.ctypes.data, nthreads, C.byref(tm))
     assert rc == 0, rc
     return (out.tobytes(), tm.as_dict()) if timings else out.tobytes()
+
+
+# ---- the files either side of the prove step at full size (cpu_ref.c, last section) ----------------------------------
+class _R1csInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("n_wires", "n_pub_out", "n_pub_in", "n_prv_in", "n_constraints")] + \
+               [("nnz", C.c_uint64 * 3), ("cons_off", C.c_uint64)]
+
+
+class _PkLayout(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_abc", "off_abc", "off_beta_g1", "off_a", "n_a", "off_b1", "n_b1", "off_b2", "n_b2",
+                                          "off_h", "n_h", "off_l", "n_l", "end")]
+
+
+class Csr:
+    """one matrix as the three numpy arrays every caller here passes around"""
+
+    def __init__(self, row_ptr, col, coeff):
+        self.row_ptr, self.col, self.coeff = row_ptr, col, coeff
+        self.nnz = int(col.size)
+
+
+def write_r1cs(mats, m, n_wires, n_pub_out, n_pub_in, n_prv_in) -> np.ndarray:
+    """main_c.r1cs for three CSR matrices (writer side of r1cs_reader.rs:54-256)"""
+    L = lib()
+    arr, _k = _csr3(mats)
+    L.ref_r1cs_file_size.restype = C.c_uint64
+    L.ref_r1cs_file_size.argtypes = [C.POINTER(_Csr), C.c_uint64, C.c_uint64]
+    L.ref_r1cs_write.argtypes = [C.POINTER(_Csr), C.c_uint64] + [C.c_uint32] * 4 + [C.c_void_p, C.c_uint64]
+    size = L.ref_r1cs_file_size(arr, m, n_wires)
+    out = np.empty(size, np.uint8)
+    rc = L.ref_r1cs_write(arr, m, n_wires, n_pub_out, n_pub_in, n_prv_in, out.ctypes.data, size)
+    assert rc == 0, rc
+    return out
+
+
+def read_r1cs(data):
+    """-> (info dict, (A, B, C) as Csr): the sequential reader, timed as the CPU side of a cold start"""
+    L = lib()
+    d = _u8(data)
+    info = _R1csInfo()
+    L.ref_r1cs_scan.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(_R1csInfo)]
+    rc = L.ref_r1cs_scan(d.ctypes.data, d.size, C.byref(info))
+    assert rc == 0, rc
+    m = info.n_constraints
+    rps = [np.empty(m + 1, np.uint64) for _ in range(3)]
+    cols = [np.empty(max(1, info.nnz[k]), np.uint32) for k in range(3)]
+    cfs = [np.empty(max(1, info.nnz[k]) * 32, np.uint8) for k in range(3)]
+    P = C.c_void_p * 3
+    L.ref_r1cs_fill.argtypes = [C.c_void_p, C.POINTER(_R1csInfo), P, P, P]
+    rc = L.ref_r1cs_fill(d.ctypes.data, C.byref(info), P(*[a.ctypes.data for a in rps]), P(*[a.ctypes.data for a in cols]),
+                         P(*[a.ctypes.data for a in cfs]))
+    assert rc == 0, rc
+    mats = tuple(Csr(rps[k], cols[k][:info.nnz[k]], cfs[k][:32 * info.nnz[k]]) for k in range(3))
+    hdr = dict(n_wires=info.n_wires, n_pub_out=info.n_pub_out, n_pub_in=info.n_pub_in, n_prv_in=info.n_prv_in, n_constraints=m,
+               num_inputs=1 + info.n_pub_in + info.n_pub_out, num_variables=info.n_wires)
+    return hdr, mats
+
+
+def _pk_struct(pk):
+    k = _Pk()
+    arrs = dict(alpha_g1=pk.vk.alpha_g1, beta_g1=pk.beta_g1, delta_g1=pk.delta_g1, beta_g2=pk.vk.beta_g2, delta_g2=pk.vk.delta_g2,
+                a_query=pk.a_query, b_g1_query=pk.b_g1_query, b_g2_query=pk.b_g2_query, h_query=pk.h_query, l_query=pk.l_query)
+    keep = {}
+    for name, a in arrs.items():
+        a = _u8(a)
+        if a.size == 0:
+            a = np.zeros(64, np.uint8)
+        keep[name] = a
+        setattr(k, name, a.ctypes.data)
+    k.a_len, k.b_g1_len, k.b_g2_len = pk.a_query.size // 64, pk.b_g1_query.size // 64, pk.b_g2_query.size // 128
+    k.h_len, k.l_len = pk.h_query.size // 64, pk.l_query.size // 64
+    return k, keep
+
+
+def write_pk(pk, nthreads=8) -> np.ndarray:
+    """ark-serialize uncompressed ProvingKey (the `groth16_params` that leads prover_params.bin) from packed canonical arrays"""
+    L = lib()
+    k, _keep = _pk_struct(pk)
+    gabc, g2 = _u8(pk.vk.gamma_abc_g1), _u8(pk.vk.gamma_g2)
+    L.ref_pk_file_size.restype = C.c_uint64
+    L.ref_pk_file_size.argtypes = [C.POINTER(_Pk), C.c_uint64]
+    L.ref_pk_write.argtypes = [C.POINTER(_Pk), C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int]
+    size = L.ref_pk_file_size(C.byref(k), gabc.size // 64)
+    out = np.empty(size, np.uint8)
+    rc = L.ref_pk_write(C.byref(k), g2.ctypes.data, gabc.ctypes.data, gabc.size // 64, out.ctypes.data, size, nthreads)
+    assert rc == 0, rc
+    return out
+
+
+class _Vk:
+    pass
+
+
+class PkArrays:
+    """what read_pk returns: the ProvingKey fields cpu_ref.prove takes (packed canonical numpy arrays)"""
+
+
+def read_pk(data, nthreads=8):
+    """-> (PkArrays, bytes consumed): flags stripped, no curve checks (creds/src/utils.rs:186)"""
+    L = lib()
+    d = _u8(data)
+    lay = _PkLayout()
+    L.ref_pk_scan.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(_PkLayout)]
+    rc = L.ref_pk_scan(d.ctypes.data, d.size, C.byref(lay))
+    assert rc == 0, rc
+    L.ref_points_strip.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
+
+    def pts(off, n, sz):
+        out = np.empty(max(1, n) * sz, np.uint8)
+        L.ref_points_strip(d.ctypes.data + off, n, sz, out.ctypes.data, nthreads)
+        return out[:n * sz]
+    pk = PkArrays()
+    pk.vk = _Vk()
+    pk.vk.alpha_g1, pk.vk.beta_g2, pk.vk.gamma_g2 = pts(0, 1, 64), pts(64, 1, 128), pts(192, 1, 128)
+    pk.vk.delta_g1, pk.vk.delta_g2 = pts(320, 1, 64), pts(384, 1, 128)
+    pk.vk.gamma_abc_g1 = pts(lay.off_abc, lay.n_abc, 64)
+    pk.beta_g1, pk.delta_g1 = pts(lay.off_beta_g1, 1, 64), pts(lay.off_beta_g1 + 64, 1, 64)
+    pk.a_query, pk.b_g1_query = pts(lay.off_a, lay.n_a, 64), pts(lay.off_b1, lay.n_b1, 64)
+    pk.b_g2_query = pts(lay.off_b2, lay.n_b2, 128)
+    pk.h_query, pk.l_query = pts(lay.off_h, lay.n_h, 64), pts(lay.off_l, lay.n_l, 64)
+    return pk, int(lay.end)

@@ -172,7 +172,7 @@ def test_circuit_load_validates_before_touching_the_gpu(cc):
     pk.h_len = 7
     for kw, msg in ((dict(window_bits=1), b"window_bits"), (dict(window_bits=23), b"window_bits"), (dict(window_bits=-3), b"window_bits"),
                     (dict(shard_count=4, shard_rank=4), b"shard_rank"), (dict(shard_count=2, shard_rank=-1), b"shard_rank"),
-                    (dict(proof_slots=-1), b"proof_slots"), (dict(flags=64), b"flags"), (dict(flags=1 << 20), b"flags"),
+                    (dict(proof_slots=-1), b"proof_slots"), (dict(flags=128), b"flags"), (dict(flags=1 << 20), b"flags"),
                     (dict(flags=2 | 4), b"exclusive")):
         opt = api._CgOptions(device=-1, **kw)
         rc = L.cg_circuit_load(ctypes.byref(h), ctypes.byref(pk), abc, 3, 4, 7, ctypes.byref(opt))
@@ -248,14 +248,15 @@ def test_rust_shim_struct_field_types_match_header():
     """the repr(C) structs of sys.rs carry the header's field TYPES, not only its names and order (the crate has
     never met rustc, so the layout is checked here): u64 / i32 / f32 widths, pointer constness, array lengths"""
     rs = open(os.path.join(ROOT, "integration", "rust", "crescent-gpu", "src", "sys.rs")).read()
-    for name in ("cg_proving_key", "cg_csr", "cg_options", "cg_timings", "cg_ctx_info"):
+    for name in ("cg_proving_key", "cg_csr", "cg_options", "cg_timings", "cg_ctx_info", "cg_load_timings"):
         body = re.search(r"pub struct %s \{(.*?)\n\}" % name, rs, flags=re.S).group(1)
         rust = [(f, " ".join(t.split())) for f, t in re.findall(r"pub (\w+):\s*([^,\n]+),", body)]
         assert rust == _c_struct_field_types(name), name
     # and the ctypes mirror's widths
     from crescent_credentials_amd import api
     width = {"u64": 8, "u32": 4, "i32": 4, "f32": 4}
-    for cls, name in ((api._CgOptions, "cg_options"), (api.CgTimings, "cg_timings"), (api.CgCtxInfo, "cg_ctx_info"), (api._CgProvingKey, "cg_proving_key")):
+    for cls, name in ((api._CgOptions, "cg_options"), (api.CgTimings, "cg_timings"), (api.CgCtxInfo, "cg_ctx_info"), (api._CgProvingKey, "cg_proving_key"),
+                      (api.CgLoadTimings, "cg_load_timings")):
         for (fname, ctype), (hname, rtype) in zip(cls._fields_, _c_struct_field_types(name)):
             assert fname == hname
             m = re.match(r"\[(\w+); (\d+)\]", rtype)
@@ -335,7 +336,7 @@ def test_rust_shim_bindings_match_header():
     rs = open(os.path.join(ROOT, "integration", "rust", "crescent-gpu", "src", "sys.rs")).read()
     fns = re.findall(r"pub fn (cg_[a-z0-9_]+)\s*\(", rs)
     assert len(fns) >= 8 and set(fns) <= set(_declared_symbols())
-    for name in ("cg_proving_key", "cg_csr", "cg_options", "cg_timings", "cg_ctx_info"):
+    for name in ("cg_proving_key", "cg_csr", "cg_options", "cg_timings", "cg_ctx_info", "cg_load_timings"):
         body = re.search(r"pub struct %s \{(.*?)\n\}" % name, rs, flags=re.S).group(1)
         fields = re.findall(r"pub (\w+):", body)
         assert fields == _c_struct_fields(name), name

@@ -212,3 +212,80 @@ def test_r1cs_writer_and_product_reader_agree(cc, oracle, af):
     # the Python oracle's reader reads the same file the same way
     parsed = oracle.parse_r1cs(blob)
     assert oracle.r1cs_to_matrices(parsed)[0] == rows
+
+
+# ------------------------------------------------------------- the compiled writers / readers of oracle/cpu_ref.c (full-size files)
+def test_compiled_file_writers_agree_with_the_python_oracle_and_the_product(cc, oracle, af, d8):
+    """oracle/cpu_ref.c's last section writes the 0.6 GB main_c.r1cs / prover_params.bin of the full-size tests and reads them
+    back for the CPU side of bench.py's cold start.  On a small circuit: its bytes are the pure-Python oracle's, its reader
+    returns what was written, and the product's (multi-threaded) parsers return the same arrays."""
+    import cpu_ref
+    from crescent_credentials_amd import workloads as wl
+    l, m, M = 5, 700, 760
+    cm, w = wl.synthetic_circuit(991, l, m, M, 0.8, 3, profile="gates")
+    rows = wl.matrices_to_rows(cm)
+    blob = cpu_ref.write_r1cs((cm.a, cm.b, cm.c), m, M, 1, l - 2, M - l)
+    assert blob.tobytes() == af.r1cs_file_bytes(rows, M, 1, l - 2, M - l)
+    hdr, mats = cpu_ref.read_r1cs(blob)
+    assert (hdr["num_inputs"], hdr["n_constraints"], hdr["num_variables"]) == (l, m, M)
+    got = cc.R1CSFile(blob.tobytes()).matrices
+    for ref, mine, prod in zip((cm.a, cm.b, cm.c), mats, (got.a, got.b, got.c)):
+        for f in ("row_ptr", "col", "coeff"):
+            assert np.array_equal(getattr(ref, f), getattr(mine, f)) and np.array_equal(getattr(ref, f), getattr(prod, f)), f
+    # a non-canonical coefficient is refused by both readers
+    bad = blob.copy()
+    at = int(hdr_offset_of_first_coefficient(blob))
+    bad[at:at + 32] = np.frombuffer(oracle.FR_MODULUS_LE, np.uint8)
+    with pytest.raises(AssertionError):
+        cpu_ref.read_r1cs(bad)
+    with pytest.raises(cc.CrescentGpuError):
+        cc.R1CSFile(bad.tobytes())
+    # the key: the D = 8 golden key (identities and both y signs occur in it)
+    pk = d8["pk"]
+    ser = cpu_ref.write_pk(pk, nthreads=3)
+    assert ser.tobytes() == oracle.pk_uncompressed(d8["opk"]) == cc.proving_key_to_bytes(pk)
+    back, used = cpu_ref.read_pk(ser)
+    assert used == ser.size
+    mine, used2 = cc.proving_key_from_bytes(ser.tobytes())
+    assert used2 == ser.size
+    for f in ("beta_g1", "delta_g1", "a_query", "b_g1_query", "b_g2_query", "h_query", "l_query"):
+        assert np.array_equal(getattr(back, f), getattr(pk, f)) and np.array_equal(getattr(mine, f), getattr(pk, f)), f
+    for f in ("alpha_g1", "beta_g2", "gamma_g2", "delta_g1", "delta_g2", "gamma_abc_g1"):
+        assert np.array_equal(getattr(back.vk, f), getattr(pk.vk, f)), f
+
+
+def hdr_offset_of_first_coefficient(blob) -> int:
+    """byte offset of the first coefficient of the constraint section of an .r1cs whose sections are header, constraints, map"""
+    off = 12                     # magic, version, section count
+    for _ in range(3):
+        ty, sz = struct.unpack_from("<IQ", blob, off)
+        off += 12
+        if ty == 2:
+            p = off
+            while True:          # the first block that has a term
+                n = struct.unpack_from("<I", blob, p)[0]
+                if n:
+                    return p + 4 + 4
+                p += 4
+        off += sz
+    raise AssertionError("no constraint section")
+
+
+def test_r1cs_parser_ranges_and_threads(cc, af):
+    """the two-pass parser cuts the constraints into one range per host thread: circuits smaller and larger than a range,
+    empty blocks, and a header that promises more constraints than the section holds"""
+    import cpu_ref
+    from crescent_credentials_amd import workloads as wl
+    for (l, m, M) in ((3, 1, 8), (4, 4097, 4200), (6, 20_000, 20_100)):
+        cm, _ = wl.synthetic_circuit(7 + m, l, m, M, 0.5, 3, profile="gates" if m > 1 else "r1")
+        blob = cpu_ref.write_r1cs((cm.a, cm.b, cm.c), m, M, 1, l - 2, M - l)
+        got = cc.R1CSFile(blob.tobytes()).matrices
+        for ref, prod in zip((cm.a, cm.b, cm.c), (got.a, got.b, got.c)):
+            assert np.array_equal(ref.row_ptr, prod.row_ptr) and np.array_equal(ref.col, prod.col) and np.array_equal(ref.coeff, prod.coeff)
+    # n_constraints patched to 2^31: refused before anything is sized by it
+    hdr_at = 12 + 12
+    bad = bytearray(blob.tobytes())
+    struct.pack_into("<I", bad, hdr_at + 60, 1 << 31)
+    with pytest.raises(cc.CrescentGpuError) as ei:
+        cc.R1CSFile(bytes(bad))
+    assert "unexpected end" in str(ei.value)
