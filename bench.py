@@ -59,7 +59,14 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E (guides/MI355X_MICROARCH.md)
 PEAK_CLOCK_GHZ = 2.4
-VALU_PEAK = 256 * 4 * PEAK_CLOCK_GHZ * 1e9 / 4   # wave-instructions/s: 256 CUs x 4 SIMDs, one VALU instruction per 4 cycles at 2.4 GHz
+N_SIMD = 256 * 4               # 256 CUs x 4 SIMDs
+# The hardware's own figure (guides/MI355X_MICROARCH.md "Wave scheduling": CDNA4 SIMDs are 32 lanes wide, a wave64 VALU
+# instruction issues in 2 cycles): 1228.8 G wave-instructions/s at 2.4 GHz - for the SIMPLE 32-bit instructions.  The
+# multiply-adds this arithmetic is made of take twice that, so the honest utilisation is counted in SIMD CYCLES, each
+# instruction class priced at what the SIMD measurably takes to issue it (tools/ubench/valu_rates --json, run inside this
+# bench; round 5 read the rates from a committed text file and divided by a 4-cycle convention: kept as `legacy_*`).
+VALU_PEAK_HW = N_SIMD * PEAK_CLOCK_GHZ * 1e9 / 2
+VALU_PEAK = N_SIMD * PEAK_CLOCK_GHZ * 1e9 / 4   # legacy: one VALU instruction per 4 cycles (the SIMD-16 model of rounds 1-5)
 # What the vector ALU really issues (round 5, tools/ubench/valu_rates.hip -> profiles/r05_e_valu_issue_rates.txt, cycles per
 # wave-instruction per SIMD): the 64-bit multiply-add the limb products are made of takes 4.91 - not the 4 the nominal peak
 # assumes - other VOP3 / 64-bit integer operations 4.5, and simple 32-bit VOP1/VOP2 operations (mov, and, add, sub, shifts)
@@ -78,7 +85,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=24)
-    ap.add_argument("--shape", default="rs256-sd")
+    ap.add_argument("--shape", default=None,
+                    help="the headline workload's shape (crescent-credentials_amd/workloads.py SHAPES); default rs256-sd, the configuration "
+                         "BASELINE.json's metric is quoted on")
+    ap.add_argument("--sharded-shape", default=None,
+                    help="N > 1: the shape the SHARDED proofs are made on; default mdl1 (S22: BASELINE.json's config 4 is 'mdl1 ... MSM sharded "
+                         "across 8 x MI355X') unless --shape was given, in which case that shape")
     ap.add_argument("--bits", type=float, default=0.9,
                     help="share of the aux wires that are bit gates' outputs in the headline workload (see DESIGN.md §5)")
     ap.add_argument("--profile", default="gates", choices=["gates", "r1"],
@@ -106,9 +118,16 @@ def parse():
                     help="N > 1: seconds the RCCL data group may take to come up (creation + first all_gather) before the sharded leg "
                          "falls back to gloo")
     ap.add_argument("--strict-exit", action="store_true",
-                    help="N > 1: when the watchdog has to print the line, leave with exit code 4 instead of 0 (default 0: the line itself "
-                         "says `incomplete`, and a non-zero rank exit makes the launcher discard it)")
+                    help="N > 1: when the watchdog has to print the line, rank 0 leaves with exit code 4 as well (default: rank 0 prints the "
+                         "line marked `incomplete` and exits 0, every OTHER rank exits 4 five seconds later - the launcher's return code says "
+                         "that the run did not complete, and the line is on stdout by then)")
     ap.add_argument("--no-check", action="store_true", help="skip the checker leg (proof_verifies, key_check)")
+    ap.add_argument("--no-cold-start", action="store_true",
+                    help="skip the cold_start record (the reference's own call: main_c.r1cs + prover_params.bin -> client_state.bin "
+                         "through the compiled C caller, with the CPU restatement's chain beside it)")
+    ap.add_argument("--no-shapes", action="store_true", help="N = 1: skip the second-shape record (`shapes`: mdl1 / S22, SURVEY 8d 'report both')")
+    ap.add_argument("--no-latency-curve", action="store_true", help="skip `inflight_curve` (rate and latency at 1 / 2 / 4 / 8 / 16 proofs in flight)")
+    ap.add_argument("--no-ubench", action="store_true", help="do not run tools/ubench/valu_rates (the in-run VALU issue rates of `roofline_valu`)")
     ap.add_argument("--stall-rank", type=int, default=-1,
                     help="testing aid: this rank stops before the sharded leg, as a rank that failed alone would (exercises --leg-timeout)")
     ap.add_argument("--leg-timeout", type=int, default=300,
@@ -255,10 +274,12 @@ class ClockSampler:
         return round(s[len(s) // 2], 3) if s else None
 
 
-def steady_stream(prove_one, total, inflight):
+def steady_stream(prove_one, total, inflight, latencies=None):
     """`total` calls of prove_one(k), `inflight` at a time from as many host threads, never letting the pipeline run
-    dry; returns the sorted completion times"""
+    dry; returns the sorted completion times.  latencies (a list, optional) receives (completion time, seconds the call
+    took) of every proof: what ONE caller waited for its proof."""
     done = [0.0] * total
+    began = [0.0] * total
     nxt = [0]
     lock = threading.Lock()
     err = []
@@ -270,6 +291,7 @@ def steady_stream(prove_one, total, inflight):
                 nxt[0] += 1
             if k >= total:
                 return
+            began[k] = time.perf_counter()
             try:
                 prove_one(k)
             except BaseException as e:   # surfaces below
@@ -283,7 +305,113 @@ def steady_stream(prove_one, total, inflight):
         t.join()
     if err:
         raise err[0]
+    if latencies is not None:
+        latencies.extend(sorted((done[k], done[k] - began[k]) for k in range(total)))
     return sorted(done)
+
+
+def percentiles_ms(xs):
+    """{p50, p95, p99, max} of a list of seconds, in ms"""
+    s_ = sorted(xs)
+    if not s_:
+        return None
+    at = lambda q: s_[min(len(s_) - 1, int(q * len(s_)))]
+    return {"p50": round(at(0.50) * 1e3, 3), "p95": round(at(0.95) * 1e3, 3), "p99": round(at(0.99) * 1e3, 3), "max": round(s_[-1] * 1e3, 3)}
+
+
+def cold_start_record(cc, a, pk, cm, w_np, l, m, M, fresh_rs, prover, ws_dev, log):
+    """The reference's own call at the reference's artefact size, in a FRESH process: `create_client_state`
+    (creds/src/lib.rs:255-301: read main_c.r1cs, read prover_params.bin, prove once, write client_state.bin) through the compiled
+    C caller integration/c/crescent_prove, which sees nothing but include/crescent_gpu.h.  The input files are written here from
+    the headline workload (oracle-side writers: fixtures, not the thing measured); the caller's own phase clock is the record.
+    The same files are then read by the C restatement's readers (the CPU chain's parse; its proof is timed by the cpu_baseline
+    leg and joined there)."""
+    import shutil
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ark_files
+    import bn254_oracle as o
+    import cpu_ref
+    import numpy as np
+    exe = os.path.join(ROOT, "integration", "c", "crescent_prove")
+    tmp = tempfile.mkdtemp(prefix="cg_cold_start_")
+    try:
+        t0 = time.perf_counter()
+        f = {k: os.path.join(tmp, k) for k in ("main_c.r1cs", "prover_params.bin", "witness.bin", "client_state.bin")}
+        cpu_ref.write_r1cs((cm.a, cm.b, cm.c), m, M, 2, l - 3, M - l).tofile(f["main_c.r1cs"])
+        g1 = lambda x: o.g1_unpack(bytes(x))
+        g2 = lambda x: o.g2_unpack(bytes(x))
+        vk = pk.vk
+        ovk = dict(alpha_g1=g1(vk.alpha_g1), beta_g2=g2(vk.beta_g2), gamma_g2=g2(vk.gamma_g2), delta_g1=g1(vk.delta_g1), delta_g2=g2(vk.delta_g2),
+                   gamma_abc_g1=[g1(vk.gamma_abc_g1[64 * i:64 * i + 64]) for i in range(vk.gamma_abc_g1.size // 64)])
+        pvk = ark_files.prepare_verifying_key(ovk)                      # Groth16::process_vk (creds/src/lib.rs:232)
+        cfg = b'{"alg": "RS256", "exp": {"type": "number", "reveal": true, "max_claim_byte_len": 31}}'
+        with open(f["prover_params.bin"], "wb") as fh:                  # ProverParams = key | prepared key | config (lib.rs:58-63)
+            cpu_ref.write_pk(pk, nthreads=cpu_ref.best_threads()).tofile(fh)
+            fh.write(ark_files.pvk_bytes(pvk))
+            fh.write(len(cfg).to_bytes(8, "little") + cfg)
+        w_np.tofile(f["witness.bin"])
+        made_s = time.perf_counter() - t0
+        r_, s_ = fresh_rs()
+
+        def run(extra=()):
+            cmd = [exe, f["main_c.r1cs"], f["prover_params.bin"], f["witness.bin"], f["client_state.bin"], "--rs", "%x" % r_, "%x" % s_,
+                   "--timings-json", *extra]
+            t1 = time.perf_counter()
+            pr = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            wall = time.perf_counter() - t1
+            if pr.returncode != 0:
+                raise RuntimeError("crescent_prove failed: " + pr.stderr[-1500:])
+            rec_ = json.loads(pr.stdout.strip().splitlines()[-1])
+            proof_ = cc.ClientState.from_bytes(open(f["client_state.bin"], "rb").read()).proof.data
+            return rec_, proof_, wall
+        want = prover.prove_dev(ws_dev[0].data_ptr(), r_, s_).data     # ws_dev[0] is w_np
+        staged, p_staged, wall_staged = run()
+        sync, p_sync, _ = run(("--sync-load",))
+        same = p_staged == want and p_sync == want
+        # the CPU chain's share of reading: the C restatement's own readers on the same two files
+        t1 = time.perf_counter()
+        hdr, mats = cpu_ref.read_r1cs(np.fromfile(f["main_c.r1cs"], np.uint8))
+        cpu_r1cs_s = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        pk2, _used = cpu_ref.read_pk(np.fromfile(f["prover_params.bin"], np.uint8), nthreads=cpu_ref.best_threads())
+        cpu_pp_s = time.perf_counter() - t1
+        parsed_ok = (all(np.array_equal(x.col, y.col) and np.array_equal(x.coeff, y.coeff) for x, y in zip(mats, (cm.a, cm.b, cm.c)))
+                     and np.array_equal(pk2.h_query, pk.h_query) and np.array_equal(pk2.b_g2_query, pk.b_g2_query))
+        gb = lambda n_, s__: round(n_ / s__ / 1e9, 2) if s__ > 0 else None
+        rec = {
+            "what": "files -> client_state.bin in a fresh process: integration/c/crescent_prove (strict C11 over include/crescent_gpu.h), "
+                    "staged load (CG_FLAG_STAGED_LOAD), ONE proof - the reference's create_client_state (creds/src/lib.rs:255-301)",
+            "workload": "%s: main_c.r1cs %d bytes, prover_params.bin %d bytes" % (a.shape, staged["r1cs_bytes"], staged["prover_params_bytes"]),
+            # the reference's own timers (creds/src/lib.rs:257,266,281) and what stands for them here
+            "reading_r1cs_s": round(staged["r1cs_read_s"] + staged["r1cs_parse_s"], 4),
+            "reading_prover_params_s": round(staged["prover_params_read_s"] + staged["prover_params_parse_s"], 4),
+            "r1cs_parse_s": staged["r1cs_parse_s"], "prover_params_parse_s": staged["prover_params_parse_s"],
+            "r1cs_parse_GB_per_s": gb(staged["r1cs_bytes"], staged["r1cs_parse_s"]),
+            "prover_params_parse_GB_per_s": gb(staged["prover_params_bytes"], staged["prover_params_parse_s"]),
+            "gpu_runtime_init_and_witness_read_s": staged["gpu_init_and_witness_s"],
+            "files_parsed_after_s": staged["files_parsed_after_s"],
+            "circuit_load_s": staged["circuit_load_s"], "circuit_load_split_ms": staged["circuit_load_split_ms"],
+            "first_proof_ms": staged["first_proof_ms"], "groth16_prove_s": round(staged["first_proof_ms"] / 1e3, 4),
+            "total_s": staged["total_s"], "process_wall_s_incl_background_and_exit": round(wall_staged, 3),
+            "background": dict(staged["background"], second_proof_ms=staged["second_proof_ms"],
+                               note="built by the library's worker behind the first proof: the h query's change of basis, the per-window "
+                                    "tables, the final proof slots; the context then proves at the steady rate"),
+            "synchronous_load": {"circuit_load_s": sync["circuit_load_s"], "circuit_load_split_ms": sync["circuit_load_split_ms"],
+                                 "first_proof_ms": sync["first_proof_ms"], "total_s": sync["total_s"]},
+            "proof_bytes_identical_to_the_resident_context": bool(same),
+            "cpu_chain": {"reading_r1cs_s": round(cpu_r1cs_s, 3), "reading_prover_params_s": round(cpu_pp_s, 3),
+                          "readers": "oracle/cpu_ref.c ref_r1cs_scan/_fill (one thread, as R1CSFile::new reads) and ref_pk_scan/ref_points_strip",
+                          "parsed_arrays_identical_to_the_source": bool(parsed_ok)},
+            "input_files_made_in_s": round(made_s, 1),
+        }
+        log("cold start: files -> client_state.bin in %.3f s (load %.3f s, first proof %.1f ms); synchronous load %.3f s" %
+            (staged["total_s"], staged["circuit_load_s"], staged["first_proof_ms"], sync["total_s"]))
+        assert same, "the cold-start proof differs from the resident context's"
+        assert parsed_ok, "the CPU readers and the source arrays differ"
+        return rec
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def block_times(done, warmup, steps, blocks, t_start):
@@ -300,6 +428,8 @@ def n_blocks(a):
 
 def main():
     a = parse()
+    a.sharded_shape = a.sharded_shape or (a.shape if a.shape else "mdl1")
+    a.shape = a.shape or "rs256-sd"
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a))
 
@@ -361,8 +491,9 @@ def main():
         with rs_lock:
             return rs_rng.randrange(R), rs_rng.randrange(R)
 
-    def make_workload(bits, seed_off):
-        cm_, w_ = wl.synthetic_circuit(0xC5E5CE47 + seed_off, l, m, M, bits, 3, profile=a.profile)
+    def make_workload(bits, seed_off, dims=None):
+        l_, m_, M_ = dims or (l, m, M)
+        cm_, w_ = wl.synthetic_circuit(0xC5E5CE47 + seed_off, l_, m_, M_, bits, 3, profile=a.profile)
         pk_ = cc.generate_parameters_with_qap(cm_, *trap)
         return cm_, w_, pk_
 
@@ -383,11 +514,12 @@ def main():
             barrier_sync(world)
         t_start = time.perf_counter()
         cpu0 = time.process_time()
+        lat = []
         if clock is not None:
             with clock:
-                done = steady_stream(prove_k, total, threads)
+                done = steady_stream(prove_k, total, threads, lat)
         else:
-            done = steady_stream(prove_k, total, threads)
+            done = steady_stream(prove_k, total, threads, lat)
         cpu_busy = (time.process_time() - cpu0) / max(1e-9, time.perf_counter() - t_start)
         torch.cuda.synchronize()
         window = done[warmup + n_timed - 1] - (done[warmup - 1] if warmup > 0 else t_start)
@@ -397,7 +529,9 @@ def main():
                "median_block": {"ms_per_step": round(med / steps * 1e3, 3), "value_this_rank": round(steps / med, 3),
                                 "spread_pct": round((bt[-1] - bt[0]) / med * 100.0, 2),
                                 "block_ms_min_median_max": [round(bt[0] * 1e3, 2), round(med * 1e3, 2), round(bt[-1] * 1e3, 2)]},
-               "host_cpus_busy": round(cpu_busy, 2)}     # process CPU seconds per second of the stream: what the callers cost the host
+               "host_cpus_busy": round(cpu_busy, 2),     # process CPU seconds per second of the stream: what the callers cost the host
+               # what ONE caller waits for its proof inside this stream (call to return of cg_prove*, the proofs of the timed window)
+               "latency_ms": percentiles_ms([d for t_, d in lat if (done[warmup - 1] if warmup > 0 else t_start) < t_ <= done[warmup + n_timed - 1]])}
         per_rank = [n_timed / window]
         if sync_ranks:
             barrier_sync(world)
@@ -509,27 +643,98 @@ def main():
             "note": "carry-propagating integer work (no MFMA): this kernel is bound by VALU issue, not by HBM - the HBM "
                     "fraction is reported because the contract asks for it; the binding roofline is `roofline_valu`"}
     instr = pmc.get("valu_wave_instr_per_proof") if pmc_current else None
+    # ---- what the vector ALU issues, measured on THIS box in THIS run (tools/ubench/valu_rates --json: shader cycles per
+    # wave-instruction per SIMD of the three classes, by clock64 on the device), and how this tree's kernels split over the
+    # classes (profiles/isa_class_counts.json: the disassembly of the library this process loaded, made by build()) ---------
+    issue = {"cycles_per_wave_instr": dict(ISSUE_CYCLES), "measured_in_run": False,
+             "source": "profiles/r05_e_valu_issue_rates.txt (committed; the in-run micro-benchmark did not run)"}
+    if rank == 0 and not a.no_ubench:
+        try:
+            exe = os.path.join(ROOT, "tools", "ubench", "valu_rates")
+            t_u = time.perf_counter()
+            ub = json.loads(subprocess.run([exe, "--json"], capture_output=True, text=True, timeout=60, check=True).stdout.strip().splitlines()[-1])
+            issue = {"cycles_per_wave_instr": ub["cycles_per_wave_instr"], "per_instruction": ub["per_instruction"], "measured_in_run": True,
+                     "clock_ghz_during_the_microbenchmark": ub["clock_ghz_during_mad_loop"], "seconds": round(time.perf_counter() - t_u, 2),
+                     "source": "tools/ubench/valu_rates --json, run by this process between the headline and the secondary legs: " + ub["how"]}
+        except Exception as e:
+            issue["error"] = repr(e)
+    cyc = issue["cycles_per_wave_instr"]
+    mix, mix_src = dict(ISSUE_MIX), "round 5's hand count of the hot loops (no per-kernel counts for this tree)"
+    simd_cycles_per_proof = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "isa_class_counts.json")) as f:
+            isa = json.load(f)
+        by_kernel = pmc.get("valu_wave_instr_per_proof_by_kernel") if pmc_current else None
+        if isa.get("csrc_sha16") == fingerprint and by_kernel:
+            tot = {"mad64": 0.0, "other": 0.0, "simple32": 0.0}
+            covered = 0.0
+            for kname, n_instr in by_kernel.items():
+                kc = isa["kernels"].get(kname)
+                if not kc or not kc["valu"]:
+                    continue
+                covered += n_instr
+                for c_ in tot:
+                    tot[c_] += n_instr * kc[c_] / kc["valu"]
+            if covered > 0.98 * sum(by_kernel.values()):
+                mix = {c_: round(tot[c_] / covered, 4) for c_ in tot}
+                mix_src = ("every kernel's static class split (profiles/isa_class_counts.json, disassembly of this library) weighted by its "
+                           "SQ_INSTS_VALU per proof (profiles/pmc_counters.json); %.1f %% of the instructions covered" % (100.0 * covered / sum(by_kernel.values())))
+                simd_cycles_per_proof = sum(tot[c_] * cyc[c_] for c_ in tot) * (instr / covered)
+    except Exception:
+        pass
+    mix_cycles = sum(cyc[c_] * mix[c_] for c_ in mix)
+    if simd_cycles_per_proof is None and instr:
+        simd_cycles_per_proof = instr * mix_cycles
+    per_gpu = value / world
+    util = (simd_cycles_per_proof * per_gpu / (N_SIMD * sustained * 1e9)) if (simd_cycles_per_proof and sustained) else None
     roof_valu = {"bound": "valu", "scope": "whole proof (every kernel of the prove path)", "unit": "G wave-instr/s",
-                 "peak": round(VALU_PEAK / 1e9, 1), "peak_clock_ghz": PEAK_CLOCK_GHZ,
-                 "achieved": round(instr * value / world / 1e9, 1) if instr else None,
-                 "frac": round(instr * value / world / VALU_PEAK, 4) if instr else None,
+                 "peak": round(VALU_PEAK_HW / 1e9, 1), "peak_clock_ghz": PEAK_CLOCK_GHZ,
+                 "peak_is": "256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 VALU instruction (SIMD-32: guides/MI355X_MICROARCH.md)",
+                 "achieved": round(instr * per_gpu / 1e9, 1) if instr else None,
+                 # THE fraction: SIMD issue cycles this workload needs per second / SIMD cycles the chip delivers at the clock it held
+                 "frac": round(util, 4) if util else None,
+                 "frac_is": "SIMD-cycle utilisation: sum over instruction classes of (wave-instructions per proof x cycles the SIMD takes to "
+                            "issue one, measured in this run) x proofs/s / (1024 SIMDs x sustained shader clock)",
+                 "frac_of_instruction_peak": round(instr * per_gpu / VALU_PEAK_HW, 4) if instr else None,
                  "sustained_clock_ghz": sustained,
-                 "frac_of_sustained_clock_peak": round(instr * value / world / (VALU_PEAK * sustained / PEAK_CLOCK_GHZ), 4)
-                 if instr and sustained else None,
                  "wave_instr_per_proof": instr,
-                 "issue_model": {"cycles_per_wave_instr": ISSUE_CYCLES, "static_mix_of_the_hot_loops": ISSUE_MIX,
-                                 "cycles_per_wave_instr_of_this_mix": round(MIX_CYCLES, 3),
-                                 "source": "tools/ubench/valu_rates.hip on MI355X (profiles/r05_e_valu_issue_rates.txt); mix from the ISA of "
-                                           "k_accum_affine / k_ntt29_pass"},
-                 "frac_of_mix_ceiling_at_sustained_clock": round(instr * value / world / (VALU_PEAK * 4.0 / MIX_CYCLES * sustained / PEAK_CLOCK_GHZ), 4)
+                 "simd_cycles_per_proof": round(simd_cycles_per_proof) if simd_cycles_per_proof else None,
+                 "issue_model": dict(issue, class_mix=mix, class_mix_source=mix_src, cycles_per_wave_instr_of_this_mix=round(mix_cycles, 3)),
+                 "legacy_frac_4_cycle_convention": round(instr * per_gpu / VALU_PEAK, 4) if instr else None,
+                 "legacy_frac_of_sustained_clock_peak": round(instr * per_gpu / (VALU_PEAK * sustained / PEAK_CLOCK_GHZ), 4)
                  if instr and sustained else None,
                  "counters": {"source": "committed pass (profiles/pmc_counters.json), not this run", "csrc_sha16_of_pass": pmc.get("csrc_sha16"),
                               "csrc_sha16_of_this_tree": fingerprint, "current": bool(pmc_current)},
                  "note": "SQ_INSTS_VALU per steady-state proof from the committed rocprofv3 --pmc pass of this command for this "
-                         "workload (null when none is committed for the kernel sources on disk) x this run's proofs/s per GPU, "
-                         "against 256 CU x 4 SIMD x 2.4 GHz / 4; sustained_clock_ghz is measured on the device during the "
-                         "timed proofs (cg_probe_shader_clock); frac_of_mix_ceiling_at_sustained_clock prices an instruction at what "
-                         "the vector ALU measurably takes for it (issue_model) instead of 4 cycles"}
+                         "workload (null when none is committed for the kernel sources on disk) x this run's proofs/s per GPU; "
+                         "sustained_clock_ghz is measured on the device during the timed proofs (cg_probe_shader_clock)"}
+    # ---- the transforms: the one kernel family SURVEY 8d called bandwidth-sensitive (64 B per element per transform) -----------
+    roof_ntt = None
+    if rank == 0:
+        try:
+            logd = prover.domain_size.bit_length() - 1
+            nt_ = cc.NttContext(logd, device=local_rank)
+            buf_ = torch.zeros(32 << logd, dtype=torch.uint8, device=dev)
+            for inv_ in (False, True):
+                nt_.run_dev(buf_.data_ptr(), inverse=inv_)
+            ms_ = [nt_.run_dev(buf_.data_ptr(), inverse=bool(i & 1), coset=bool(i & 2)) for i in range(8)]
+            nt_.close()
+            del buf_
+            t_ms = sum(ms_) / len(ms_)
+            alg = 64.0 * (1 << logd)
+            roof_ntt = {"kernel": "k_ntt29_pass (radix-2 transform over Fr, 2^%d elements: cg_ntt_run, the kernels cg_prove's witness map runs)" % logd,
+                        "bound": "hbm", "achieved": round(alg / (t_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_transform_ms": round(t_ms, 4),
+                        "algorithmic_bytes_per_transform": int(alg),
+                        "traffic": round(pmc["ntt_first_pass_hbm_kb_per_launch_corrected"] * 1024) if pmc_current and pmc.get("ntt_first_pass_hbm_kb_per_launch_corrected") else None,
+                        "traffic_is": "HBM bytes of ONE first pass (k_ntt29_pass<0,0,*>) from the committed counter pass, corrected on its own known byte count; a transform is two passes at this size",
+                        "binds": False,
+                        "note": "a butterfly is ~306 instructions around a 207-instruction product: the passes are bound by VALU issue "
+                                "(69-76 % of their own instruction floor stand-alone), not by the 64 B per element they move; SURVEY 8d's "
+                                "30 % target assumed a bandwidth-bound kernel.  Timed: eight transforms (forward / inverse, plain / coset) of the "
+                                "unit entry point, canonical in and out, HIP events inside the call"}
+        except Exception as e:
+            roof_ntt = {"error": repr(e)}
 
     out = {
         "metric": "Groth16 proofs/sec (rs256-sd-shaped circuit, BN254), G1 MSM scalar-adds/sec reported alongside",
@@ -562,7 +767,8 @@ def main():
                                "matrices_GB": round(info["matrix_bytes"] / 1e9, 3),
                                "window_bits": info["window_bits"], "tuned": bool(info["tuned"]),
                                "retune_skipped_for_memory": info["retune_skipped_for_memory"]}},
-        "roofline": roof, "roofline_valu": roof_valu, "phase_ms": phases,
+        "roofline": roof, "roofline_valu": roof_valu, "roofline_ntt": roof_ntt, "phase_ms": phases,
+        "latency_ms": timing.get("latency_ms"),
         "phase_ms_note": "one proof ALONE on this throughput context, whose proofs run their kernels back to back on one stream each (the "
                          "overlap comes from the other proofs in flight); a latency context (proof_slots = 1) spreads a proof over five "
                          "streams: 6.3 ms (profiles/r03_l_shard_latency.txt)",
@@ -570,6 +776,15 @@ def main():
         "entries_g1": tm["entries_g1"], "entries_g2": tm["entries_g2"],
         "g1_msm_scalar_adds_per_s": round(g1_pairs * value, 1),      # pairs consumed per second of whole-job time
     }
+
+    legs_s = {}                 # wall seconds of every leg after the headline (the default run has to finish within minutes)
+    out["legs_s"] = legs_s
+    t_leg = [time.perf_counter()]
+
+    def leg_done(name):
+        now_ = time.perf_counter()
+        legs_s[name] = round(now_ - t_leg[0], 1)
+        t_leg[0] = now_
 
     # ---- checker, first part (rank 0, any N): the reference's acceptance criterion on a proof of the TIMED stream --------
     # (the oracle is the checker here, never the thing measured; ~1.5 s of Python pairing)
@@ -591,12 +806,14 @@ def main():
             out["proof_verifies"] = None
             out["proof_checked"] = {"error": repr(e)}
         assert out["proof_verifies"] is not False, "a proof of the timed stream does not verify"
+    leg_done("proof_check")
 
     # N > 1: the secondary legs below run collectives on a path that no multi-GPU box has exercised before the driver's own
     # run.  Should one of them stall (a rank that failed alone leaves the others in a barrier), the headline measured above
     # must not be lost with it: after --leg-timeout seconds rank 0 prints the line as it stands here, marked `incomplete`,
-    # and every rank leaves - with exit code 0 by default, because a non-zero rank makes the launcher (and whoever runs it)
-    # discard the line that was just printed; --strict-exit turns that into exit code 4.
+    # and leaves with exit code 0; every other rank leaves five seconds later with exit code 4, so the launcher - and this
+    # script when it started the ranks itself - returns non-zero: the exit status tells the truth about a run that did not
+    # complete, and the line was on stdout before any rank failed.  (--strict-exit: rank 0 exits 4 too.)
     watchdog = None
     if world > 1 and a.leg_timeout > 0:
         core_line = json.dumps(out)
@@ -606,7 +823,7 @@ def main():
                 note = "secondary legs did not finish within %d s: line printed by the watchdog without them" % a.leg_timeout
                 os.write(stdout_fd, (core_line[:-1] + ', "incomplete": %s}\n' % json.dumps(note)).encode())
             print("[bench] rank %d: watchdog after %d s in the secondary legs" % (rank, a.leg_timeout), file=sys.stderr, flush=True)
-            os._exit(4 if a.strict_exit else 0)
+            os._exit(4 if (a.strict_exit or rank != 0) else 0)
         watchdog = threading.Timer(a.leg_timeout + (0 if rank == 0 else 5), bail)
         watchdog.daemon = True
         watchdog.start()
@@ -658,6 +875,41 @@ def main():
                                      "device_resident_proofs_per_s": round(rates["device"], 3) if "device" in rates else None,
                                      "value_is": a.witness}
 
+    leg_done("host_witness")
+
+    # ---- rate and latency against the number of proofs in flight: what a host sizing `proof_slots` for a latency budget needs
+    # (the reference's server runs one task per credential and a user waits for ONE proof: sample/client_helper/src/main.rs:177-216)
+    if world == 1 and not a.no_latency_curve:
+        try:
+            curve = []
+            pk_ = stream_of(a.witness)
+            for k in (1, 2, 4, 8, 16):
+                if k > inflight:
+                    break
+                n_ = 300
+                lat = []
+                done_ = steady_stream(pk_, n_ + k, k, lat)                  # the first k completions are the ramp
+                rate_ = n_ / (done_[-1] - done_[k - 1])
+                curve.append({"in_flight": k, "proofs": n_, "proofs_per_s": round(rate_, 2),
+                              "latency_ms": percentiles_ms([d for t_, d in lat if t_ > done_[k - 1]])})
+            knee = next((c_["in_flight"] for c_ in curve if c_["proofs_per_s"] >= 0.95 * max(x["proofs_per_s"] for x in curve)), None)
+            out["inflight_curve"] = {"points": curve, "callers": "k host threads on the headline context (%d slots, throughput arrangement), witness "
+                                     "from %s memory" % (inflight, a.witness),
+                                     "in_flight_for_95_pct_of_the_best_rate": knee}
+        except Exception as e:
+            out["inflight_curve"] = {"error": repr(e)}
+        leg_done("inflight_curve")
+
+    # ---- the reference's own call, cold: files -> client_state.bin in a fresh process (creds/src/lib.rs:255-301) -------------
+    if rank == 0 and world == 1 and not a.no_cold_start:
+        try:
+            out["cold_start"] = cold_start_record(cc, a, pk, cm, w_np, l, m, M, fresh_rs, prover, ws_dev, log)
+        except AssertionError:
+            raise
+        except Exception as e:
+            out["cold_start"] = {"error": repr(e)}
+        leg_done("cold_start")
+
     # ---- N > 1: proofs sharded over the ranks (config 4), measured in the same run -------------------------------------
     if world > 1 and not a.no_sharded:
         if rank == a.stall_rank:
@@ -675,19 +927,37 @@ def main():
                 sh["backend_fallback"] = used
                 log("sharded leg: %s -> falling back to %s" % (sh["error"], used))
             srng = random.Random(99)                     # the same (r, s) on every rank
+            # The sharded proofs are made on config 4's own circuit - mdl1, S22 (BASELINE.json configs[3]: "mdl1 ... MSM sharded
+            # across 8 x MI355X") - unless the run was given a shape; `value` above stays the replica rate of the headline shape.
+            # (Config 5's shape, rs256-db, is the headline's with l = 28 instead of 26: two more of 1.5 M wires move from the l
+            # query to gamma_abc, which no kernel's time can tell apart - its replica rate IS `value`.)
+            if a.sharded_shape != a.shape:
+                ls_, ms_, Ms_ = wl.SHAPES[a.sharded_shape]
+                t_w = time.time()
+                cm_s, w_s_np, pk_s = make_workload(a.bits, 5, (ls_, ms_, Ms_))
+                ws_s = [torch.from_numpy(x).to(dev) for x in permuted_assignments(w_s_np, ls_, 2, 9)]
+                ref_s = cc.Prover(pk_s, cm_s, device=local_rank, window_bits=a.window, h_coefficient_basis=a.h_coefficient_basis)
+                log("sharded leg: %s workload made and loaded in %.1fs" % (a.sharded_shape, time.time() - t_w))
+            else:
+                ls_, ms_, Ms_ = l, m, M
+                cm_s, pk_s, ws_s, ref_s = cm, pk, ws_dev, prover
+            same_shape = a.sharded_shape == a.shape
+            sh["config"] = {"workload": "%s shape: D=2^%d, m=%d, M=%d, l=%d, nnz=%d (%s mix); bit_fraction=%.2f" %
+                            (a.sharded_shape, ref_s.domain_size.bit_length() - 1, ms_, Ms_, ls_, cm_s.a.nnz + cm_s.b.nnz + cm_s.c.nnz, a.profile, a.bits),
+                            "is": "BASELINE.json configs[3] (mdl1 sharded over the ranks)" if a.sharded_shape == "mdl1" else "the shape given with --shape / --sharded-shape"}
             kfl = max(1, a.sharded_inflight)
             # one proof at a time: a latency context (five streams); several in flight: a throughput context with kfl slots
-            sp_ctx = cc.Prover(pk, cm, device=local_rank, window_bits=a.window, shard_rank=rank, shard_count=world,
+            sp_ctx = cc.Prover(pk_s, cm_s, device=local_rank, window_bits=a.window, shard_rank=rank, shard_count=world,
                                h_coefficient_basis=a.h_coefficient_basis)
             sp = ShardedProver(sp_ctx, dev, group=grp)
             for _ in range(3):
-                sp.prove_dev(ws_dev[0].data_ptr(), srng.randrange(R), srng.randrange(R))
+                sp.prove_dev(ws_s[0].data_ptr(), srng.randrange(R), srng.randrange(R))
             barrier_sync(world)
             gathers0 = sp.all_gathers
             sp.reset_breakdown()
             t_start = time.perf_counter()
             for k in range(a.sharded_steps):
-                sp.prove_dev(ws_dev[k % len(ws_dev)].data_ptr(), srng.randrange(R), srng.randrange(R))
+                sp.prove_dev(ws_s[k % len(ws_s)].data_ptr(), srng.randrange(R), srng.randrange(R))
             torch.cuda.synchronize()
             barrier_sync(world)
             ds = max_over_ranks(time.perf_counter() - t_start, world)
@@ -701,14 +971,14 @@ def main():
                 if turn == rank:
                     t1 = time.perf_counter()
                     for k in range(5):
-                        sp_ctx.prove_partial(ws_dev[k % len(ws_dev)].data_ptr(), srng.randrange(R), on_device=True)
+                        sp_ctx.prove_partial(ws_s[k % len(ws_s)].data_ptr(), srng.randrange(R), on_device=True)
                     alone = (time.perf_counter() - t1) / 5 * 1e3
             barrier_sync(world)
             alone_max = max_over_ranks(alone, world)
             # every rank assembled the same bytes as the unsharded context does
             r_, s_ = srng.randrange(R), srng.randrange(R)
-            want = prover.prove_dev(ws_dev[0].data_ptr(), r_, s_).data
-            same = sp.prove_dev(ws_dev[0].data_ptr(), r_, s_).data == want
+            want = ref_s.prove_dev(ws_s[0].data_ptr(), r_, s_).data
+            same = sp.prove_dev(ws_s[0].data_ptr(), r_, s_).data == want
             sh.update({"mode": "l/a/b queries range-sharded over the ranks, the h query by coset points j = rank (mod ranks) (two of a "
                                "shard's four transforms shrink by the rank count); 5 partial points per rank and proof",
                        "proofs": a.sharded_steps, "proofs_in_flight": 1,
@@ -723,27 +993,27 @@ def main():
             # the D/N-element slices, and the ranks prove with them (cg_prove_partial_q; ranks != 0 hold no witness-map memory)
             if not a.h_coefficient_basis:
                 try:
-                    sc_ctx = cc.Prover(pk, cm, device=local_rank, window_bits=a.window, shard_rank=rank, shard_count=world,
+                    sc_ctx = cc.Prover(pk_s, cm_s, device=local_rank, window_bits=a.window, shard_rank=rank, shard_count=world,
                                        h_scalars_external=(rank != 0))
                     sps = ShardedProver(sc_ctx, dev, group=grp, arrangement="scatter")
                     for _ in range(3):
-                        sps.prove_dev(ws_dev[0].data_ptr(), srng.randrange(R), srng.randrange(R))
+                        sps.prove_dev(ws_s[0].data_ptr(), srng.randrange(R), srng.randrange(R))
                     barrier_sync(world)
                     sps.reset_breakdown()
                     c0 = (sps.scatters, sps.all_gathers)
                     t_start = time.perf_counter()
                     for k in range(a.sharded_steps):
-                        sps.prove_dev(ws_dev[k % len(ws_dev)].data_ptr(), srng.randrange(R), srng.randrange(R))
+                        sps.prove_dev(ws_s[k % len(ws_s)].data_ptr(), srng.randrange(R), srng.randrange(R))
                     torch.cuda.synchronize()
                     barrier_sync(world)
                     dsc = max_over_ranks(time.perf_counter() - t_start, world)
                     r_, s_ = srng.randrange(R), srng.randrange(R)
-                    same_s = sps.prove_dev(ws_dev[0].data_ptr(), r_, s_).data == prover.prove_dev(ws_dev[0].data_ptr(), r_, s_).data
+                    same_s = sps.prove_dev(ws_s[0].data_ptr(), r_, s_).data == ref_s.prove_dev(ws_s[0].data_ptr(), r_, s_).data
                     sh["arrangements"] = {
                         "recompute": {"ms_per_proof": sh["ms_per_proof"], "collectives_per_proof": 1,
                                       "what": "every rank runs the witness map for its own h points (two full-size + two 1/N-size transforms)"},
                         "scatter": {"ms_per_proof": round(dsc / a.sharded_steps * 1e3, 3), "collectives_per_proof": 2,
-                                    "scatter_bytes_per_peer": int(prover.domain_size * 32 // world),
+                                    "scatter_bytes_per_peer": int(ref_s.domain_size * 32 // world),
                                     "scatters": sps.scatters - 1 - c0[0], "all_gathers": sps.all_gathers - 1 - c0[1],
                                     "ms_breakdown_rank0": sps.breakdown_ms(), "bytes_identical_to_unsharded": bool(same_s),
                                     "what": "rank 0 runs the witness map once (four full-size transforms), scatters the coset values, "
@@ -758,11 +1028,11 @@ def main():
             # sample/client_helper/src/main.rs:177-216): partial sums of proofs k+1.. on the GPU while proof k's record is
             # exchanged and finished
             if kfl > 1:
-                pp_ctx = cc.Prover(pk, cm, device=local_rank, window_bits=a.window, shard_rank=rank, shard_count=world,
+                pp_ctx = cc.Prover(pk_s, cm_s, device=local_rank, window_bits=a.window, shard_rank=rank, shard_count=world,
                                    proof_slots=kfl, h_coefficient_basis=a.h_coefficient_basis)
                 pp = ShardedProver(pp_ctx, dev, group=grp)
                 njobs = max(4 * kfl, a.sharded_stream)
-                mk = lambda n_: [(ws_dev[k % len(ws_dev)].data_ptr(), srng.randrange(R), srng.randrange(R)) for k in range(n_)]
+                mk = lambda n_: [(ws_s[k % len(ws_s)].data_ptr(), srng.randrange(R), srng.randrange(R)) for k in range(n_)]
                 pp.prove_stream(mk(2 * kfl), kfl)              # first proofs + the one-time re-tune
                 barrier_sync(world)
                 jobs = mk(njobs)
@@ -776,9 +1046,9 @@ def main():
                 skip = kfl                                     # the ramp-up: the first kfl completions
                 win = max_over_ranks(times[-1] - times[skip - 1], world)
                 rate = (njobs - skip) / win
-                same_p = proofs[0] is not None and proofs[0].data == prover.prove_dev(jobs[0][0], jobs[0][1], jobs[0][2]).data
+                same_p = proofs[0] is not None and proofs[0].data == ref_s.prove_dev(jobs[0][0], jobs[0][1], jobs[0][2]).data
                 sh["in_flight"] = {"proofs_in_flight": kfl, "proofs": njobs, "proofs_per_s": round(rate, 3),
-                                   "ms_per_proof": round(1e3 / rate, 3), "over_replica_rate_of_the_same_ranks": round(rate / value, 4),
+                                   "ms_per_proof": round(1e3 / rate, 3), "over_replica_rate_of_the_same_ranks": round(rate / value, 4) if same_shape else None,
                                    "ms_breakdown_rank0": pp.breakdown_ms(), "all_gathers": pp.all_gathers - g0,
                                    "bytes_identical_to_unsharded": bool(same_p),
                                    "note": "every shard repeats the two sparse products and the two full-size inverse transforms of the "
@@ -802,10 +1072,10 @@ def main():
                         times_s.sort()
                         win_s = max_over_ranks(times_s[-1] - times_s[skip - 1], world)
                         rate_s = (njobs - skip) / win_s
-                        same_s2 = proofs_s[0] is not None and proofs_s[0].data == prover.prove_dev(jobs_s[0][0], jobs_s[0][1], jobs_s[0][2]).data
+                        same_s2 = proofs_s[0] is not None and proofs_s[0].data == ref_s.prove_dev(jobs_s[0][0], jobs_s[0][1], jobs_s[0][2]).data
                         sh["in_flight"]["scatter_rotating"] = {
                             "proofs_per_s": round(rate_s, 3), "ms_per_proof": round(1e3 / rate_s, 3),
-                            "over_replica_rate_of_the_same_ranks": round(rate_s / value, 4), "over_recompute_in_flight": round(rate_s / rate, 4),
+                            "over_replica_rate_of_the_same_ranks": round(rate_s / value, 4) if same_shape else None, "over_recompute_in_flight": round(rate_s / rate, 4),
                             "scatters": pps.scatters - s0_, "all_gathers": pps.all_gathers - g0_, "ms_breakdown_rank0": pps.breakdown_ms(),
                             "bytes_identical_to_unsharded": bool(same_s2),
                             "note": "one full witness map per proof on rank (job mod ranks) instead of a partial one on every rank"}
@@ -815,11 +1085,14 @@ def main():
                     except Exception as e:
                         sh["in_flight"]["scatter_rotating"] = {"error": repr(e)}
                 pp_ctx.close()
+            if ref_s is not prover:
+                ref_s.close()
         except AssertionError:
             raise
         except Exception as e:     # the throughput value above stands on its own: report the failure instead of losing the line
             sh["error"] = (sh.get("error", "") + " | " if sh.get("error") else "") + repr(e)
         out["sharded"] = sh
+        leg_done("sharded")
 
     # ---- N = 1 diagnostic: one proof over k sharded contexts on this one GPU, shard by shard ----------------
     if world == 1 and a.shard_sim > 1:
@@ -866,6 +1139,7 @@ def main():
             raise
         except Exception as e:
             out["key_check"] = {"ok": None, "error": repr(e)}
+        leg_done("key_check")
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
@@ -915,6 +1189,13 @@ def main():
                                                "proof_bytes_identical_to_gpu": bool(same8)}},
                 "cpu_quota": cpu_ref.cpu_quota() if cpu_ref.cpu_quota() != float("inf") else None,
                 "gpu_over_cpu": round(value / (1.0 / ctm["total_s"]), 1)}
+            if isinstance(out.get("cold_start"), dict) and "cpu_chain" in out["cold_start"]:
+                cch = out["cold_start"]["cpu_chain"]
+                cch["key_decode_s"] = round(ctm["load_s"], 3)
+                cch["groth16_prove_s"] = round(ctm["total_s"], 3)
+                cch["total_s"] = round(cch["reading_r1cs_s"] + cch["reading_prover_params_s"] + ctm["load_s"] + ctm["total_s"], 3)
+                cch["threads"] = threads
+                out["cold_start"]["gpu_over_cpu_cold"] = round(cch["total_s"] / out["cold_start"]["total_s"], 1)
             # no published number exists for this metric (none in the tree); the only baseline there is is
             # this same-run CPU restatement, and the ratio to it is what the field carries - named for what it is
             out["vs_baseline"] = out["cpu_baseline"]["gpu_over_cpu"]
@@ -924,6 +1205,50 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
             if isinstance(e, AssertionError):
                 raise
+
+    leg_done("cpu_baseline")
+
+    # ---- the second shape of SURVEY 8d's table ("S21 with l = 26 AND S22 ... report both"): mdl1, D = 2^22, measured as the
+    # headline is (witness in pageable host memory, sixteen proofs in flight, steady state) over >= 300 proofs ------------------
+    if rank == 0 and world == 1 and not a.no_shapes and a.shape != "mdl1":
+        prover.close()
+        try:
+            t_w = time.time()
+            l2, m2, M2 = wl.SHAPES["mdl1"]
+            cm2, w2, pk2 = make_workload(a.bits, 5, (l2, m2, M2))
+            p2 = cc.Prover(pk2, cm2, device=local_rank, window_bits=a.window, proof_slots=inflight, h_coefficient_basis=a.h_coefficient_basis)
+            ws2 = permuted_assignments(w2, l2, 2, 9)
+            made_s = time.time() - t_w
+
+            def prove2_k(k, p2=p2, ws2=ws2):
+                p2.prove_host_ptr(ws2[k % len(ws2)].ctypes.data, *fresh_rs())
+            prime(prove2_k)
+            d2, rec2, _ = measure(prove2_k, 100, inflight, 3, False, threads=inflight + 2)
+            w2d = torch.from_numpy(ws2[0]).to(dev)
+            tm2, ph2 = phase_record(p2, w2d, reps=2)
+            r_, s_ = fresh_rs()
+            same2 = p2.prove_host_ptr(ws2[0].ctypes.data, r_, s_).data == p2.prove_dev(w2d.data_ptr(), r_, s_).data
+            info2 = p2.info()
+            out["shapes"] = {"mdl1": {
+                "workload": "mdl1 shape: D=2^%d, m=%d, M=%d, l=%d, nnz=%d (%s mix); bit_fraction=%.2f; pk from seeded trapdoor (GPU setup)" %
+                            (p2.domain_size.bit_length() - 1, m2, M2, l2, cm2.a.nnz + cm2.b.nnz + cm2.c.nnz, a.profile, a.bits),
+                "proofs_per_s": round(300 / d2, 3), "ms_per_step": round(d2 / 300 * 1e3, 4), "window_proofs": rec2["window_proofs"],
+                "block_spread_pct": rec2["median_block"]["spread_pct"], "latency_ms": rec2["latency_ms"],
+                "witness_origin": "host (pageable): %d-byte assignments through cg_prove, 2 in rotation, (r, s) fresh per proof" % int(ws2[0].size),
+                "proofs_in_flight": inflight, "msm_g1_pairs_per_proof": tm2["msm_g1_pairs"], "entries_g1": tm2["entries_g1"],
+                "g1_msm_scalar_adds_per_s": round(tm2["msm_g1_pairs"] * 300 / d2, 1), "phase_ms_one_proof_alone": ph2,
+                "resident_GB": round(info2["total_bytes"] / 1e9, 2), "window_bits": info2["window_bits"], "tuned": bool(info2["tuned"]),
+                "host_and_device_witness_give_the_same_bytes": bool(same2), "workload_and_key_made_and_loaded_in_s": round(made_s, 1),
+                "is": "SURVEY 8d config 3's second instance / config 4's circuit on one GPU"}}
+            log("mdl1 (S22): %.2f proofs/s over %d proofs" % (300 / d2, rec2["window_proofs"]))
+            assert same2, "mdl1: host-witness and device-resident proofs differ"
+            p2.close()
+            del w2d
+        except AssertionError:
+            raise
+        except Exception as e:
+            out["shapes"] = {"mdl1": {"error": repr(e)}}
+        leg_done("shapes_mdl1")
 
     # ---- secondary: the same measurement over the share of bit wires (the headline's one assumption) --------------------
     if rank == 0 and world == 1 and not a.no_sweep:
@@ -957,6 +1282,7 @@ def main():
         u = [x for x in sweep if x["bit_fraction"] == 0.0]
         if u:
             out["g1_msm_scalar_adds_per_s_uniform_scalars"] = u[0]["g1_msm_scalar_adds_per_s"]   # SURVEY §8d's definition
+        leg_done("witness_sweep")
 
     if watchdog:
         watchdog.cancel()

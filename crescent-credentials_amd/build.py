@@ -157,6 +157,41 @@ def build(verbose: bool = False, jobs: int = int(os.environ.get("CG_BUILD_JOBS",
     return LIB
 
 
+UBENCH_SRC = os.path.join(HERE, "..", "tools", "ubench", "valu_rates.hip")
+UBENCH_BIN = os.path.join(HERE, "..", "tools", "ubench", "valu_rates")
+
+
+def build_ubench(verbose: bool = False) -> str:
+    """tools/ubench/valu_rates: the VALU issue-rate micro-benchmark bench.py runs (--json) to price `roofline_valu` in SIMD
+    cycles measured on the box it runs on"""
+    if not os.path.exists(UBENCH_BIN) or os.path.getmtime(UBENCH_BIN) < max(os.path.getmtime(UBENCH_SRC), _newest_header()):
+        if verbose:
+            print("[build] compiling tools/ubench/valu_rates", file=sys.stderr)
+        r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O2", "-o", UBENCH_BIN, UBENCH_SRC], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("valu_rates build failed:\n" + r.stderr[-4000:])
+    return UBENCH_BIN
+
+
+def write_isa_class_counts(verbose: bool = False) -> str:
+    """profiles/isa_class_counts.json: per-kernel static VALU instruction-class counts from the code objects of the library
+    just built (tools/isa_mix.py), stamped with the source fingerprint; rewritten only when the fingerprint changed"""
+    import json
+    out = os.path.join(HERE, "..", "profiles", "isa_class_counts.json")
+    try:
+        with open(out) as f:
+            if json.load(f).get("csrc_sha16") == source_fingerprint():
+                return out
+    except Exception:
+        pass
+    r = subprocess.run([sys.executable, os.path.join(HERE, "..", "tools", "isa_mix.py"), LIB, out], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("tools/isa_mix.py failed:\n" + (r.stdout + r.stderr)[-3000:])
+    if verbose:
+        print("[build]", r.stdout.strip().splitlines()[0], file=sys.stderr)
+    return out
+
+
 if __name__ == "__main__":
     print(build(verbose=True))
     if "--tuning" in sys.argv[1:]:

@@ -14,6 +14,7 @@
 
 #include "../../include/crescent_gpu.h"
 #include "curve.hpp"
+#include "errors.hpp"
 
 namespace cg {
 
@@ -21,10 +22,6 @@ namespace cg {
 std::string& last_error();
 int fail(int code, const char* fmt, ...);
 
-struct HipError : std::runtime_error {
-    int code;
-    HipError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
-};
 
 #define CG_HIP(expr)                                                                              \
     do {                                                                                          \

@@ -2,7 +2,6 @@
 // (twiddles, coset powers, vanishing-polynomial inverse) of ark-poly's radix-2 domain as driven by
 // forks/groth16/src/r1cs_to_qap.rs:150-213, the CSR upload with its coefficient dictionary, and the
 // saturated sparse product used by cg_setup.  The transforms themselves run on 29-bit limbs: csrc/wmap29.hip.
-#include <unordered_map>
 
 #include "ntt.hpp"
 
@@ -138,154 +137,39 @@ void csr_transpose(const cg_csr& m, uint64_t rows, uint64_t cols, HostCsc& out) 
 
 
 void DevCsr::upload(const cg_csr& m, uint64_t rows_, uint64_t num_variables, hipStream_t st, bool sliced) {
+    // host side (csr_host.hpp, all host threads): validation, coefficient dictionary, sliced layout
+    static const bool plain = CG_TUNE_ENV("SELL_PLAIN") != nullptr;       // A/B aid (tuning builds): round 2's layout (terms as given, pieces by length)
+    HostCsr h;
+    csr_prepare_host(m, rows_, num_variables, sliced, !plain, h);
     rows = rows_;
     nnz = m.nnz;
-    if (nnz >= (1ull << 32)) throw HipError(CG_ERR_INVALID_ARGUMENT, "matrix with >= 2^32 non-zeros");
-    if (m.row_ptr[0] != 0 || m.row_ptr[rows] != nnz) throw HipError(CG_ERR_INVALID_ARGUMENT, "row_ptr does not span [0, nnz]");
-    std::vector<uint32_t> rp(rows + 1);
-    for (uint64_t i = 0; i <= rows; ++i) {
-        if (i && m.row_ptr[i] < m.row_ptr[i - 1]) throw HipError(CG_ERR_INVALID_ARGUMENT, "row_ptr not monotone");
-        rp[i] = (uint32_t)m.row_ptr[i];
-    }
-    // coefficient dictionary (circom matrices repeat a handful of constants millions of times)
-    struct Key { uint64_t w[4]; bool operator==(const Key& o) const { return !memcmp(w, o.w, 32); } };
-    struct KeyHash { size_t operator()(const Key& k) const { return (size_t)(k.w[0] * 0x9e3779b97f4a7c15ull ^ k.w[1] ^ (k.w[2] << 1) ^ (k.w[3] << 7)); } };
-    std::unordered_map<Key, uint32_t, KeyHash> map;
-    std::vector<Fr> dict_h;
-    std::vector<uint32_t> idx(nnz);
-    {
-        Key one{};
-        one.w[0] = 1;
-        map.emplace(one, 0u);
-        Fr o = Fr::zero(); o.l[0] = 1;
-        dict_h.push_back(o);
-    }
-    for (uint64_t t = 0; t < nnz; ++t) {
-        if (m.col[t] >= num_variables) throw HipError(CG_ERR_INVALID_ARGUMENT, "column index out of range");
-        Key k;
-        memcpy(k.w, m.coeff + 32 * t, 32);
-        auto it = map.find(k);
-        if (it == map.end()) {
-            Fr c = fp_from_bytes<Fr>(m.coeff + 32 * t);
-            if (!fp_is_canonical(c)) throw HipError(CG_ERR_INVALID_ARGUMENT, "non-canonical matrix coefficient");
-            it = map.emplace(k, (uint32_t)dict_h.size()).first;
-            dict_h.push_back(c);
-        }
-        idx[t] = it->second;
-    }
-    for (auto& c : dict_h) c = to_mont(c);
     row_ptr.alloc(rows + 1);
-    {
-        std::vector<uint32_t> lr;
-        for (uint64_t i = 0; i < rows; ++i) if (rp[i + 1] - rp[i] > 4096u) lr.push_back((uint32_t)i);
-        n_long_rows = lr.size();
-        long_rows.alloc(lr.size() ? lr.size() : 1);
-        if (!lr.empty()) h2d_sync(long_rows.p, lr.data(), lr.size() * 4, st);
-    }
+    n_long_rows = h.long_rows.size();
+    long_rows.alloc(h.long_rows.size() ? h.long_rows.size() : 1);
     col.alloc(nnz ? nnz : 1);
     coef_idx.alloc(nnz ? nnz : 1);
-    dict.alloc(dict_h.size());
-    h2d_sync(row_ptr.p, rp.data(), (rows + 1) * 4, st);
-    if (nnz) {
-        h2d_sync(col.p, m.col, nnz * 4, st);
-        h2d_sync(coef_idx.p, idx.data(), nnz * 4, st);
+    dict.alloc(h.dict_mont.size());
+    // the copies go out back to back and are waited for once (the host arrays live until then)
+    auto h2d = [&](void* dst, const void* src, size_t bytes) { if (bytes) CG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st)); };
+    h2d(long_rows.p, h.long_rows.data(), h.long_rows.size() * 4);
+    h2d(row_ptr.p, h.rp.data(), (rows + 1) * 4);
+    h2d(col.p, m.col, nnz * 4);
+    h2d(coef_idx.p, h.idx.p, nnz * 4);
+    h2d(dict.p, h.dict_mont.data(), h.dict_mont.size() * sizeof(Fr));
+    n_sell = (int)h.levels.size();
+    sell_scratch = h.sell_scratch;
+    for (int k = 0; k < n_sell; ++k) {
+        const HostSellLevel& H = h.levels[k];
+        SellLevel& L = sell[k];
+        L.n_pieces = H.n_pieces;
+        L.n_partials = H.n_partials;
+        L.slice_ptr.alloc(H.slice_ptr.size()); L.col.alloc(H.n_slots); L.cidx.alloc(H.n_slots); L.dst.alloc(H.dst.size());
+        h2d(L.slice_ptr.p, H.slice_ptr.data(), H.slice_ptr.size() * 4);
+        h2d(L.col.p, H.col.p, H.n_slots * 4);
+        h2d(L.cidx.p, H.cidx.p, H.n_slots * 4);
+        h2d(L.dst.p, H.dst.p, H.dst.size() * 4);
     }
-    h2d_sync(dict.p, dict_h.data(), dict_h.size() * sizeof(Fr), st);
-    if (sliced) build_sell(rp, m.col, idx, st);
-}
-
-// the sliced layout of ntt.hpp's SellLevel, built on the host once per matrix
-void DevCsr::build_sell(const std::vector<uint32_t>& rp, const uint32_t* col_h, const std::vector<uint32_t>& idx, hipStream_t st) {
-    struct Item { uint32_t row, first, len; };              // a row of the current level: `len` terms from `first`
-    std::vector<uint32_t> cur_col(col_h, col_h + nnz), cur_idx(idx);
-    std::vector<Item> items;
-    items.reserve(rows);
-    for (uint64_t i = 0; i < rows; ++i)
-        if (rp[i + 1] > rp[i]) items.push_back({(uint32_t)i, rp[i], rp[i + 1] - rp[i]});
-    // Inside a row the terms with a coefficient other than one come first (a sum does not care), so a piece is "k
-    // products, then plain additions", and the pieces are sorted by k before they are sliced: the 64 lanes of a slice
-    // then agree on which of their steps multiply.  Circom rows are mostly unit coefficients with the powers of two
-    // concentrated in the adder rows (gate mix: 82 % of A's rows carry no other coefficient at all), and a wave pays the
-    // 207-instruction product at every step at which ANY of its lanes needs it.
-    static const bool plain = CG_TUNE_ENV("SELL_PLAIN") != nullptr;       // A/B aid (tuning builds): round 2's layout (terms as given, pieces by length)
-    for (const Item& it : items) {
-        if (plain) break;
-        uint32_t w = it.first;
-        for (uint32_t t = it.first; t < it.first + it.len; ++t)
-            if (cur_idx[t] != 0) {
-                std::swap(cur_idx[t], cur_idx[w]);
-                std::swap(cur_col[t], cur_col[w]);
-                ++w;
-            }
-    }
-    n_sell = 0;
-    sell_scratch = 0;
-    while (!items.empty()) {
-        if (n_sell >= 8) throw HipError(CG_ERR_INVALID_ARGUMENT, "matrix row too long for the sliced layout");
-        SellLevel& L = sell[n_sell++];
-        struct Piece { uint32_t first, len, dst; };
-        std::vector<Piece> pieces;
-        std::vector<Item> next_items;
-        std::vector<uint32_t> next_col;
-        uint32_t partials = 0;
-        for (const Item& it : items) {
-            const uint32_t np = (it.len + SELL_PIECE - 1) / SELL_PIECE;
-            if (np == 1) {
-                pieces.push_back({it.first, it.len, it.row | SELL_FINAL});
-                continue;
-            }
-            next_items.push_back({it.row, (uint32_t)next_col.size(), np});
-            for (uint32_t k = 0; k < np; ++k) {
-                const uint32_t b = it.first + k * SELL_PIECE;
-                const uint32_t l = it.len - k * SELL_PIECE < SELL_PIECE ? it.len - k * SELL_PIECE : SELL_PIECE;
-                pieces.push_back({b, l, partials});
-                next_col.push_back(partials++);
-            }
-        }
-        // most products first, then longest first: a slice holds pieces of (nearly) one shape
-        auto products_of = [&](const Piece& p) {
-            uint32_t k = 0;
-            if (plain) return k;
-            for (uint32_t t = 0; t < p.len; ++t) k += cur_idx[p.first + t] != 0;
-            return k;
-        };
-        constexpr uint32_t NK = (SELL_PIECE + 1) * (SELL_PIECE + 1);
-        auto key_of = [&](const Piece& p) { return (SELL_PIECE - products_of(p)) * (SELL_PIECE + 1) + (SELL_PIECE - p.len); };
-        std::vector<uint32_t> start(NK + 1, 0);
-        for (const Piece& p : pieces) start[key_of(p) + 1]++;
-        for (uint32_t k = 0; k < NK; ++k) start[k + 1] += start[k];
-        std::vector<Piece> sorted(pieces.size());
-        for (const Piece& p : pieces) sorted[start[key_of(p)]++] = p;
-        const uint32_t np = (uint32_t)sorted.size(), ns = (np + 63) / 64;
-        std::vector<uint32_t> sp(ns + 1, 0), dst(np);
-        for (uint32_t s = 0; s < ns; ++s) {
-            uint32_t longest = 0;
-            for (uint32_t p = s * 64; p < np && p < (s + 1) * 64; ++p) longest = std::max(longest, sorted[p].len);
-            sp[s + 1] = sp[s] + 64 * longest;
-        }
-        std::vector<uint32_t> lc(sp[ns] ? sp[ns] : 1, 0), li(sp[ns] ? sp[ns] : 1, SELL_PAD);
-        for (uint32_t p = 0; p < np; ++p) {
-            const Piece& pc = sorted[p];
-            dst[p] = pc.dst;
-            const uint32_t base = sp[p / 64] + (p & 63);
-            for (uint32_t t = 0; t < pc.len; ++t) {
-                lc[base + t * 64] = cur_col[pc.first + t];
-                li[base + t * 64] = cur_idx[pc.first + t];
-            }
-        }
-        L.n_pieces = np;
-        L.n_partials = partials;
-        if (partials > sell_scratch) sell_scratch = partials;
-        L.slice_ptr.alloc(ns + 1); L.col.alloc(lc.size()); L.cidx.alloc(li.size()); L.dst.alloc(np ? np : 1);
-        h2d_sync(L.slice_ptr.p, sp.data(), (ns + 1) * 4, st);
-        h2d_sync(L.col.p, lc.data(), lc.size() * 4, st);
-        h2d_sync(L.cidx.p, li.data(), li.size() * 4, st);
-        if (np) h2d_sync(L.dst.p, dst.data(), np * 4, st);
-        // the next level sums the partials: unit coefficients over this level's scratch vector
-        items.swap(next_items);
-        cur_col.swap(next_col);
-        cur_idx.assign(cur_col.size(), 0u);
-    }
+    CG_HIP(hipStreamSynchronize(st));
 }
 
 static constexpr uint32_t SPMV_LONG_ROW = 4096;

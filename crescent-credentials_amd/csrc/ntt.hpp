@@ -3,6 +3,7 @@
 // (internal C++ interface).  The transforms run on 29-bit limbs (wmap29.hpp).
 #pragma once
 #include "common.hpp"
+#include "csr_host.hpp"
 
 namespace cg {
 
@@ -25,15 +26,7 @@ Fr fr_root_of_unity(int logn);  // primitive 2^logn-th root, = 5^((r-1)/2^28) ^ 
 // out[p] = scale * base^(bitrev ? rev(p) : p), p < n (Montgomery form)
 void fr_pow_table(Fr* out, const Fr& base, const Fr& scale, uint64_t n, bool bitrev, int logn, hipStream_t st);
 
-// One level of the sliced layout the prove path's sparse product runs on (wmap29.hip k_sell29).  A row is cut into
-// PIECES of at most SELL_PIECE terms; a lane takes one piece, so no lane walks more than SELL_PIECE terms however long
-// the row is (circom's substituted adder rows carry hundreds of terms).  Pieces are sorted by length and stored in
-// slices of 64 with the terms of a slice interleaved (term t of the 64 pieces side by side): the index loads of a
-// wave are contiguous.  A row of one piece is finished by that piece; the pieces of a longer row leave partial sums
-// in a scratch vector and the row becomes a row of the next level, whose "terms" are those partial sums.
-static constexpr uint32_t SELL_PIECE = 8;
-static constexpr uint32_t SELL_FINAL = 0x80000000u;    // dst flag: the piece is its row's only piece; low bits = row
-static constexpr uint32_t SELL_PAD = 0xffffffffu;      // coefficient index of a padding slot
+// (the sliced layout and its constants are described in csr_host.hpp, which prepares it on the host)
 struct SellLevel {
     uint32_t n_pieces = 0, n_partials = 0;   // partials written to the scratch vector by this level
     DevBuf<uint32_t> slice_ptr;  // n_slices + 1 slot offsets (multiples of 64)
@@ -58,7 +51,6 @@ struct DevCsr {
     // sliced = false: skip the sliced layout (the generator's transposed matrices only run the saturated product)
     // st: the loader's stream (the host arrays are copied on it and waited for)
     void upload(const cg_csr& m, uint64_t rows, uint64_t num_variables, hipStream_t st, bool sliced = true);
-    void build_sell(const std::vector<uint32_t>& rp, const uint32_t* col_h, const std::vector<uint32_t>& idx, hipStream_t st);
 };
 // host-side transpose of a CSR view (rows x cols): CSR of the transpose, terms of one column kept in row order
 struct HostCsc {

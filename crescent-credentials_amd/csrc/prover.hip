@@ -545,6 +545,14 @@ static void staged_worker(cg_ctx* c) {
             }
             return msm_default_window(n ? n : 1, true);
         };
+        // The FIRST proof goes first.  A host that loads and proves once (create_client_state) is waiting for exactly that
+        // proof, and the change of basis below fills every wave slot of the chip for seconds: started at once it triples the
+        // first proof's time (70-85 ms against ~25 alone at the rs256 size).  So the worker lets the first warm-up proof
+        // finish - or a tenth of a second pass without one, for a host that loads now and proves later - and only then starts.
+        for (int waited = 0; waited < 100 && c->warmup_proofs.load() == 0; ++waited) {
+            stop();
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
         {
             AllocScope booking(&table_bytes);
             ScopedStream st;
@@ -599,12 +607,17 @@ static void staged_worker(cg_ctx* c) {
                 std::lock_guard<std::mutex> pl(c->pick_mu);
                 c->pick_cv.notify_all();
             }
+            // The warm-up slots and row-0 tables are released HERE, while the gate is held: hipFree waits for the whole
+            // device, and with callers proving back to back each of the ~150 releases would wait for - and stall - the
+            // pipeline in turn (9 s of them measured behind a sixteen-slot context under four callers).  With the gate held
+            // nothing is in flight and they take microseconds each.
+            slots.clear();
+            bh = MsmBases<Fq>(); bl = MsmBases<Fq>(); ba = MsmBases<Fq>(); bb1 = MsmBases<Fq>(); bb2 = MsmBases<Fq2>();
+            std::vector<uint64_t>().swap(c->c_transposed.ptr);
+            std::vector<uint32_t>().swap(c->c_transposed.row);
+            std::vector<uint8_t>().swap(c->c_transposed.coeff);
         }
-        std::vector<uint64_t>().swap(c->c_transposed.ptr);
-        std::vector<uint32_t>().swap(c->c_transposed.row);
-        std::vector<uint8_t>().swap(c->c_transposed.coeff);
         done = true;
-        // (the warm-up slots and row-0 tables go here, with this scope: hipFree waits for the device, not for the gate)
     } catch (const WorkerCancelled&) {
         status = 0;
     } catch (...) {
@@ -690,28 +703,28 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         ScopedStream s0_guard;
         const hipStream_t s0 = s0_guard;
         const uint32_t form = pk->coord_form;
-        // ---- the three matrices on host threads of their own (validation, coefficient dictionary, sliced layout: host
-        // work, 17 M terms at the rs256 size), next to the key on this thread.  Every thread books what it leaves resident.
+        // ---- the three matrices on a host thread of their own (validation, coefficient dictionary, sliced layout: host work
+        // over 17 M terms at the rs256 size, every pass of it on all host threads - csr_host.hpp), next to the key on this
+        // thread.  Every thread books what it leaves resident.
         struct MatJob { std::exception_ptr err; int64_t bytes = 0; float ms = 0.f; } mj[4];
         DevCsr* mats[3] = {&c->A, &c->B, &c->C};
         cg_ctx* cp = c.get();
         {
             JoinAll jobs;
-            for (int k = 0; k < 3; ++k)
-                jobs.th.emplace_back([&, k] {
-                    try {
-                        const auto t = std::chrono::steady_clock::now();
-                        CG_HIP(hipSetDevice(dev));
-                        AllocScope booking(&mj[k].bytes);
-                        ScopedStream st;
-                        // validates the CSR view (monotone row_ptr, column range, canonical coefficients); a context that
-                        // never runs the witness map skips the sliced layout
-                        mats[k]->upload(abc[k], m, M, st, !cp->external_q);
-                        mj[k].ms = ms_since(t);
-                    } catch (...) {
-                        mj[k].err = std::current_exception();
-                    }
-                });
+            jobs.th.emplace_back([&] {
+                try {
+                    const auto t = std::chrono::steady_clock::now();
+                    CG_HIP(hipSetDevice(dev));
+                    AllocScope booking(&mj[0].bytes);
+                    ScopedStream st;
+                    // validates the CSR views (monotone row_ptr, column range, canonical coefficients); a context that
+                    // never runs the witness map skips the sliced layout
+                    for (int k = 0; k < 3; ++k) mats[k]->upload(abc[k], m, M, st, !cp->external_q);
+                    mj[0].ms = ms_since(t);
+                } catch (...) {
+                    mj[0].err = std::current_exception();
+                }
+            });
             if (staged)      // C^T for the fold, made now: the worker must not read the caller's arrays after this call returns
                 jobs.th.emplace_back([&] {
                     try {

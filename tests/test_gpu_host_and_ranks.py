@@ -450,14 +450,19 @@ def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
     assert len(d["value_per_rank"]) == 2 and abs(sum(d["value_per_rank"]) - d["value"]) < 0.35 * d["value"]
     assert d["proof_verifies"] is True and d["key_check"]["ok"] is True and d["key_check"]["proof_equals_trapdoor_closed_form"] is True
     assert d["timing"]["window_proofs"] == 36 and abs(d["ms_per_step"] * d["value"] / 2 - 1000.0) < 1.0
+    assert "medium shape" in sh["config"]["workload"]          # a run that names its shape shards that shape
     # a rank that stops alone inside a secondary leg leaves the others in a barrier: the watchdog prints the headline that
-    # was measured, marked incomplete, and every rank leaves with exit code 0
+    # was measured, marked incomplete - and the exit status says so too: rank 0 leaves with 0 once the line is out, the other
+    # ranks with 4, so the launcher's (and this script's) return code is non-zero AND the line was captured
     run = subprocess.run(cmd + ["--stall-rank", "1", "--leg-timeout", "20"], env=env, capture_output=True, text=True, timeout=1500)
-    assert run.returncode == 0, run.stderr[-3000:]
+    assert run.returncode != 0, run.stderr[-3000:]
     lines = [x for x in run.stdout.splitlines() if x.strip()]
     assert len(lines) == 1, run.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and "sharded" not in d and "watchdog" in d["incomplete"]
+    # tools/line_value.py (every A/B and round-end script reads bench lines through it) refuses such a line
+    chk = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "line_value.py"), "x"], input=run.stdout, capture_output=True, text=True)
+    assert chk.returncode == 3 and "REFUSED" in chk.stdout
     # and with RCCL two ranks cannot share the one GPU: refused up front with a message, not a hang
     if __import__("torch").cuda.device_count() == 1:
         run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=env,
@@ -489,6 +494,27 @@ def test_bench_gpus_8_as_eight_processes_on_the_one_gpu():
     fl = sh["in_flight"]
     assert fl["proofs_in_flight"] == 2 and fl["all_gathers"] == fl["proofs"] == 16 and fl["bytes_identical_to_unsharded"] is True
     assert fl["scatter_rotating"]["bytes_identical_to_unsharded"] is True and fl["scatter_rotating"]["scatters"] == 16
+
+
+def test_bench_gpus_2_without_a_shape_shards_config_4s_own_circuit():
+    """the driver's multi-GPU command carries no --shape: `value` is then the rs256-sd replica rate (the configuration the metric
+    is quoted on) and the SHARDED proofs are made on mdl1 at S22 - BASELINE.json configs[3], "mdl1 ... MSM sharded across 8 x
+    MI355X" - in both arrangements, with the bytes of an unsharded mdl1 context."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "8", "--warmup", "2",
+           "--inflight", "4", "--blocks", "3", "--no-host-witness", "--no-check", "--sharded-steps", "4", "--sharded-inflight", "2",
+           "--sharded-stream", "8", "--leg-timeout", "900"]
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=2400)
+    assert run.returncode == 0, run.stderr[-3000:]
+    d = json.loads([x for x in run.stdout.splitlines() if x.strip()][-1])
+    assert d["n_gpus"] == 2 and "incomplete" not in d and "rs256-sd shape: D=2^21" in d["config"]["workload"]
+    sh = d["sharded"]
+    assert "error" not in sh, sh
+    assert "mdl1 shape: D=2^22, m=2980000, M=3000000, l=21" in sh["config"]["workload"] and "configs[3]" in sh["config"]["is"]
+    assert sh["bytes_identical_to_unsharded"] is True and sh["all_gathers"] == sh["proofs"] == 4
+    assert sh["arrangements"]["scatter"]["bytes_identical_to_unsharded"] is True
+    assert sh["in_flight"]["bytes_identical_to_unsharded"] is True and sh["in_flight"]["scatter_rotating"]["bytes_identical_to_unsharded"] is True
+    assert sh["in_flight"]["over_replica_rate_of_the_same_ranks"] is None      # another shape than `value`'s: no ratio
 
 
 @pytest.mark.skipif(_gpus() != 1, reason="the RCCL failure is provoked by two ranks sharing the one GPU")

@@ -1,9 +1,14 @@
 // Micro-benchmark: issue rate of the integer/FP64 VALU instructions that BN254 limb arithmetic
 // is built from, on gfx950.  Prints wave-instructions per cycle per SIMD (1/cycles-per-instr).
-// Usage: ./valu_rates   (needs a GPU)
+// Usage: ./valu_rates          the round-5 table (wall-clock time, cycles at the nominal clock)
+//        ./valu_rates --json   one JSON line for bench.py: cycles per wave-instruction per SIMD of the three instruction
+//                              classes the prove path's roofline is priced in, measured in SHADER CYCLES on the device
+//                              (clock64 around every wave's own loop), so the figure does not depend on the clock the chip
+//                              happens to hold (needs a GPU; built by __graft_entry__.build())
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
+#include <string.h>
 #include <vector>
 #include "../../crescent-credentials_amd/csrc/field.hpp"
 
@@ -104,6 +109,101 @@ __global__ void __launch_bounds__(256) k_fpmul(F* io, int iters) {
     io[t] = cg::add(cg::add(a, b), cg::add(c, d));
 }
 
+// The same loops timed by every wave itself, in shader cycles.  1024 workgroups of four waves are one wave per SIMD slot
+// four deep on 256 CUs x 4 SIMDs - all resident at once, all issuing the same instruction stream - so a SIMD issues
+// (4 waves x N instructions) in the T cycles a wave sees: cycles per wave-instruction = T / (4 N).
+template <int KIND>
+__global__ void __launch_bounds__(256) k_rate_cycles(uint32_t* out, unsigned long long* cycles, int iters, uint32_t seed) {
+    uint32_t a0 = threadIdx.x + seed, a1 = a0 * 3 + 1, a2 = a0 * 5 + 7, a3 = a0 ^ 0x1234567;
+    uint64_t d0 = a0, d1 = a1, d2 = a2, d3 = a3;
+    const unsigned long long c0 = clock64();
+    for (int i = 0; i < iters; ++i) {
+        if (KIND == 0) {
+            REP64(asm volatile("v_mad_u64_u32 %0, s[10:11], %4, %5, %0\n v_mad_u64_u32 %1, s[10:11], %4, %6, %1\n"
+                               "v_mad_u64_u32 %2, s[10:11], %5, %6, %2\n v_mad_u64_u32 %3, s[10:11], %6, %7, %3\n"
+                               : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "s10", "s11");)
+        } else if (KIND == 1) {
+            REP64(asm volatile("v_mad_i64_i32 %0, s[10:11], %4, %5, %0\n v_mad_i64_i32 %1, s[10:11], %4, %6, %1\n"
+                               "v_mad_i64_i32 %2, s[10:11], %5, %6, %2\n v_mad_i64_i32 %3, s[10:11], %6, %7, %3\n"
+                               : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "s10", "s11");)
+        } else if (KIND == 2) {
+            REP64(asm volatile("v_add_co_u32 %0, vcc, %0, %4\n v_addc_co_u32 %1, vcc, %1, %4, vcc\n v_addc_co_u32 %2, vcc, %2, %4, vcc\n v_addc_co_u32 %3, vcc, %3, %4, vcc\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed) : "vcc");)
+        } else if (KIND == 3) {
+            REP64(asm volatile("v_add3_u32 %0, %0, %4, %1\n v_add3_u32 %1, %1, %4, %2\n v_add3_u32 %2, %2, %4, %3\n v_add3_u32 %3, %3, %4, %0\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed));)
+        } else if (KIND == 4) {
+            REP64(asm volatile("v_lshrrev_b64 %0, 29, %0\n v_lshrrev_b64 %1, 29, %1\n v_lshrrev_b64 %2, 29, %2\n v_lshrrev_b64 %3, 29, %3\n"
+                               : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));)
+        } else if (KIND == 5) {
+            REP64(asm volatile("v_lshl_add_u64 %0, %0, 0, %1\n v_lshl_add_u64 %1, %1, 0, %2\n v_lshl_add_u64 %2, %2, 0, %3\n v_lshl_add_u64 %3, %3, 0, %0\n"
+                               : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));)
+        } else if (KIND == 6) {
+            REP64(asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %0\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+        } else if (KIND == 7) {
+            REP64(asm volatile("v_and_b32 %0, %0, %1\n v_and_b32 %1, %1, %2\n v_and_b32 %2, %2, %3\n v_and_b32 %3, %3, %0\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+        } else if (KIND == 8) {
+            REP64(asm volatile("v_add_u32 %0, %0, %1\n v_add_u32 %1, %1, %2\n v_add_u32 %2, %2, %3\n v_add_u32 %3, %3, %0\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+        } else if (KIND == 9) {
+            REP64(asm volatile("v_lshrrev_b32 %0, 3, %1\n v_lshrrev_b32 %1, 3, %2\n v_lshrrev_b32 %2, 3, %3\n v_lshrrev_b32 %3, 3, %0\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+        }
+    }
+    const unsigned long long c1 = clock64();
+    if ((threadIdx.x & 63) == 0) cycles[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = c1 - c0;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + (uint32_t)(d0 + d1 + d2 + d3);
+}
+
+template <int KIND>
+double cycles_per_instr(uint32_t* d_out, unsigned long long* d_cyc, double* wall_ms) {
+    const int blocks = 256 * 4, threads = 256, iters = 40, waves = blocks * threads / 64;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    k_rate_cycles<KIND><<<blocks, threads>>>(d_out, d_cyc, 4, 1);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    k_rate_cycles<KIND><<<blocks, threads>>>(d_out, d_cyc, iters, 1);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (wall_ms) *wall_ms = ms;
+    std::vector<unsigned long long> h(waves);
+    CHECK(hipMemcpy(h.data(), d_cyc, waves * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double sum = 0;
+    for (auto c : h) sum += (double)c;
+    const double n_instr = (double)iters * 64.0 * 4.0;          // per wave
+    return (sum / waves) / (4.0 * n_instr);
+}
+
+static int json_mode() {
+    int ncu = 0;
+    CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
+    uint32_t* d_out; CHECK(hipMalloc(&d_out, 256 * 4 * 256 * 4));
+    unsigned long long* d_cyc; CHECK(hipMalloc(&d_cyc, 256 * 4 * 4 * sizeof(unsigned long long)));
+    double w_mad = 0;
+    const double mad_u = cycles_per_instr<0>(d_out, d_cyc, &w_mad), mad_i = cycles_per_instr<1>(d_out, d_cyc, nullptr);
+    const double addc = cycles_per_instr<2>(d_out, d_cyc, nullptr), add3 = cycles_per_instr<3>(d_out, d_cyc, nullptr);
+    const double shr64 = cycles_per_instr<4>(d_out, d_cyc, nullptr), lshladd64 = cycles_per_instr<5>(d_out, d_cyc, nullptr);
+    const double mov = cycles_per_instr<6>(d_out, d_cyc, nullptr), and32 = cycles_per_instr<7>(d_out, d_cyc, nullptr);
+    const double add32 = cycles_per_instr<8>(d_out, d_cyc, nullptr), shr32 = cycles_per_instr<9>(d_out, d_cyc, nullptr);
+    // the clock the chip held during the multiply-add loop: its cycles over the wall time of the launch
+    const double n_instr = 40.0 * 64.0 * 4.0;
+    const double clock_ghz = mad_u * 4.0 * n_instr / (w_mad * 1e-3) / 1e9;
+    printf("{\"cus\": %d, \"cycles_per_wave_instr\": {\"mad64\": %.3f, \"other\": %.3f, \"simple32\": %.3f}, "
+           "\"per_instruction\": {\"v_mad_u64_u32\": %.3f, \"v_mad_i64_i32\": %.3f, \"v_add_co_u32+v_addc_co_u32\": %.3f, \"v_add3_u32\": %.3f, "
+           "\"v_lshrrev_b64\": %.3f, \"v_lshl_add_u64\": %.3f, \"v_mov_b32\": %.3f, \"v_and_b32\": %.3f, \"v_add_u32\": %.3f, \"v_lshrrev_b32\": %.3f}, "
+           "\"clock_ghz_during_mad_loop\": %.3f, "
+           "\"how\": \"shader cycles (clock64) around each wave's own loop of 10240 instructions, 4 waves per SIMD resident on every SIMD; "
+           "mad64 = mean of the two multiply-adds, other = mean of the four VOP3 / 64-bit operations, simple32 = mean of the four "
+           "32-bit VOP1 / VOP2 operations\"}\n",
+           ncu, (mad_u + mad_i) / 2, (addc + add3 + shr64 + lshladd64) / 4, (mov + and32 + add32 + shr32) / 4, mad_u, mad_i, addc, add3, shr64,
+           lshladd64, mov, and32, add32, shr32, clock_ghz);
+    return 0;
+}
+
 template <int KIND>
 void run(const char* name, int per_iter, uint32_t* d_out, double clk_hz) {
     const int blocks = 256 * 8, threads = 256, iters = 200;
@@ -122,7 +222,8 @@ void run(const char* name, int per_iter, uint32_t* d_out, double clk_hz) {
            name, ms, wave_instr / (ms * 1e-3) / 1e9, clk_hz / 1e9, clk_hz / per_simd_per_s);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "--json")) return json_mode();
     hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
     double clk = p.clockRate * 1e3;
     printf("device %s CUs %d clock %.0f MHz\n", p.name, p.multiProcessorCount, clk / 1e6);
