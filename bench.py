@@ -127,6 +127,9 @@ def parse():
                          "through the compiled C caller, with the CPU restatement's chain beside it)")
     ap.add_argument("--no-shapes", action="store_true", help="N = 1: skip the second-shape record (`shapes`: mdl1 / S22, SURVEY 8d 'report both')")
     ap.add_argument("--no-latency-curve", action="store_true", help="skip `inflight_curve` (rate and latency at 1 / 2 / 4 / 8 / 16 proofs in flight)")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="profiling and A/B runs: the headline measurement and nothing else (implies every --no-* leg switch: sweep, CPU baseline, "
+                         "host witness, checker, cold start, shapes, latency curve, micro-benchmark, sharded leg)")
     ap.add_argument("--no-ubench", action="store_true", help="do not run tools/ubench/valu_rates (the in-run VALU issue rates of `roofline_valu`)")
     ap.add_argument("--stall-rank", type=int, default=-1,
                     help="testing aid: this rank stops before the sharded leg, as a rank that failed alone would (exercises --leg-timeout)")
@@ -428,6 +431,9 @@ def n_blocks(a):
 
 def main():
     a = parse()
+    if a.headline_only:
+        a.no_sweep = a.no_cpu_baseline = a.no_host_witness = a.no_check = a.no_cold_start = a.no_shapes = a.no_latency_curve = True
+        a.no_ubench = a.no_sharded = True
     a.sharded_shape = a.sharded_shape or (a.shape if a.shape else "mdl1")
     a.shape = a.shape or "rs256-sd"
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -654,7 +660,7 @@ def main():
             t_u = time.perf_counter()
             ub = json.loads(subprocess.run([exe, "--json"], capture_output=True, text=True, timeout=60, check=True).stdout.strip().splitlines()[-1])
             issue = {"cycles_per_wave_instr": ub["cycles_per_wave_instr"], "per_instruction": ub["per_instruction"], "measured_in_run": True,
-                     "clock_ghz_during_the_microbenchmark": ub["clock_ghz_during_mad_loop"], "seconds": round(time.perf_counter() - t_u, 2),
+                     "sustained_mad64": ub["sustained_mad64"], "seconds": round(time.perf_counter() - t_u, 2),
                      "source": "tools/ubench/valu_rates --json, run by this process between the headline and the secondary legs: " + ub["how"]}
         except Exception as e:
             issue["error"] = repr(e)
@@ -700,6 +706,16 @@ def main():
                  "wave_instr_per_proof": instr,
                  "simd_cycles_per_proof": round(simd_cycles_per_proof) if simd_cycles_per_proof else None,
                  "issue_model": dict(issue, class_mix=mix, class_mix_source=mix_src, cycles_per_wave_instr_of_this_mix=round(mix_cycles, 3)),
+                 # What the chip SUSTAINS on this arithmetic: it is power-limited.  ~60 ms of nothing but multiply-adds on every SIMD
+                 # runs at the rate and clock below (in-run micro-benchmark) - well under the clock the proofs hold, because their
+                 # mix is lighter.  The proofs' SIMD cycles per second, expressed in multiply-adds, against that sustained rate:
+                 "power_limit": ({"sustained_mad64_G_per_s": issue["sustained_mad64"]["G_wave_instr_per_s"],
+                                  "clock_ghz_under_that_load": issue["sustained_mad64"]["clock_ghz"],
+                                  "achieved_in_mad64_equivalents_G_per_s": round(simd_cycles_per_proof * per_gpu / cyc["mad64"] / 1e9, 1),
+                                  "frac_of_sustained_rate": round(simd_cycles_per_proof * per_gpu / cyc["mad64"] / 1e9 / issue["sustained_mad64"]["G_wave_instr_per_s"], 4),
+                                  "note": "a proof's SIMD issue cycles / cycles per multiply-add = the multiply-adds that would keep the SIMDs as "
+                                          "busy; over the multiply-add rate the chip holds for 60 ms at its power limit"}
+                                 if simd_cycles_per_proof and issue.get("sustained_mad64") else None),
                  "legacy_frac_4_cycle_convention": round(instr * per_gpu / VALU_PEAK, 4) if instr else None,
                  "legacy_frac_of_sustained_clock_peak": round(instr * per_gpu / (VALU_PEAK * sustained / PEAK_CLOCK_GHZ), 4)
                  if instr and sustained else None,
@@ -710,7 +726,7 @@ def main():
                          "sustained_clock_ghz is measured on the device during the timed proofs (cg_probe_shader_clock)"}
     # ---- the transforms: the one kernel family SURVEY 8d called bandwidth-sensitive (64 B per element per transform) -----------
     roof_ntt = None
-    if rank == 0:
+    if rank == 0 and not a.headline_only:        # (profiling runs: the unit transforms would be counted into the proofs' kernels)
         try:
             logd = prover.domain_size.bit_length() - 1
             nt_ = cc.NttContext(logd, device=local_rank)
@@ -886,7 +902,7 @@ def main():
             for k in (1, 2, 4, 8, 16):
                 if k > inflight:
                     break
-                n_ = 300
+                n_ = 200
                 lat = []
                 done_ = steady_stream(pk_, n_ + k, k, lat)                  # the first k completions are the ramp
                 rate_ = n_ / (done_[-1] - done_[k - 1])
@@ -1019,6 +1035,27 @@ def main():
                                     "what": "rank 0 runs the witness map once (four full-size transforms), scatters the coset values, "
                                             "every rank proves with its slice"}}
                     assert same_s, "the scatter arrangement's proof differs from the unsharded one"
+                    # the same arrangement in two calls: every rank opens the proof (its l, a, b1, b2 sums run), THEN the witness map
+                    # and the scatter, then the h share - the assignment-driven MSMs leave the critical path
+                    spt = ShardedProver(sc_ctx, dev, group=grp, arrangement="scatter", two_call=True)
+                    for _ in range(3):
+                        spt.prove_dev(ws_s[0].data_ptr(), srng.randrange(R), srng.randrange(R))
+                    barrier_sync(world)
+                    spt.reset_breakdown()
+                    t_start = time.perf_counter()
+                    for k in range(a.sharded_steps):
+                        spt.prove_dev(ws_s[k % len(ws_s)].data_ptr(), srng.randrange(R), srng.randrange(R))
+                    torch.cuda.synchronize()
+                    barrier_sync(world)
+                    dst_ = max_over_ranks(time.perf_counter() - t_start, world)
+                    r_, s_ = srng.randrange(R), srng.randrange(R)
+                    same_t = spt.prove_dev(ws_s[0].data_ptr(), r_, s_).data == ref_s.prove_dev(ws_s[0].data_ptr(), r_, s_).data
+                    sh["arrangements"]["scatter_two_call"] = {
+                        "ms_per_proof": round(dst_ / a.sharded_steps * 1e3, 3), "collectives_per_proof": 2,
+                        "ms_breakdown_rank0": spt.breakdown_ms(), "bytes_identical_to_unsharded": bool(same_t),
+                        "what": "cg_prove_partial_q_begin on every rank (l, a, b1, b2 partial sums queued), rank 0's witness map on its open "
+                                "proof, the scatter, cg_prove_partial_q_finish with the slice (the h share)"}
+                    assert same_t, "the two-call scatter arrangement's proof differs from the unsharded one"
                     sc_ctx.close()
                 except AssertionError:
                     raise

@@ -57,7 +57,7 @@ class _CgCsr(C.Structure):
 
 class _CgOptions(C.Structure):
     _fields_ = [("device", C.c_int32), ("window_bits", C.c_int32), ("shard_rank", C.c_int32),
-                ("shard_count", C.c_int32), ("proof_slots", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("shard_count", C.c_int32), ("proof_slots", C.c_int32), ("flags", C.c_int32), ("hw_queues", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class CgTimings(C.Structure):
@@ -126,6 +126,10 @@ _SIGNATURES = {
     "cg_witness_map_coset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "cg_h_scalars_slice": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "cg_prove_partial_q": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(CgTimings)]),
+    "cg_prove_partial_q_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "cg_partial_witness_map_coset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "cg_prove_partial_q_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(CgTimings)]),
+    "cg_prove_partial_q_abort": (None, [C.c_void_p]),
     "cg_host_alloc": (C.c_void_p, [C.c_uint64]),
     "cg_host_free": (None, [C.c_void_p]),
     "cg_host_register": (C.c_int, [C.c_void_p, C.c_uint64]),
@@ -351,6 +355,51 @@ class ConstraintMatrices:
 # ------------------------------------------------------------------------------------------------
 # prover
 # ------------------------------------------------------------------------------------------------
+class OpenPartial:
+    """a sharded proof between cg_prove_partial_q_begin and _finish (cg_partial): it holds one of its context's proof slots"""
+
+    def __init__(self, prover, handle, keep):
+        self._prover, self._h, self._keep = prover, handle, keep
+
+    def witness_map_coset(self, out_dev: Optional[int] = None, out_host: Optional[int] = None):
+        """cg_partial_witness_map_coset (the rank that runs the witness map): all coset values for this proof's assignment,
+        shard-major; -> numpy bytes, or written to the device address out_dev / the host address out_host"""
+        if out_dev is not None:
+            _check(lib().cg_partial_witness_map_coset(self._h, C.c_void_p(int(out_dev)), 1))
+            return None
+        if out_host is not None:
+            _check(lib().cg_partial_witness_map_coset(self._h, C.c_void_p(int(out_host)), 0))
+            return None
+        q = np.zeros(self._prover.domain_size * 32, dtype=np.uint8)
+        _check(lib().cg_partial_witness_map_coset(self._h, _ptr(q), 0))
+        return q
+
+    def finish(self, q_slice, q_on_device: bool = False, timings: bool = False):
+        """cg_prove_partial_q_finish: the h share with this shard's slice; -> the 384-byte record.  The handle is gone afterwards,
+        whether the call succeeded or not."""
+        out = np.zeros(384, dtype=np.uint8)
+        if q_on_device:
+            qptr = C.c_void_p(int(q_slice))
+        else:
+            q = _u8(q_slice)
+            qptr = C.c_void_p(_ptr(q) if q.size else _ptr(out))
+        tm = CgTimings()
+        h, self._h = self._h, None
+        _check(lib().cg_prove_partial_q_finish(h, qptr, 1 if q_on_device else 0, _ptr(out), C.byref(tm) if timings else None))
+        return (out.tobytes(), tm.as_dict()) if timings else out.tobytes()
+
+    def abort(self):
+        if self._h is not None:
+            h, self._h = self._h, None
+            lib().cg_prove_partial_q_abort(h)
+
+    def __del__(self):
+        try:
+            self.abort()
+        except Exception:
+            pass
+
+
 class Prover:
     """A circuit loaded on one GPU (cg_ctx): proving key tables + matrices resident in HBM."""
 
@@ -501,6 +550,20 @@ class Prover:
         _check(lib().cg_prove_partial_q(self._h, ptr, 1 if on_device else 0, qptr, 1 if q_on_device else 0, _ptr(rb), _ptr(out),
                                         C.byref(tm) if timings else None))
         return (out.tobytes(), tm.as_dict()) if timings else out.tobytes()
+
+    def prove_partial_q_begin(self, assignment, r: int, on_device: bool = False) -> "OpenPartial":
+        """cg_prove_partial_q_begin: takes a proof slot, queues this shard's l, a, b1, b2 partial sums and returns while they run;
+        the h share follows with OpenPartial.finish(slice) once the slice has arrived"""
+        rb = _u8(fr_to_bytes(r))
+        keep = None
+        if on_device:
+            ptr = C.c_void_p(int(assignment))
+        else:
+            keep = _u8(assignment, self.num_variables * 32)
+            ptr = C.c_void_p(_ptr(keep))
+        h = C.c_void_p()
+        _check(lib().cg_prove_partial_q_begin(self._h, ptr, 1 if on_device else 0, _ptr(rb), C.byref(h)))
+        return OpenPartial(self, h, keep)
 
     def h_scalars_slice(self, shard: int) -> Tuple[int, int]:
         """(offset, count) of shard `shard`'s scalars inside witness_map_coset's output, in elements (cg_h_scalars_slice)"""
@@ -674,21 +737,28 @@ class _Held:
 
 
 def _freeze(*arrays) -> "_Held":
-    """The digest of an object is remembered on it, so its arrays must not change afterwards: they are made read-only - and so
-    is every array they are views of, since a write through a writable base would change them all the same - so that an
-    in-place write raises instead of silently proving against the old resident copy.  (A side effect on arrays the caller
-    owns, documented on Groth16.prove / Prover: the key and matrix arrays a prover was made from become read-only.)  An
-    attribute REPLACED by another array (the supported way to change a key or a matrix) is seen - the memo holds the
-    arrays themselves - and hashed again."""
+    """The digest of an object is remembered on it, so its arrays must not change afterwards: the arrays that were HASHED are
+    made read-only, so that an in-place write through them raises instead of silently proving against the old resident copy.
+    Only those: an array they are views of stays as the caller left it (round 5 walked `.base` and froze the parents too, which
+    changed unrelated views of a buffer the caller owns).  A view whose parent is still writable can be changed behind the
+    memo's back, so such a set is marked not `stable` and its digest is NOT remembered: it is recomputed at every use (0.3 s per
+    GB) - slower, never stale.  An attribute REPLACED by another array (the supported way to change a key or a matrix) is seen
+    - the memo holds the arrays themselves - and hashed again."""
+    stable = True
     for a in arrays:
-        b = a
-        while isinstance(b, np.ndarray):
+        if isinstance(a, np.ndarray):
             try:
-                b.setflags(write=False)
+                a.setflags(write=False)
             except ValueError:
                 pass
-            b = b.base
-    return _Held(arrays)
+            b = a.base
+            while isinstance(b, np.ndarray):
+                if b.flags.writeable:
+                    stable = False
+                b = b.base
+    held = _Held(arrays)
+    held.stable = stable
+    return held
 
 
 def _matrices_key(m: "ConstraintMatrices") -> tuple:
@@ -699,7 +769,8 @@ def _matrices_key(m: "ConstraintMatrices") -> tuple:
     if memo is not None and memo[0].same_as(arrays):
         return memo[1]
     k = (m.num_instance_variables, m.num_witness_variables, m.num_constraints, m.a.nnz, m.b.nnz, m.c.nnz, _content_digest(*arrays))
-    m._content_key = (_freeze(*arrays), k)
+    held = _freeze(*arrays)
+    m._content_key = (held, k) if held.stable else None
     return k
 
 
@@ -711,7 +782,8 @@ def _pk_key(pk: "ProvingKey") -> tuple:
     if memo is not None and memo[0].same_as(arrays) and memo[2] == pk.coord_form:
         return memo[1]
     k = (pk.coord_form, pk.a_query.size, pk.h_query.size, pk.l_query.size, _content_digest(*arrays))
-    pk._content_key = (_freeze(*arrays), k, pk.coord_form)
+    held = _freeze(*arrays)
+    pk._content_key = (held, k, pk.coord_form) if held.stable else None
     return k
 
 

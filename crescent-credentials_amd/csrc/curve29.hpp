@@ -344,64 +344,20 @@ CG_HD void pack_signed_record(const G1AccS& a, uint32_t* w) {
 }
 #if defined(__HIPCC__)
 // The flush of the accumulation's loop: it runs for one or two lanes of a wave in 71 % of the iterations (equal segments
-// over runs of ~52 entries), so the WAVE pays every vector-ALU instruction of it 0.71 times per entry - 130 of the 2180
-// instructions per entry in rounds 2-4, most of them register moves that line the 36 words up in fours for 16-byte stores
-// (and selects that zero the record of an empty run).  Here the words leave from the registers they are in, one 4-byte
-// store each - relaxed wavefront-scope atomic stores, which the optimiser neither merges nor decorates with cache
-// controls; vector-memory instructions do not take the vector ALU's issue slots - and the empty run (a cancellation: rare)
-// takes a branch of its own.
-// HOW the 36 words leave (measured, profiles/r05_d_flush_variants.txt):
-//   0  nine 16-byte stores: the optimiser first lines the words up in fours, ~68 register moves per flush;
-//   1  36 four-byte stores from the registers the words are in (relaxed wavefront-scope atomic stores: neither merged nor
-//      decorated with cache controls): no vector-ALU work at all, four times the vector-memory instructions;
-//   2  through a 144-byte slot of LDS per wave: the flushing lanes take turns, write their words one by one (LDS
-//      instructions), read them back as nine 16-byte values - consecutive registers by construction - and store those.
-template <int HOW>
-CG_HD void store_acc_signed(uint32_t* __restrict__ dst, const G1AccS& a, bool inf, uint32_t* wave_slot = nullptr) {
+// over runs of ~52 entries), so the WAVE pays every vector-ALU instruction of it 0.71 times per entry.  The record leaves as
+// nine 16-byte stores.  (Round 5 measured two other ways out - 36 four-byte stores straight from the registers, and through a
+// 144-byte LDS slot per wave; neither won, profiles/r05_d_flush_variants.txt, and round 6 took them out of the sources.)
+CG_HD void store_acc_signed(uint32_t* __restrict__ dst, const G1AccS& a, bool inf) {
+    uint4* p = reinterpret_cast<uint4*>(dst);
     if (inf) {
-        uint4* p = reinterpret_cast<uint4*>(dst);
 #pragma unroll
         for (int i = 0; i < 9; ++i) p[i] = make_uint4(0u, 0u, 0u, 0u);
         return;
     }
-    const uint32_t zz8 = (uint32_t)a.zz.l[8] | 0x80000000u | (((uint32_t)a.t >> 31) << 30);
-    if constexpr (HOW == 1) {
-        auto put = [&](int i, uint32_t v) { __hip_atomic_store(dst + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); };
+    uint32_t w[36];
+    pack_signed_record(a, w);
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            put(i, (uint32_t)a.x.l[i]);
-            put(9 + i, (uint32_t)a.sy.l[i]);
-            put(18 + i, i < 8 ? (uint32_t)a.zz.l[i] : zz8);
-            put(27 + i, (uint32_t)a.zzz.l[i]);
-        }
-    } else if constexpr (HOW == 2) {
-        // the lanes of this wave that are here take turns at the wave's slot
-        unsigned long long todo = __ballot(1);
-        const unsigned lane = __lane_id();
-        while (todo) {
-            const unsigned leader = (unsigned)__ffsll((long long)todo) - 1u;
-            if (lane == leader) {
-#pragma unroll
-                for (int i = 0; i < 9; ++i) {
-                    wave_slot[i] = (uint32_t)a.x.l[i];
-                    wave_slot[9 + i] = (uint32_t)a.sy.l[i];
-                    wave_slot[18 + i] = i < 8 ? (uint32_t)a.zz.l[i] : zz8;
-                    wave_slot[27 + i] = (uint32_t)a.zzz.l[i];
-                }
-                const uint4* q = reinterpret_cast<const uint4*>(wave_slot);
-                uint4* p = reinterpret_cast<uint4*>(dst);
-#pragma unroll 1
-                for (int i = 0; i < 9; ++i) p[i] = q[i];           // a real loop: four registers in flight, not thirty-six
-            }
-            todo &= todo - 1ull;
-        }
-    } else {
-        uint32_t w[36];
-        pack_signed_record(a, w);
-        uint4* p = reinterpret_cast<uint4*>(dst);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) p[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
-    }
+    for (int i = 0; i < 9; ++i) p[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
 #endif
 CG_HD void signed_record_to_stored(uint32_t* w) {

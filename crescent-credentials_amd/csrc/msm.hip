@@ -812,18 +812,13 @@ __global__ void __launch_bounds__(256) CG_ACCUM_ATTR k_accum_affine(const uint64
 // A flushed run leaves as a SIGNED record (curve29.hpp store_acc_signed: the accumulator as it is, marked); load_acc brings
 // it to the stored (unsigned) invariant in the kernels that read it - a flush runs for a lane or two of a wave in 71 % of the
 // loop's iterations, so every instruction taken out of it is taken out of the loop.
-#if !defined(CG_FLUSH_HOW)
-#define CG_FLUSH_HOW 0
-#endif
-template <int FLUSH, int BLOCK = 256>
+template <int BLOCK = 256>
 __global__ void __launch_bounds__(BLOCK) CG_ACCUM_ATTR k_accum_affine_g1s(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ plan,
                                                           const uint32_t* __restrict__ table,
                                                           uint32_t* __restrict__ bucket_sums, uint32_t* __restrict__ part_keys,
                                                           uint32_t* __restrict__ part_pts) {
     typedef Fq29 F29T;
     constexpr int ACC = Words29<F29T>::ACC;
-    __shared__ __attribute__((aligned(16))) uint32_t flush_slots[FLUSH == 2 ? (BLOCK / 64) * 36 : 4];       // one 144-byte slot per wave
-    uint32_t* const wave_slot = flush_slots + (FLUSH == 2 ? (threadIdx.x >> 6) * 36 : 0);
     const uint32_t N = plan[PLAN_N], L = plan[PLAN_L], T = plan[PLAN_T];
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
@@ -846,9 +841,9 @@ __global__ void __launch_bounds__(BLOCK) CG_ACCUM_ATTR k_accum_affine_g1s(const 
             // the record leaves in the signed form (curve29.hpp store_acc_signed); its readers convert it
             if (first && !final_level) {
                 part_keys[2 * t] = cur;
-                store_acc_signed<FLUSH>(part_pts + (size_t)(2 * t) * ACC, acc, inf, wave_slot);
+                store_acc_signed(part_pts + (size_t)(2 * t) * ACC, acc, inf);
             } else {
-                store_acc_signed<FLUSH>(bucket_sums + (size_t)cur * ACC, acc, inf, wave_slot);
+                store_acc_signed(bucket_sums + (size_t)cur * ACC, acc, inf);
             }
             first = false;
             inf = true;
@@ -858,15 +853,15 @@ __global__ void __launch_bounds__(BLOCK) CG_ACCUM_ATTR k_accum_affine_g1s(const 
         madd29s(acc, inf, p, (int32_t)v >> 31 | 1, neg1, neg2);       // sigma = -1 for a negative digit, +1 otherwise
     }
     if (final_level) {
-        store_acc_signed<FLUSH>(bucket_sums + (size_t)cur * ACC, acc, inf, wave_slot);
+        store_acc_signed(bucket_sums + (size_t)cur * ACC, acc, inf);
     } else if (first) {  // the whole segment is one run
         part_keys[2 * t] = cur;
-        store_acc_signed<FLUSH>(part_pts + (size_t)(2 * t) * ACC, acc, inf, wave_slot);
+        store_acc_signed(part_pts + (size_t)(2 * t) * ACC, acc, inf);
         part_keys[2 * t + 1] = cur;
-        store_acc_signed<FLUSH>(part_pts + (size_t)(2 * t + 1) * ACC, acc, true, wave_slot);
+        store_acc_signed(part_pts + (size_t)(2 * t + 1) * ACC, acc, true);
     } else {
         part_keys[2 * t + 1] = cur;
-        store_acc_signed<FLUSH>(part_pts + (size_t)(2 * t + 1) * ACC, acc, inf, wave_slot);
+        store_acc_signed(part_pts + (size_t)(2 * t + 1) * ACC, acc, inf);
     }
 }
 
@@ -1093,20 +1088,17 @@ static void launch_accum_affine(const uint64_t* entries, const uint32_t* plan, u
         static const bool unsigned_ref = CG_TUNE_ENV("ACCUM_UNSIGNED") != nullptr && CG_TUNE_ENV("ACCUM_UNSIGNED")[0] == '1';
         if (unsigned_ref) k_accum_affine<F29T><<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
         else {
-#ifdef CG_TUNING      // CG_FLUSH=0 / 1 / 2: how a flushed record leaves (curve29.hpp store_acc_signed)
-            static const int how = [] { const char* e = CG_TUNE_ENV("FLUSH"); return e ? atoi(e) : CG_FLUSH_HOW; }();
+#ifdef CG_TUNING
             // CG_ACCUM_BLOCK=64 / 128 / 512 / 1024: the kernel has no barrier, so any workgroup size is legal - smaller ones measure
             // -3.5 % in the pipeline, 512 -0.6 %, 1024 -2 % (profiles/r05_ab_accum_workgroup_size.txt: a 256-thread workgroup puts one
             // wave on each SIMD of a CU)
             static const uint32_t blk = [] { const char* e = CG_TUNE_ENV("ACCUM_BLOCK"); const int v = e ? atoi(e) : 0; return (uint32_t)(v == 64 || v == 128 || v == 512 || v == 1024 ? v : 0); }();
-            if (blk == 512) k_accum_affine_g1s<0, 512><<<ceil_div(T_max, 512u), 512, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
-            else if (blk == 1024) k_accum_affine_g1s<0, 1024><<<ceil_div(T_max, 1024u), 1024, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
-            else if (blk) k_accum_affine_g1s<0><<<ceil_div(T_max, blk), blk, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
-            else if (how == 1) k_accum_affine_g1s<1><<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
-            else if (how == 2) k_accum_affine_g1s<2><<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
-            else k_accum_affine_g1s<0><<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
+            if (blk == 512) k_accum_affine_g1s<512><<<ceil_div(T_max, 512u), 512, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
+            else if (blk == 1024) k_accum_affine_g1s<1024><<<ceil_div(T_max, 1024u), 1024, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
+            else if (blk) k_accum_affine_g1s<256><<<ceil_div(T_max, blk), blk, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
+            else k_accum_affine_g1s<256><<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
 #else
-            k_accum_affine_g1s<CG_FLUSH_HOW><<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
+            k_accum_affine_g1s<256><<<ceil_div(T_max, 256), 256, 0, st>>>(entries, plan, table, bucket_sums, part_keys, part_pts);
 #endif
         }
     }
@@ -1492,7 +1484,7 @@ static void part_bits(int c, int W, bool precomputed, int& bits1, int& bits2) {
 }
 
 template <class F>
-void MsmEngine<F>::init(const MsmBases<F>* b) {
+void MsmEngine<F>::init(const MsmBases<F>* b, hipStream_t zero_stream) {
     bases = b;
     const uint64_t n = b->n;
     const int W = b->W;
@@ -1572,7 +1564,10 @@ void MsmEngine<F>::init(const MsmBases<F>* b) {
     // default stream it runs on does not order itself against this library's non-blocking streams - the first MSM of a
     // freshly loaded context could start before the fill and have its counters zeroed under it.  Seen as wrong proofs and
     // memory faults in test_contexts_come_and_go_while_others_prove, 10 runs in 12.)
-    {
+    if (zero_stream) {        // the caller waits for it (once, for all the engines it makes)
+        CG_HIP(hipMemsetAsync(counters.p, 0, counters.bytes(), zero_stream));
+        CG_HIP(hipMemsetAsync(bucket_sums.p, 0, bucket_sums.bytes(), zero_stream));
+    } else {
         hipStream_t zs = nullptr;
         CG_HIP(hipStreamCreateWithFlags(&zs, hipStreamNonBlocking));
         hipError_t e1 = hipMemsetAsync(counters.p, 0, counters.bytes(), zs);

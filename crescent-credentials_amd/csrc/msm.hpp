@@ -121,7 +121,9 @@ struct MsmEngine {
     float ms_sort() const;
     float ms_accum() const;
 
-    void init(const MsmBases<F>* b);
+    // zero_stream: the stream the initial zero-fill of the counters and buckets is enqueued on; the CALLER waits for it before the
+    // engine's first MSM (a loader that makes many engines waits once).  Null: a stream of the engine's own, waited for here.
+    void init(const MsmBases<F>* b, hipStream_t zero_stream = nullptr);
     ~MsmEngine();
     // device memory this engine holds, by kind (cg_ctx_get_info): entry lists and segment pieces it OWNS (nothing when it
     // works in a shared scratch), and the rest (bucket array, reduction buffers, partition counters)

@@ -447,8 +447,11 @@ static void load_query(MsmBases<F>& bases, const uint8_t* bytes, uint32_t form, 
 
 // One proof slot (working set + streams) over the given tables.  Everything else it is cut for - the domain, the matrices'
 // scratch, the mode - is the context's.
+// zs: the stream the engines' initial zero-fills go out on; the caller waits for it ONCE after its last slot (a wait per
+// engine is a wait for a fill kernel to be scheduled, and behind a busy context that is tens of ms each: eighty of them made
+// a sixteen-slot set take 2 s on a loaded GPU).
 static std::unique_ptr<ProofSlot> make_slot(cg_ctx* c, const MsmBases<Fq>* bh, const MsmBases<Fq>* bl, const MsmBases<Fq>* ba,
-                                            const MsmBases<Fq>* bb1, const MsmBases<Fq2>* bb2) {
+                                            const MsmBases<Fq>* bb1, const MsmBases<Fq2>* bb2, hipStream_t zs) {
     CG_HIP(hipSetDevice(c->device));
     std::unique_ptr<ProofSlot> sl(new ProofSlot());
     // A throughput context runs every proof on ONE stream: with a dozen proofs in flight the overlap comes from the
@@ -486,7 +489,7 @@ static std::unique_ptr<ProofSlot> make_slot(cg_ctx* c, const MsmBases<Fq>* bh, c
         const bool zero_at_end = !(CG_TUNE_ENV("NO_ZERO_AT_END") && CG_TUNE_ENV("NO_ZERO_AT_END")[0] == '1');     // A/B aid (tuning builds)
         sl->eh.zero_at_end = sl->el.zero_at_end = sl->ea.zero_at_end = sl->eb1.zero_at_end = sl->eb2.zero_at_end = zero_at_end;
     }
-    sl->eh.init(bh); sl->el.init(bl); sl->ea.init(ba); sl->eb1.init(bb1); sl->eb2.init(bb2);
+    sl->eh.init(bh, zs); sl->el.init(bl, zs); sl->ea.init(ba, zs); sl->eb1.init(bb1, zs); sl->eb2.init(bb2, zs);
     if (c->external_q) {      // only the landing buffer of a slice that arrives in host memory, and the input flag
         sl->h_canon.alloc(c->rh.hi - c->rh.lo ? c->rh.hi - c->rh.lo : 1);
         sl->wm.h_bad_input.alloc(1);
@@ -581,10 +584,12 @@ static void staged_worker(cg_ctx* c) {
         stop();
         {
             const auto tt = std::chrono::steady_clock::now();
+            ScopedStream zs;
             for (int k = 0; k < c->n_slots_final; ++k) {
-                slots.push_back(make_slot(c, &bh, &bl, &ba, &bb1, &bb2));
+                slots.push_back(make_slot(c, &bh, &bl, &ba, &bb1, &bb2, zs));
                 stop();
             }
+            CG_HIP(hipStreamSynchronize(zs));
             ms_slots = ms_since(tt);
         }
         {
@@ -660,6 +665,7 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
     const int wb = opt ? opt->window_bits : 0;
     if (wb < 0 || wb == 1 || wb > 22) return fail(CG_ERR_INVALID_ARGUMENT, "window_bits must be 0 (automatic) or in [2, 22]");
     if (opt && opt->proof_slots < 0) return fail(CG_ERR_INVALID_ARGUMENT, "proof_slots must not be negative");
+    if (opt && opt->hw_queues < 0) return fail(CG_ERR_INVALID_ARGUMENT, "hw_queues must not be negative");
     constexpr int32_t KNOWN_FLAGS = CG_FLAG_H_COEFFICIENT_BASIS | CG_FLAG_LATENCY_MODE | CG_FLAG_THROUGHPUT_MODE | CG_FLAG_SPIN_WAIT |
                                     CG_FLAG_CONTIGUOUS_H_SHARDS | CG_FLAG_H_SCALARS_EXTERNAL | CG_FLAG_STAGED_LOAD;
     if (opt && (opt->flags & ~KNOWN_FLAGS)) return fail(CG_ERR_INVALID_ARGUMENT, "unknown bits in flags");
@@ -839,12 +845,16 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         // final ones.
         const int n_now = staged ? std::min(n_slots, 4) : n_slots;
         if (staged) c->folded = false;                    // the arrangement in force until the swap
-        for (int k = 0; k < n_now; ++k) c->slots.push_back(make_slot(c.get(), &c->bh, &c->bl, &c->ba, &c->bb1, &c->bb2));
+        for (int k = 0; k < n_now; ++k) c->slots.push_back(make_slot(c.get(), &c->bh, &c->bl, &c->ba, &c->bb1, &c->bb2, s0));
+        CG_HIP(hipStreamSynchronize(s0));
         // Four shared copy-only streams when the runtime's hardware queues hold them beside the proof streams one each
         // (GPU_MAX_HW_QUEUES is the HIP runtime's own variable; cg_init asks for 20); with fewer queues four shared streams
         // would only concentrate the blocking (measured -5 % on 16 queues), so every buffer keeps a stream of its own there.
+        // (cg_options.hw_queues when the host states it; else the runtime's own variable - which cg_init set to 20 if the host
+        // had not, effective only if HIP was not initialised before cg_init: a host that initialises HIP first exports the
+        // variable itself or passes hw_queues)
         const char* hwq_env = getenv("GPU_MAX_HW_QUEUES");
-        const int hwq = hwq_env ? atoi(hwq_env) : 4;
+        const int hwq = (opt && opt->hw_queues > 0) ? opt->hw_queues : (hwq_env ? atoi(hwq_env) : 4);
         const size_t n_copy_streams = hwq >= n_slots + 4 ? 4 : (size_t)n_slots + 2;
         for (int k = 0; k < n_slots + 2; ++k) {
             if (c->up_streams.size() < n_copy_streams) {
@@ -1405,6 +1415,190 @@ extern "C" int cg_prove_partial(cg_ctx* ctx, const void* full_assignment, int as
 extern "C" int cg_prove_partial_q(cg_ctx* ctx, const void* full_assignment, int assignment_on_device, const void* q_slice, int q_on_device,
                                   const uint8_t r[32], uint8_t out_partials[384], cg_timings* timings) {
     return prove_partial_common(ctx, full_assignment, assignment_on_device, q_slice, q_on_device, true, r, out_partials, timings);
+}
+
+// ---------------------------------------------------------------------------------------------
+// a sharded proof in two calls (cg_prove_partial_q_begin / _finish): the assignment-driven MSMs run while the h scalars are
+// still on their way
+// ---------------------------------------------------------------------------------------------
+struct cg_partial {
+    cg_ctx* c = nullptr;
+    ProofSlot* S = nullptr;
+    Upload* up = nullptr;
+    const Fr* w_dev = nullptr;
+    bool skip_b1 = false;
+    bool gate_held = false;
+    std::chrono::steady_clock::time_point t0;
+    // everything the open proof holds is given back exactly once, whichever call ends it
+    void close() {
+        if (S) {
+            for (auto st : S->st) if (st) (void)hipStreamSynchronize(st);
+            c->release(S);
+            S = nullptr;
+        }
+        if (up) {
+            (void)hipStreamSynchronize(up->st);
+            c->release_upload(up);
+            up = nullptr;
+        }
+        if (gate_held) { c->tune_mu.unlock_shared(); gate_held = false; }
+        if (c) { c->calls_inside.fetch_sub(1, std::memory_order_acq_rel); c = nullptr; }
+    }
+};
+
+extern "C" int cg_prove_partial_q_begin(cg_ctx* ctx, const void* full_assignment, int assignment_on_device, const uint8_t r[32], cg_partial** out) {
+    if (!ctx || !full_assignment || !r || !out) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (!scalar_is_canonical(r)) return fail(CG_ERR_INVALID_ARGUMENT, "r not canonical");
+    if (!ctx->folded || ctx->shard_count <= 1) return fail(CG_ERR_INVALID_ARGUMENT, "cg_prove_partial_q_begin needs a sharded context over the folded key");
+    if (ctx->broken) return fail(CG_ERR_OUT_OF_MEMORY, "%s", BROKEN_CONTEXT);
+    std::unique_ptr<cg_partial> p(new cg_partial());
+    p->c = ctx;
+    ctx->calls_inside.fetch_add(1, std::memory_order_acq_rel);
+    try {
+        ctx->tune_mu.lock_shared();
+        p->gate_held = true;
+        if (ctx->broken) { p->close(); return fail(CG_ERR_OUT_OF_MEMORY, "%s", BROKEN_CONTEXT); }
+        CG_HIP(hipSetDevice(ctx->device));
+        p->t0 = std::chrono::steady_clock::now();
+        p->w_dev = (const Fr*)full_assignment;
+        if (!assignment_on_device) {
+            p->up = ctx->acquire_upload();
+            (void)upload_assignment(ctx, p->up, full_assignment, false);
+            p->w_dev = p->up->w.p;
+        }
+        p->S = ctx->acquire();
+        p->skip_b1 = scalar_is_zero(r);
+        ProofSlot* S = p->S;
+        cg_ctx* c = ctx;
+        const Fr* w_l = p->w_dev + c->rl.lo;                      // folded l query: one base per wire
+        const uint64_t n_l = c->rl.hi - c->rl.lo, n_a = c->ra.hi - c->ra.lo;
+        const Fr* w_a = p->w_dev + 1 + c->ra.lo;
+        const bool b2_adopts = !p->skip_b1 && c->b_same_identities && S->eb2.can_adopt(S->eb1) && n_a > 0;
+        hipStream_t s0 = S->st[0];
+        if (S->one_stream) {
+            S->el.digits(w_l, n_l, s0); S->el.accumulate(s0);
+            S->ea.digits(w_a, n_a, s0); S->ea.accumulate(s0);
+            if (!p->skip_b1) S->eb1.digits(w_a, n_a, s0);
+            if (b2_adopts) S->eb2.adopt(S->eb1.grouped(), S->eb1.counters.p, n_a, s0);
+            if (!p->skip_b1) S->eb1.accumulate(s0);
+            if (!b2_adopts) S->eb2.digits(w_a, n_a, s0);
+            S->eb2.accumulate(s0);
+        } else {
+            CG_HIP(hipEventRecord(S->ev_w, s0));
+            for (int i = 1; i < 5; ++i) CG_HIP(hipStreamWaitEvent(S->st[i], S->ev_w, 0));
+            S->el.digits(w_l, n_l, S->st[1]);
+            S->ea.digits(w_a, n_a, S->st[2]);
+            if (!p->skip_b1) S->eb1.digits(w_a, n_a, S->st[3]);
+            if (b2_adopts) {
+                CG_HIP(hipEventRecord(S->ev_b1, S->st[3]));
+                CG_HIP(hipStreamWaitEvent(S->st[4], S->ev_b1, 0));
+                S->eb2.adopt(S->eb1.grouped(), S->eb1.counters.p, n_a, S->st[4]);
+            } else {
+                S->eb2.digits(w_a, n_a, S->st[4]);
+            }
+            S->el.accumulate(S->st[1]);
+            S->ea.accumulate(S->st[2]);
+            if (!p->skip_b1) S->eb1.accumulate(S->st[3]);
+            S->eb2.accumulate(S->st[4]);
+        }
+        *out = p.release();
+        return CG_OK;
+    } catch (...) {
+        const int e = translate_exception();
+        p->close();
+        return e;
+    }
+}
+
+extern "C" int cg_partial_witness_map_coset(cg_partial* p, void* q_out, int q_on_device) {
+    if (!p || !p->c || !p->S || !q_out) return fail(CG_ERR_INVALID_ARGUMENT, "null argument or a closed handle");
+    cg_ctx* ctx = p->c;
+    if (ctx->external_q) return fail(CG_ERR_INVALID_ARGUMENT, "context loaded with CG_FLAG_H_SCALARS_EXTERNAL holds no witness-map resources");
+    try {
+        CG_HIP(hipSetDevice(ctx->device));
+        ProofSlot* S = p->S;
+        hipStream_t s0 = S->st[0];
+        // all coset values, natural order, then shard-major for strided shards (as cg_witness_map_coset)
+        wm29_run(ctx->wdom, ctx->A, ctx->B, ctx->C, ctx->dA, ctx->dB, ctx->dC, S->wm, p->w_dev, ctx->M, ctx->m, ctx->l, S->h_canon.p, s0, true, nullptr);
+        const Fr* src = S->h_canon.p;
+        if (ctx->h_strided) {
+            Fr* tmp = reinterpret_cast<Fr*>(S->wm.vt.p);
+            k_shard_major<<<ceil_div(ctx->D, 256), 256, 0, s0>>>(S->h_canon.p, tmp, ctx->D, (uint32_t)ctx->shard_count);
+            CG_KERNEL_CHECK();
+            src = tmp;
+        }
+        CG_HIP(hipMemcpyAsync(q_out, src, ctx->D * 32, q_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s0));
+        CG_HIP(hipStreamSynchronize(s0));
+        if (S->wm.h_bad_input.p[0]) return fail(CG_ERR_INVALID_ARGUMENT, "full_assignment holds a value >= the scalar field modulus");
+        return CG_OK;
+    } catch (...) {
+        return translate_exception();
+    }
+}
+
+extern "C" int cg_prove_partial_q_finish(cg_partial* p, const void* q_slice, int q_on_device, uint8_t out_partials[384], cg_timings* timings) {
+    if (!p) return fail(CG_ERR_INVALID_ARGUMENT, "null handle");
+    std::unique_ptr<cg_partial> own(p);
+    if (!p->c || !p->S) return fail(CG_ERR_INVALID_ARGUMENT, "closed handle");
+    if (!q_slice || !out_partials) { p->close(); return fail(CG_ERR_INVALID_ARGUMENT, "null argument"); }
+    cg_ctx* c = p->c;
+    ProofSlot* S = p->S;
+    int e = CG_OK;
+    Partials P;
+    TuneStats ts;
+    try {
+        CG_HIP(hipSetDevice(c->device));
+        hipStream_t s0 = S->st[0];
+        const uint64_t nq = c->rh.hi - c->rh.lo;
+        const Fr* q_dev = (const Fr*)q_slice;
+        if (!q_on_device && nq) {
+            Fr* dst = c->external_q ? S->h_canon.p : S->h_canon.p + c->rh.lo;
+            CG_HIP(hipMemcpyAsync(dst, q_slice, nq * 32, hipMemcpyHostToDevice, s0));
+            q_dev = dst;
+        }
+        const Fr* h_scalars = witness_map_or_check(c, S, p->w_dev, q_dev, s0);
+        S->eh.digits(h_scalars, nq, s0);
+        S->eh.accumulate(s0);
+        if (S->one_stream && !spin_wait(c)) {
+            CG_HIP(hipEventRecord(S->ev_done, s0));
+            wait_sleeping(S->ev_done, 250);
+        } else {
+            for (int i = 0; i < 5; ++i) CG_HIP(hipStreamSynchronize(S->st[i]));
+        }
+        if (S->wm.h_bad_input.p[0]) {
+            e = fail(CG_ERR_INVALID_ARGUMENT, "full_assignment or the h-scalar slice holds a value >= the scalar field modulus");
+        } else {
+            P.h = to_affine(S->eh.value());
+            P.l = to_affine(S->el.value());
+            P.a = to_affine(S->ea.value());
+            P.b1 = p->skip_b1 ? G1Affine::inf() : to_affine(S->eb1.value());
+            P.b2 = to_affine(S->eb2.value());
+            if (timings) {
+                memset(timings, 0, sizeof(*timings));
+                timings->msm_h_ms = S->eh.ms_total(); timings->msm_l_ms = S->el.ms_total(); timings->msm_a_ms = S->ea.ms_total();
+                timings->msm_b1_ms = p->skip_b1 ? 0.f : S->eb1.ms_total(); timings->msm_b2_ms = S->eb2.ms_total();
+                timings->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - p->t0).count();
+            }
+            snapshot_tune_stats(c, S, p->skip_b1, ts);
+        }
+    } catch (...) {
+        e = translate_exception();
+    }
+    p->c->calls_inside.fetch_add(1, std::memory_order_acq_rel);    // this call's own tail (the re-tune check) outlives the handle's hold
+    p->close();
+    if (!e) {
+        maybe_retune(c, ts);
+        partials_to_bytes(P, out_partials);
+    }
+    c->calls_inside.fetch_sub(1, std::memory_order_acq_rel);
+    return e;
+}
+
+extern "C" void cg_prove_partial_q_abort(cg_partial* p) {
+    if (!p) return;
+    p->close();
+    delete p;
 }
 
 extern "C" int cg_h_scalars_slice(const cg_ctx* ctx, uint32_t shard, uint64_t* offset, uint64_t* count) {

@@ -182,6 +182,16 @@ def gather_partials(partial: bytes, device, group=None) -> bytes:
     return PartialGather(device, group)(partial)
 
 
+class WitnessMapFailed(Exception):
+    """the source rank's witness map failed - raised by HScalarScatter.exchange AFTER the scatter every rank takes part in, so
+    the sequence of collectives is intact and the job can be poisoned through the gather; `cause` is the original exception.
+    Anything else exchange() raises comes from the collective itself: the transport is gone and nothing more can be exchanged."""
+
+    def __init__(self, cause):
+        super().__init__(repr(cause))
+        self.cause = cause
+
+
 class HScalarScatter:
     """The exchange step of the "scatter" arrangement: ONE rank computes every shard's h scalars (witness_map_coset), each rank
     receives its slice.  Chunks are padded to the longest slice (strided shards are all domain_size / world long); buffers are
@@ -213,23 +223,26 @@ class HScalarScatter:
     def _global(self, r: int) -> int:
         return dist.get_global_rank(self.group, r) if (self.world > 1 and self.group is not None) else r
 
-    def exchange(self, assignment, on_device: bool, seconds: dict, src: int = 0, slot: int = 0):
+    def exchange(self, assignment, on_device: bool, seconds: dict, src: int = 0, slot: int = 0, wm=None):
         """Rank `src` (of the group) runs the witness map on `assignment` and scatters; every rank's slice lands in receive
         buffer `slot`.  -> (this rank's slice: a device address or numpy bytes, whether it is on the device).  A witness
-        map that fails on the source is raised there AFTER the scatter the other ranks are already waiting in."""
+        map that fails on the source is raised there AFTER the scatter the other ranks are already waiting in.
+        wm (optional): the witness map of an OPEN two-call proof (OpenPartial.witness_map_coset) to use instead of the
+        context's own - it runs on the working set the open proof holds."""
         t0 = time.perf_counter()
         off, cnt = self.slices[self.rank]
         failure = None
         if self.rank == src:
             try:
+                run = wm if wm is not None else (lambda **kw: self.prover.witness_map_coset(assignment, on_device=on_device, **kw))
                 if self.on_host:
                     if self._direct_host:       # the library writes straight into the (page-locked) tensor the scatter sends from
-                        self.prover.witness_map_coset(assignment, on_device=on_device, out_host=self._all.data_ptr())
+                        run(out_host=self._all.data_ptr())
                     else:
-                        got = np.frombuffer(bytes(self.prover.witness_map_coset(assignment, on_device=on_device)), dtype=np.uint8)
+                        got = np.frombuffer(bytes(run()), dtype=np.uint8)
                         self._all.numpy()[:] = got[:self._all.numel()]    # (a stand-in may return more than its shards' slices cover)
                 else:
-                    self.prover.witness_map_coset(assignment, on_device=on_device, out_dev=self._all.data_ptr())
+                    run(out_dev=self._all.data_ptr())
             except BaseException as e:   # noqa: BLE001
                 failure = e
         t1 = time.perf_counter()
@@ -250,7 +263,7 @@ class HScalarScatter:
         else:
             mine = self._all[off * 32:(off + cnt) * 32]
         if failure is not None:
-            raise failure            # the caller turns it into a poison record for the gather that follows
+            raise WitnessMapFailed(failure)     # the caller turns it into a poison record for the gather that follows
         t2 = time.perf_counter()
         seconds["witness_map"] += t1 - t0
         seconds["scatter"] += t2 - t1
@@ -258,8 +271,8 @@ class HScalarScatter:
             return mine.numpy()[:cnt * 32], False
         return mine.data_ptr(), True
 
-    def __call__(self, assignment, on_device: bool, seconds: dict):
-        return self.exchange(assignment, on_device, seconds, 0, 0)
+    def __call__(self, assignment, on_device: bool, seconds: dict, wm=None):
+        return self.exchange(assignment, on_device, seconds, 0, 0, wm)
 
 
 class ShardedProver:
@@ -275,7 +288,8 @@ class ShardedProver:
     collectives whatever order its partial sums finish in), and the host finish of proof k runs while the partial sums
     of the next proofs are on the GPU."""
 
-    def __init__(self, prover, device, group=None, arrangement: str = "recompute", rotate: bool = False, stream_slots: int = 8):
+    def __init__(self, prover, device, group=None, arrangement: str = "recompute", rotate: bool = False, stream_slots: int = 8,
+                 two_call: bool = False):
         """arrangement ("run the witness map on GPU 0 and scatter h, or recompute it redundantly on every GPU -
         measure both"):
           "recompute" - every rank runs the witness map for its own share of the h MSM (cg_prove_partial); one collective
@@ -290,6 +304,13 @@ class ShardedProver:
                         flight of such a stream (a receive buffer each)."""
         if arrangement not in ("recompute", "scatter"):
             raise ValueError("arrangement must be 'recompute' or 'scatter'")
+        if two_call and arrangement != "scatter":
+            raise ValueError("two_call belongs to the 'scatter' arrangement")
+        # two_call ("scatter" only): every rank OPENS the proof first (cg_prove_partial_q_begin: its l, a, b1, b2 partial sums are
+        # queued and run) and only then takes part in the witness map + scatter; the h share follows with the slice
+        # (cg_prove_partial_q_finish).  The assignment-driven MSMs leave the critical path: witness map -> scatter -> h share.
+        # `prover` needs prove_partial_q_begin (-> an object with witness_map_coset / finish / abort).
+        self.two_call = bool(two_call)
         self.prover = prover
         self.device = device
         self.group = group
@@ -305,13 +326,11 @@ class ShardedProver:
         self._stream_slots = max(1, stream_slots)
         self._scatter = (HScalarScatter(prover, device, group, self.rank, self.world, slots=self._stream_slots, rotate=self.rotate)
                          if arrangement == "scatter" else None)
-        # a stream of scatter-arrangement proofs issues scatters from one thread and gathers from another: each sequence on a
-        # group of its own, so that every rank sees both in the same order whatever the threads' interleaving is
-        self._gather_stream = None
-        if arrangement == "scatter" and self.world > 1:
-            g2 = dist.new_group(ranks=[dist.get_global_rank(group, r) for r in range(self.world)] if group is not None else None,
-                                backend=dist.get_backend(group))
-            self._gather_stream = PartialGather(device, g2)
+        # A stream of scatter-arrangement proofs issues BOTH its collectives - the scatter of job k and the gather of job
+        # k - in_flight - from ONE communication thread on a fixed schedule (_prove_stream_scatter), on the one group.  (Round 5
+        # issued them from two free-running threads on two groups: each group saw its own sequence in order, but nothing ordered
+        # the two against each other across ranks - rank A could enqueue scatter-then-gather where rank B enqueued
+        # gather-then-scatter, which RCCL documents as a deadlock hazard for communicators used concurrently.)
 
     def _prove(self, assignment, on_device: bool, r: int, s: int):
         """one sharded proof.  A shard that fails here does not leave the other ranks waiting in the collective either: the
@@ -319,18 +338,49 @@ class ShardedProver:
         naming it (the protocol of prove_stream, for one proof)."""
         t0 = time.perf_counter()
         failure = None
-        try:
-            if self._scatter is not None:
-                q, q_on_device = self._scatter(assignment, on_device, self.seconds)
-                self.scatters += 1
-                t0 = time.perf_counter()
-                part = self.prover.prove_partial_q(assignment, q, r, on_device=on_device, q_on_device=q_on_device)
-            else:
-                part = self.prover.prove_partial(assignment, r, on_device=on_device)
-        except BaseException as e:   # noqa: BLE001 - raised below, after the collective every rank is about to enter
-            if self.world <= 1:
+        part = None
+        if self._scatter is not None and self.two_call:
+            opened = self.prover.prove_partial_q_begin(assignment, r, on_device=on_device)     # a failure here precedes every collective
+            q = None
+            try:
+                q, q_on_device = self._scatter(assignment, on_device, self.seconds, wm=opened.witness_map_coset)
+            except WitnessMapFailed as e:
+                failure = e.cause
+            except BaseException:            # noqa: BLE001 - the collective failed: give the slot back, nothing can follow
+                opened.abort()
                 raise
-            failure, part = e, POISON
+            self.scatters += 1
+            t0 = time.perf_counter()
+            if failure is None:
+                try:
+                    part = opened.finish(q, q_on_device)
+                except BaseException as e:   # noqa: BLE001 - raised below, after the gather
+                    failure = e
+            else:
+                opened.abort()
+        elif self._scatter is not None:
+            q = None
+            try:
+                q, q_on_device = self._scatter(assignment, on_device, self.seconds)
+            except WitnessMapFailed as e:            # the scatter itself was done: the job is poisoned through the gather below
+                failure = e.cause
+            # (anything else the scatter raises comes from the collective: no gather can follow, it propagates)
+            self.scatters += 1
+            t0 = time.perf_counter()
+            if failure is None:
+                try:
+                    part = self.prover.prove_partial_q(assignment, q, r, on_device=on_device, q_on_device=q_on_device)
+                except BaseException as e:           # noqa: BLE001 - raised below, after the collective every rank is about to enter
+                    failure = e
+        else:
+            try:
+                part = self.prover.prove_partial(assignment, r, on_device=on_device)
+            except BaseException as e:               # noqa: BLE001
+                failure = e
+        if failure is not None:
+            if self.world <= 1:
+                raise failure
+            part = POISON
         t1 = time.perf_counter()
         if self.world > 1:
             parts = self._gather(part)
@@ -457,15 +507,18 @@ class ShardedProver:
         return proofs
 
     def _prove_stream_scatter(self, jobs, in_flight: int, on_device: bool, done_times: Optional[list]):
-        """prove_stream in the "scatter" arrangement.  Three kinds of thread per rank: ONE producer walks the jobs in order -
-        on the job's source rank (k mod world with `rotate`, else rank 0) it runs the witness map, then every rank takes part
-        in the scatter of job k - `in_flight` workers prove with the slices as they arrive (cg_prove_partial_q) and finish the
-        proofs, ONE gatherer exchanges the 384-byte records in job order.  Scatters and gathers run on two groups.  A job whose
-        witness map or partial sums fail on some rank is poisoned for every rank through the gather, as in prove_stream."""
+        """prove_stream in the "scatter" arrangement.  Two kinds of thread per rank: ONE communication thread issues every
+        collective of the stream on a schedule that is the same on every rank - step t: the gather of job t - d's 384-byte records
+        (d = in_flight), then the scatter of job t (on the job's source rank, k mod world with `rotate`, else rank 0, the witness map
+        runs first); `in_flight` workers prove with the slices as they arrive (cg_prove_partial_q) and finish the proofs.  Job t's
+        scatter reuses the receive buffer of job t - d, whose partial sums are done by then - the same event the gather of job t - d
+        waits for, so the schedule costs no extra wait.  A job whose witness map or partial sums fail on some rank is poisoned
+        for every rank through the gather, as in prove_stream; a collective that raises ends the stream on this rank."""
         n = len(jobs)
         in_flight = max(1, min(in_flight, n, self._stream_slots))
+        d = in_flight
         world, rank, sc = self.world, self.rank, self._scatter
-        gather = self._gather_stream
+        gather = self._gather
         src_of = (lambda k: k % world) if self.rotate else (lambda k: 0)
         parts, gathered, proofs = [None] * n, [None] * n, [None] * n
         slices = [None] * n
@@ -478,27 +531,40 @@ class ShardedProver:
         lock = threading.Lock()
         mine, theirs, fatal = [], [], []
 
-        def producer():
+        def comm():
             try:
-                if not sc.on_host:
-                    torch.cuda.set_device(self.device)
-                for k in range(n):
-                    if k >= in_flight:
-                        have_part[k - in_flight].wait()        # its receive buffer is free again
-                    if fatal:
-                        return
-                    a = jobs[k][0]
-                    try:
-                        slices[k] = sc.exchange(a, on_device, self.seconds, src_of(k), k % in_flight)
+                if not sc.on_host or (gather is not None and not gather.on_host):
+                    torch.cuda.set_device(self.device)   # a new thread starts on device 0
+                for t in range(n + d):
+                    kg = t - d
+                    if kg >= 0:                              # the records of job t - d: every rank's partial sums are awaited alike
+                        have_part[kg].wait()
+                        if fatal:
+                            return
+                        t0 = time.perf_counter()
+                        if world > 1:
+                            allp = gather(parts[kg])
+                            self.all_gathers += 1
+                        else:
+                            allp = parts[kg]
+                        bad = [q for q in range(world) if allp[PARTIAL_BYTES * q:PARTIAL_BYTES * (q + 1)] == POISON]
+                        if bad:
+                            theirs.extend((kg, q) for q in bad)
+                        else:
+                            gathered[kg] = allp
+                        self.seconds["gather"] += time.perf_counter() - t0
+                        have_all[kg].set()
+                    if t < n:                                # the slices of job t (receive buffer t mod d: free since the wait above)
+                        try:
+                            slices[t] = sc.exchange(jobs[t][0], on_device, self.seconds, src_of(t), t % d)
+                        except WitnessMapFailed as e:        # this rank's witness map failed; the scatter itself was done
+                            mine.append((t, e.cause))
+                            slices[t] = None
                         self.scatters += 1
-                    except BaseException as e:   # noqa: BLE001 - this rank's witness map failed (the scatter itself was done)
-                        self.scatters += 1
-                        mine.append((k, e))
-                        slices[k] = None
-                    q_ready[k].set()
-            except BaseException as e:           # noqa: BLE001 - the transport failed
+                        q_ready[t].set()
+            except BaseException as e:                       # noqa: BLE001 - a collective failed: nothing more can be exchanged
                 fatal.append(e)
-                for ev in q_ready + have_all:
+                for ev in q_ready + have_all + have_part:
                     ev.set()
 
         def worker():
@@ -541,33 +607,7 @@ class ShardedProver:
                     self.seconds["assemble"] += t3 - t2
                     self.proofs += 1
 
-        def gatherer():
-            try:
-                if gather is not None and not gather.on_host:
-                    torch.cuda.set_device(self.device)
-                for k in range(n):
-                    have_part[k].wait()
-                    if fatal:
-                        return
-                    t0 = time.perf_counter()
-                    if world > 1:
-                        allp = gather(parts[k])
-                        self.all_gathers += 1
-                    else:
-                        allp = parts[k]
-                    bad = [q for q in range(world) if allp[PARTIAL_BYTES * q:PARTIAL_BYTES * (q + 1)] == POISON]
-                    if bad:
-                        theirs.extend((k, q) for q in bad)
-                    else:
-                        gathered[k] = allp
-                    self.seconds["gather"] += time.perf_counter() - t0
-                    have_all[k].set()
-            except BaseException as e:           # noqa: BLE001
-                fatal.append(e)
-                for ev in q_ready + have_all + have_part:
-                    ev.set()
-
-        ts = [threading.Thread(target=producer)] + [threading.Thread(target=worker) for _ in range(in_flight)] + [threading.Thread(target=gatherer)]
+        ts = [threading.Thread(target=comm)] + [threading.Thread(target=worker) for _ in range(in_flight)]
         for t in ts:
             t.start()
         for t in ts:

@@ -95,8 +95,14 @@ typedef struct cg_options {
                               set and streams; cg_prove* from different threads overlap on the GPU); 0 = 1, at
                               most 16.  1 = a latency context (five streams per proof); more = a throughput
                               context (one stream per proof; twelve reach the full rate at the rs256 size) */
-    int32_t flags;         /* CG_FLAG_* (the library reads no environment variable: everything a host may choose is here) */
-    int32_t reserved[2];
+    int32_t flags;         /* CG_FLAG_* (the library reads none of ITS OWN switches from the environment: what a host may choose is here) */
+    int32_t hw_queues;     /* the hardware queues the host's HIP runtime maps its streams onto (the runtime's own GPU_MAX_HW_QUEUES,
+                              read once when HIP initialises; default 4), if the host knows; 0 = the library looks at that variable:
+                              cg_init sets it to 20 when the host has not - which only takes effect if HIP was not initialised before
+                              cg_init - and a throughput context then shares four copy-only streams among its upload buffers.  A host that
+                              initialises HIP first and cannot export the variable passes the real count here (4 unless it chose
+                              otherwise): with fewer queues than proof_slots + 4 every upload buffer keeps a stream of its own */
+    int32_t reserved[1];
 } cg_options;
 
 /* By default cg_circuit_load moves the h query into the evaluation basis of the coset and folds the C matrix into
@@ -316,6 +322,25 @@ int cg_witness_map_coset(cg_ctx* ctx, const void* full_assignment, int assignmen
 int cg_h_scalars_slice(const cg_ctx* ctx, uint32_t shard, uint64_t* offset, uint64_t* count);
 int cg_prove_partial_q(cg_ctx* ctx, const void* full_assignment, int assignment_on_device, const void* q_slice,
                        int q_on_device, const uint8_t r[32], uint8_t out_partials[384], cg_timings* timings);
+
+/* The same in TWO CALLS, so that a shard's assignment-driven MSMs run WHILE the witness map and the scatter are still under way
+ * somewhere else: of a sharded proof's critical path - witness map, scatter, partial sums - only the h share has to wait for
+ * the slice (the l, a and b sums of prover.rs:74,266 need the assignment alone).
+ *   cg_prove_partial_q_begin  : takes one of the context's proof slots, brings the assignment onto the GPU if it is not there,
+ *       queues the l, a, b1 and b2 partial sums and RETURNS without waiting for them.  *out is the open proof.
+ *   cg_partial_witness_map_coset : on the rank that runs the witness map (a context loaded WITHOUT CG_FLAG_H_SCALARS_EXTERNAL):
+ *       cg_witness_map_coset for the open proof's assignment, on the open proof's own working set (a one-slot context has no other),
+ *       next to the MSMs already queued.  Waits for the values.
+ *   cg_prove_partial_q_finish : with this shard's slice (host or device memory): queues the h share, waits for everything, writes
+ *       the 384-byte record, gives the slot back and destroys the handle - also when it fails.
+ *   cg_prove_partial_q_abort  : for a caller that cannot deliver the slice: waits for what was queued, gives the slot back.
+ * An open proof holds its slot: begin as many as the context has slots and no more, or begin blocks.  Calls on one handle are
+ * the caller's to serialise; begin and finish may come from different threads. */
+typedef struct cg_partial cg_partial;
+int cg_prove_partial_q_begin(cg_ctx* ctx, const void* full_assignment, int assignment_on_device, const uint8_t r[32], cg_partial** out);
+int cg_partial_witness_map_coset(cg_partial* p, void* q_out, int q_on_device);
+int cg_prove_partial_q_finish(cg_partial* p, const void* q_slice, int q_on_device, uint8_t out_partials[384], cg_timings* timings);
+void cg_prove_partial_q_abort(cg_partial* p);
 
 /* R1CS -> QAP witness map only: h coefficients, domain_size x 32 B canonical.
  * Replaces: `LibsnarkReduction::witness_map_from_matrices`, r1cs_to_qap.rs:150-213. */

@@ -51,7 +51,8 @@ pub struct cg_options {
     pub shard_count: i32,
     pub proof_slots: i32,
     pub flags: i32,
-    pub reserved: [i32; 2],
+    pub hw_queues: i32,
+    pub reserved: [i32; 1],
 }
 
 #[repr(C)]
@@ -127,6 +128,7 @@ pub struct cg_load_timings {
 }
 
 pub enum cg_ctx {}
+pub enum cg_partial {}
 pub enum cg_msm_ctx {}
 pub enum cg_qap_ctx {}
 
@@ -193,6 +195,23 @@ extern "C" {
         timings: *mut cg_timings,
     ) -> c_int;
     pub fn cg_witness_map(ctx: *mut cg_ctx, full_assignment: *const u8, h_out: *mut u8) -> c_int;
+    // the same in two calls: the l, a, b1, b2 sums start at once, the h share follows the slice
+    pub fn cg_prove_partial_q_begin(
+        ctx: *mut cg_ctx,
+        full_assignment: *const c_void,
+        assignment_on_device: c_int,
+        r: *const u8,
+        out: *mut *mut cg_partial,
+    ) -> c_int;
+    pub fn cg_partial_witness_map_coset(p: *mut cg_partial, q_out: *mut c_void, q_on_device: c_int) -> c_int;
+    pub fn cg_prove_partial_q_finish(
+        p: *mut cg_partial,
+        q_slice: *const c_void,
+        q_on_device: c_int,
+        out_partials: *mut u8,
+        timings: *mut cg_timings,
+    ) -> c_int;
+    pub fn cg_prove_partial_q_abort(p: *mut cg_partial);
     pub fn cg_domain_size(ctx: *const cg_ctx) -> u64;
     pub fn cg_qap_load(
         out: *mut *mut cg_qap_ctx,

@@ -127,20 +127,24 @@ def test_counter_pass_is_tied_to_the_kernel_sources():
     assert mod.source_fingerprint() == fp
 
 
-def test_content_digest_memo_holds_its_arrays_and_freezes_bases():
+def test_content_digest_memo_holds_its_arrays_and_is_not_kept_for_views_of_writable_buffers():
     """the digest memo kept (id, address, size) of the arrays, which CPython and malloc recycle - a replaced
-    array of the same size could be taken for the old one.  It now holds the arrays and compares by identity; and a view's
-    writable base is frozen with it."""
+    array of the same size could be taken for the old one.  It now holds the arrays and compares by identity.  ADVICE r5
+    (low): the hashed arrays are frozen, their parents are NOT (round 5 froze them too and changed unrelated views of the
+    caller's buffer); a set that contains a view of a still-writable buffer is not memoised - hashed again at every use."""
     import numpy as np
     from crescent_credentials_amd import api
     base = np.arange(64 * 4, dtype=np.uint8)
     view = base[:64]
     held = api._freeze(view, b"abc")
     assert held.same_as((view, held.arrays[1])) and not held.same_as((base[:64], held.arrays[1]))     # another view object: not "the same"
-    assert not view.flags.writeable and not base.flags.writeable
+    assert not view.flags.writeable and base.flags.writeable and not held.stable
     import pytest
     with pytest.raises(ValueError):
-        base[0] = 1
+        view[0] = 1
+    base[0] = 1                                              # the caller's buffer stays the caller's
+    own = np.arange(64, dtype=np.uint8)
+    assert api._freeze(own).stable and not own.flags.writeable
     # a replacing array that lands on the old one's address cannot be confused with it: the memo keeps the old one alive
     rows = [[(1, 0)], [(1, 1)]]
     cm = api.ConstraintMatrices.from_rows(rows, rows, rows, 1, 2)
@@ -152,3 +156,12 @@ def test_content_digest_memo_holds_its_arrays_and_freezes_bases():
     cm.a.coeff[0] ^= 1
     assert api._matrices_key(cm) != k1
     assert cm._content_key[0].arrays[2] is cm.a.coeff and old is not cm.a.coeff
+    # matrices made of VIEWS of a writable buffer: no memo, and a write through the buffer is seen
+    buf = np.zeros(64, np.uint8)
+    buf[0] = 1
+    cm2 = api.ConstraintMatrices.from_rows(rows, rows, rows, 1, 2)
+    cm2.a.coeff = buf[:32]
+    k2 = api._matrices_key(cm2)
+    assert cm2._content_key is None
+    buf[1] = 7
+    assert api._matrices_key(cm2) != k2

@@ -72,6 +72,23 @@ class OracleShard:
         hs = [int.from_bytes(q[i:i + 32], "little") for i in range(0, len(q), 32)]
         return self.prove_partial(w, r, h_slice=hs)
 
+    # the two-call form (cg_prove_partial_q_begin / cg_partial_witness_map_coset / cg_prove_partial_q_finish)
+    def prove_partial_q_begin(self, w, r, on_device=False):
+        shard = self
+        shard.begun = getattr(shard, "begun", 0) + 1
+
+        class Open:
+            def witness_map_coset(self, out_dev=None, out_host=None):
+                return shard.witness_map_coset(w)
+
+            def finish(self, q_slice, q_on_device=False):
+                shard.finished = getattr(shard, "finished", 0) + 1
+                return shard.prove_partial_q(w, q_slice, r)
+
+            def abort(self):
+                shard.aborted = getattr(shard, "aborted", 0) + 1
+        return Open()
+
     def assemble(self, parts, n, r, s):
         o, pk = self.o, self.pk
         acc = [o.G1.jac_infinity() for _ in range(4)]
@@ -169,6 +186,14 @@ def _worker(rank, world, port, q):
             ok = ok and sps.prove(w, int(case["r"], 16), int(case["s"], 16)).hex() == case["proof"]
         ok = ok and sps.all_gathers == sps.scatters == len(g["proofs"]) and getattr(shard_b, "map_calls", 0) == 0
         ok = ok and getattr(shard_b, "coset_calls", 0) == (len(g["proofs"]) if rank == 0 else 0)
+        # the two-call form of the same arrangement: every rank opens the proof (its assignment-driven sums start), the source's
+        # witness map runs on the open proof, the h share follows the scatter; the same golden proofs
+        shard_t = OracleShard(o, pk, _rows(g["matrices"]), g["num_inputs"], g["num_constraints"], g["num_variables"], rank, world)
+        spt = ShardedProver(shard_t, torch.device("cpu"), arrangement="scatter", two_call=True)
+        for case in g["proofs"]:
+            ok = ok and spt.prove(w, int(case["r"], 16), int(case["s"], 16)).hex() == case["proof"]
+        ok = ok and spt.all_gathers == spt.scatters == len(g["proofs"]) == shard_t.begun == shard_t.finished
+        ok = ok and getattr(shard_t, "aborted", 0) == 0 and getattr(shard_t, "coset_calls", 0) == (len(g["proofs"]) if rank == 0 else 0)
         # ... and a STREAM of such proofs, the rank that runs the witness map rotating from job to job (k mod world): scatters
         # from one thread, gathers from another (two groups), three proofs in flight per rank; every proof the golden one, one
         # scatter + one gather per job, and the witness maps spread over the ranks

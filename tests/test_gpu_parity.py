@@ -1077,3 +1077,70 @@ def test_rejected_witnesses_among_proofs_in_flight(cc, oracle):
     finally:
         serial.close(); par.close()
 
+
+
+@pytest.mark.parametrize("n,contig,slots", [(4, False, 1), (8, False, 1), (4, True, 1), (4, False, 3)],
+                         ids=["4-strided", "8-strided", "4-contiguous", "4-strided-throughput-slots"])
+def test_sharded_proof_in_two_calls(cc, oracle, n, contig, slots):
+    """cg_prove_partial_q_begin / cg_partial_witness_map_coset / cg_prove_partial_q_finish: every shard opens the proof (its l, a,
+    b1, b2 partial sums are queued and run), the first shard's witness map runs ON the open proof's working set - a one-slot
+    context has no other - and the h share follows with the slice.  The 384-byte records are the one-call form's, the assembled
+    proof the unsharded context's; satisfying and arbitrary assignments, r = 0, slices in host and in device memory, latency
+    (one slot, five streams) and throughput (several slots, one stream) contexts; abort gives the slot back."""
+    import torch
+    from crescent_credentials_amd import workloads as wl
+    l, m, M = _CPU_SHAPES["log14"]
+    cm, w = wl.synthetic_circuit(83 + n, l, m, M, 0.6, 3, profile="gates")
+    rng = random.Random(18 + n)
+    pk = cc.generate_parameters_with_qap(cm, *[rng.randrange(1, oracle.R) for _ in range(4)])
+    w_bad = _scalars([rng.randrange(oracle.R) for _ in range(M)])
+    whole = cc.Prover(pk, cm)
+    first = cc.Prover(pk, cm, shard_rank=0, shard_count=n, contiguous_h_shards=contig, proof_slots=slots)
+    others = [cc.Prover(pk, cm, shard_rank=k, shard_count=n, contiguous_h_shards=contig, h_scalars_external=True, proof_slots=slots)
+              for k in range(1, n)]
+    shards = [first] + others
+    try:
+        D = whole.domain_size
+        slices = [first.h_scalars_slice(k) for k in range(n)]
+        for wit in (w, w_bad):
+            wd = torch.from_numpy(np.ascontiguousarray(wit)).cuda()
+            for r, s in ((0, 0), (rng.randrange(oracle.R), rng.randrange(oracle.R))):
+                want = whole.prove(wit, r, s).data
+                q_ref = first.witness_map_coset(wit)
+                one_call = b"".join(p.prove_partial_q(wit, q_ref[o * 32:(o + c) * 32], r) for p, (o, c) in zip(shards, slices))
+                # host memory throughout
+                opened = [p.prove_partial_q_begin(wit, r) for p in shards]
+                q = opened[0].witness_map_coset()
+                assert bytes(q) == bytes(q_ref)
+                parts = b"".join(op.finish(q[o * 32:(o + c) * 32]) for op, (o, c) in zip(opened, slices))
+                assert parts == one_call and others[-1].assemble(parts, n, r, s).data == want
+                # device memory throughout
+                qd = torch.empty(D * 32, dtype=torch.uint8, device="cuda")
+                opened = [p.prove_partial_q_begin(wd.data_ptr(), r, on_device=True) for p in shards]
+                opened[0].witness_map_coset(out_dev=qd.data_ptr())
+                parts = b"".join(op.finish(qd.data_ptr() + o * 32, q_on_device=True) for op, (o, c) in zip(opened, slices))
+                assert parts == one_call
+        # an open proof holds its slot; abort gives it back; a bad slice fails the finish and gives it back too
+        r = 5
+        q = first.witness_map_coset(w)
+        o1, c1 = slices[1]
+        for _ in range(slots + 2):
+            others[0].prove_partial_q_begin(w, r).abort()
+        q_bad = q[o1 * 32:(o1 + c1) * 32].copy()
+        q_bad[32 * 2:32 * 3] = np.frombuffer(oracle.R.to_bytes(32, "little"), np.uint8)
+        for _ in range(slots + 1):
+            with pytest.raises(cc.CrescentGpuError):
+                others[0].prove_partial_q_begin(w, r).finish(q_bad)
+        assert others[0].prove_partial_q_begin(w, r).finish(q[o1 * 32:(o1 + c1) * 32]) == others[0].prove_partial_q(w, q[o1 * 32:(o1 + c1) * 32], r)
+        with pytest.raises(cc.CrescentGpuError):
+            others[0].prove_partial_q_begin(w, r).witness_map_coset()                 # no witness-map resources on an external shard
+        with pytest.raises(cc.CrescentGpuError):
+            whole.prove_partial_q_begin(w, r)                                         # needs a sharded context
+        # ... and the slots are all still there: as many open proofs as slots, at once
+        held = [others[0].prove_partial_q_begin(w, r) for _ in range(slots)]
+        outs = [h.finish(q[o1 * 32:(o1 + c1) * 32]) for h in held]
+        assert len(set(outs)) == 1
+    finally:
+        whole.close()
+        for p in shards:
+            p.close()

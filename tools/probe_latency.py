@@ -34,5 +34,20 @@ if shard > 1:
         t0 = time.perf_counter(); p.witness_map_coset(wd.data_ptr(), on_device=True, out_dev=q.data_ptr()); tw.append((time.perf_counter() - t0) * 1e3)
         t0 = time.perf_counter(); ext.prove_partial_q(wd.data_ptr(), q.data_ptr() + off * 32, 5, on_device=True, q_on_device=True); tq.append((time.perf_counter() - t0) * 1e3)
     print("shards", shard, "scatter arrangement: witness map for all shards", round(float(np.median(tw)), 3), "ms; a shard with its slice", round(float(np.median(tq)), 3), "ms")
+    # the two-call form: on the witness-map rank the l, a, b sums are queued first and the witness map runs next to them; on every
+    # rank only the h share is left once the slice has arrived (cg_prove_partial_q_begin / cg_partial_witness_map_coset / _finish)
+    tsrc, tfin = [], []
+    for i in range(13):
+        t0 = time.perf_counter(); op = p.prove_partial_q_begin(wd.data_ptr(), 5, on_device=True); op.witness_map_coset(out_dev=q.data_ptr())
+        t_src = (time.perf_counter() - t0) * 1e3
+        o0, c0 = p.h_scalars_slice(0)
+        op.finish(q.data_ptr() + o0 * 32, q_on_device=True)
+        ope = ext.prove_partial_q_begin(wd.data_ptr(), 5, on_device=True)
+        torch.cuda.synchronize()                       # its l, a, b1, b2 sums are done: what is left is what follows the scatter
+        t0 = time.perf_counter(); ope.finish(q.data_ptr() + off * 32, q_on_device=True); t_fin = (time.perf_counter() - t0) * 1e3
+        if i >= 3:
+            tsrc.append(t_src); tfin.append(t_fin)
+    print("shards", shard, "two-call form: begin + witness map on the source rank", round(float(np.median(tsrc)), 3), "ms; the h share after the slice",
+          round(float(np.median(tfin)), 3), "ms; critical path ~", round(float(np.median(tsrc)) + float(np.median(tfin)), 3), "ms + the scatter")
     ext.close()
 print("shards", shard, "wall ms", round(float(np.median(ws)), 3), "library total_ms", round(float(np.median(ts)), 3), {k: round(v, 3) for k, v in tm.items() if k.endswith("_ms")})

@@ -12,7 +12,7 @@ IV=${1:-8388608}; [ $# -gt 0 ] && shift
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-FLAGS="--steps 20 --warmup 4 --blocks 2 --no-sweep --no-cpu-baseline --no-host-witness --no-check --no-clock-probe --witness device $*"
+FLAGS="--steps 20 --warmup 4 --blocks 2 --headline-only --no-sweep --no-cpu-baseline --no-host-witness --no-check --no-clock-probe --witness device $*"
 timeout 420 rocprofv3 --pc-sampling-beta-enabled --pc-sampling-unit cycles --pc-sampling-method stochastic --pc-sampling-interval $IV \
   --kernel-trace --output-format csv -d "$OUT/raw" -o pcs -- python3 "$ROOT/bench.py" $FLAGS > "$OUT/line.json" 2> "$OUT/run.log"
 echo "rc=$?" >> "$OUT/run.log"

@@ -7,7 +7,7 @@ OUT="$ROOT/$1"; shift
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace -d "$OUT/trace" -o t -- python3 "$ROOT/bench.py" --steps 40 --warmup 8 --blocks 3 --no-sweep --no-cpu-baseline --no-host-witness --no-check --no-clock-probe "$@" > "$OUT/trace_line.json" 2> "$OUT/trace.log"
+rocprofv3 --kernel-trace -d "$OUT/trace" -o t -- python3 "$ROOT/bench.py" --steps 40 --warmup 8 --blocks 3 --headline-only --no-sweep --no-cpu-baseline --no-host-witness --no-check --no-clock-probe "$@" > "$OUT/trace_line.json" 2> "$OUT/trace.log"
 T=$(find "$OUT/trace" -name '*.db' | head -1)
 python3 "$ROOT/tools/rocpd_stats.py" "$T" "$OUT/kernel_stats.md" > /dev/null
 python3 "$ROOT/tools/rocpd_busy.py" "$T" > "$OUT/busy.txt" 2>&1

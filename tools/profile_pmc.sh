@@ -7,7 +7,7 @@ OUT="$ROOT/$1"; KEY="$2"; shift; shift
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-FLAGS="--steps 6 --warmup 2 --blocks 1 --no-sweep --no-cpu-baseline --no-host-witness --no-check --no-clock-probe --inflight 1 --mode throughput --witness device $*"
+FLAGS="--steps 6 --warmup 2 --blocks 1 --headline-only --no-sweep --no-cpu-baseline --no-host-witness --no-check --no-clock-probe --inflight 1 --mode throughput --witness device $*"
 for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
   rocprofv3 --pmc $C -d "$OUT/$C" -o p -- python3 "$ROOT/bench.py" $FLAGS > "$OUT/$C.line.json" 2> "$OUT/$C.log"
 done

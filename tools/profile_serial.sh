@@ -8,7 +8,7 @@ OUT="$ROOT/$1"; shift
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-FLAGS="--steps 8 --warmup 2 --blocks 1 --no-sweep --no-cpu-baseline --no-host-witness --no-check --no-clock-probe --inflight 1 --mode throughput --witness device $*"
+FLAGS="--steps 8 --warmup 2 --blocks 1 --headline-only --no-sweep --no-cpu-baseline --no-host-witness --no-check --no-clock-probe --inflight 1 --mode throughput --witness device $*"
 rocprofv3 --kernel-trace -d "$OUT/trace" -o t -- python3 "$ROOT/bench.py" $FLAGS > "$OUT/trace_line.json" 2> "$OUT/trace.log"
 rocprofv3 --pmc SQ_INSTS_VALU -d "$OUT/pmc" -o p -- python3 "$ROOT/bench.py" $FLAGS > "$OUT/pmc_line.json" 2> "$OUT/pmc.log"
 T=$(find "$OUT/trace" -name '*.db' | head -1); P=$(find "$OUT/pmc" -name '*.db' | head -1)

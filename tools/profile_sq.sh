@@ -8,7 +8,7 @@ OUT="$ROOT/$1"; shift
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-FLAGS="--steps 4 --warmup 2 --blocks 1 --no-sweep --no-cpu-baseline --no-host-witness --no-check --no-clock-probe --inflight 1 --mode throughput --witness device $*"
+FLAGS="--steps 4 --warmup 2 --blocks 1 --headline-only --no-sweep --no-cpu-baseline --no-host-witness --no-check --no-clock-probe --inflight 1 --mode throughput --witness device $*"
 i=0
 : > "$OUT/sq_counters.md"
 echo "SQ counters per launch (steady state), serial streams, one proof in flight: \`rocprofv3 --pmc <set> -- python3 bench.py $FLAGS\` (one pass per set), summarised by tools/rocpd_counters.py" >> "$OUT/sq_counters.md"

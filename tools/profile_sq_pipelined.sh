@@ -11,7 +11,7 @@ OUT="$ROOT/$1"; shift
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-FLAGS="--steps 20 --warmup 4 --blocks 2 --no-sweep --no-cpu-baseline --no-host-witness --no-check --no-clock-probe --witness device $*"
+FLAGS="--steps 20 --warmup 4 --blocks 2 --headline-only --no-sweep --no-cpu-baseline --no-host-witness --no-check --no-clock-probe --witness device $*"
 i=0
 DBS=""
 for SET in "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES" \

@@ -17,7 +17,7 @@ tools/profile_pipeline_capacity.sh $O/pipe > /dev/null 2>&1
 tools/profile_sq.sh $O/sq > /dev/null 2>&1
 # one counter pass over the PIPELINED run (program directly after --; kernels are serialised by the counter collection,
 # so these are stand-alone figures of the launches the pipelined run makes, segment lengths included)
-( export TMPDIR=/tmp; cd /tmp; rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OLDPWD/$O/sqpipe -o p -- python3 $OLDPWD/bench.py --steps 20 --warmup 4 --blocks 2 --no-sweep --no-cpu-baseline --no-host-witness --no-check --no-clock-probe > $OLDPWD/$O/sqpipe.line.json 2> $OLDPWD/$O/sqpipe.log )
+( export TMPDIR=/tmp; cd /tmp; rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OLDPWD/$O/sqpipe -o p -- python3 $OLDPWD/bench.py --steps 20 --warmup 4 --blocks 2 --headline-only --no-sweep --no-cpu-baseline --no-host-witness --no-check --no-clock-probe > $OLDPWD/$O/sqpipe.line.json 2> $OLDPWD/$O/sqpipe.log )
 DB=$(find $O/sqpipe -name '*.db' | head -1); [ -n "$DB" ] && python3 tools/rocpd_counters.py "$DB" $O/sq_counters_pipelined_run.md > /dev/null; rm -rf $O/sqpipe
 python bench.py --gpus 2 --backend gloo --steps 24 --warmup 4 > $O/bench_2rank_gloo.json 2> $O/bench_2rank_gloo.err
 python bench.py --gpus 2 --backend nccl --allow-shared-gpu --steps 24 --warmup 4 --no-host-witness > $O/bench_2rank_nccl_one_gpu.json 2> $O/bench_2rank_nccl_one_gpu.err
