@@ -882,7 +882,9 @@ class Groth16:
     def _prover_for(cls, pk: ProvingKey, matrices: ConstraintMatrices) -> Prover:
         """a LEASED resident prover for this key and these matrices: the caller must `_unlease()` it"""
         cls._cache.max_cached = cls.MAX_CACHED
-        return cls._cache.lease((_pk_key(pk), _matrices_key(matrices)), lambda: Prover(pk, matrices))
+        # the load is STAGED (CG_FLAG_STAGED_LOAD): `Groth16::prove` is what create_client_state calls once per credential
+        # (creds/src/lib.rs:281-283), so the first proof must not wait for tables that only pay off over many
+        return cls._cache.lease((_pk_key(pk), _matrices_key(matrices)), lambda: Prover(pk, matrices, staged_load=True))
 
     @classmethod
     def create_proof_with_reduction_and_matrices(cls, pk: ProvingKey, r: int, s: int, matrices: ConstraintMatrices,

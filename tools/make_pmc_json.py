@@ -5,11 +5,25 @@ usage: make_pmc_json.py <workload-key> fetch.db write.db valu.db <command string
 import json, os, re, sqlite3, sys
 
 
+def short(name):
+    """a kernel's name as tools/isa_mix.py writes it: no return type, no argument list"""
+    d = re.sub(r"^void ", "", name)
+    depth = 0
+    for i, ch in enumerate(d):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            return d[:i]
+    return d
+
+
 def rows(db, ctr):
     r = sqlite3.connect(db).execute("select kernel_name, counter_name, value, start, dispatch_id from counters_collection").fetchall()
     t_tab = max([x[3] for x in r if "k_table_next" in x[0]] + [0])
     first = min(x[3] for x in r if "k_w_to29" in x[0] and x[3] > t_tab)
-    r = [x for x in r if x[3] >= first and x[1] == ctr]
+    r = [(short(x[0]),) + tuple(x[1:]) for x in r if x[3] >= first and x[1] == ctr]
     nproofs = len(set(x[4] for x in r if "k_w_to29" in x[0]))
     return r, nproofs
 
