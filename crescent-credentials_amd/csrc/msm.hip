@@ -1480,6 +1480,12 @@ static void part_bits(int c, int W, bool precomputed, int& bits1, int& bits2) {
     if (key_bits < 1) key_bits = 1;
     if (key_bits <= PART_MAX_BITS) { bits1 = key_bits; bits2 = 0; return; }
     bits1 = (key_bits + 1) / 2;
+    // tuning builds, CG_PART_BITS1_DELTA=-2..2 (experiment): fewer level-1 bins write longer runs per bin and sub-tile, more of them
+    // leave shorter runs at level 2
+    if (const char* e = CG_TUNE_ENV("PART_BITS1_DELTA")) {
+        const int b = bits1 + atoi(e);
+        if (b >= 1 && b <= PART_MAX_BITS && key_bits - b >= 1 && key_bits - b <= PART_MAX_BITS) bits1 = b;
+    }
     bits2 = key_bits - bits1;
 }
 
