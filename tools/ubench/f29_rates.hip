@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 #include "../../crescent-credentials_amd/csrc/curve29.hpp"
 using namespace cg;
@@ -43,6 +44,62 @@ __global__ void __launch_bounds__(256) k_add(const uint32_t* pts, uint32_t* out,
     store_acc(out + (size_t)t * ACC, acc, inf);
 }
 
+// the same two loops timed by every wave itself in shader cycles (clock64): cycles per operation per SIMD = T / (waves per SIMD x
+// iterations), independent of the clock the chip holds.  ./f29_rates --cycles
+__global__ void __launch_bounds__(256) k_fq_mul_cyc(uint32_t* io, unsigned long long* cyc, int iters) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    Fq29 a, b; for (int i = 0; i < 9; ++i) { a.l[i] = io[t * 18 + i] & M29; b.l[i] = io[t * 18 + 9 + i] & M29; }
+    const unsigned long long c0 = clock64();
+    for (int i = 0; i < iters; ++i) { a = mul(a, b); b = mul(b, a); }
+    const unsigned long long c1 = clock64();
+    if ((threadIdx.x & 63) == 0) cyc[t >> 6] = c1 - c0;
+    for (int i = 0; i < 9; ++i) io[t * 18 + i] = a.l[i] + b.l[i];
+}
+__global__ void __launch_bounds__(256) k_madd_cyc(const uint32_t* table, uint32_t* out, unsigned long long* cyc, int iters, int npts) {
+    constexpr int ACC = Words29<Fq29>::ACC;
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    XYZZ29<Fq29> acc; bool inf = true;
+    const unsigned long long c0 = clock64();
+    for (int i = 0; i < iters; ++i) {
+        Affine29<Fq29> p = load_table_point<Fq29>(table, (uint32_t)((t * 7 + i * 13) % npts), (i & 1) != 0);
+        madd29(acc, inf, p);
+    }
+    const unsigned long long c1 = clock64();
+    if ((threadIdx.x & 63) == 0) cyc[t >> 6] = c1 - c0;
+    store_acc(out + (size_t)t * ACC, acc, inf);
+}
+static double mean_cycles(unsigned long long* d_cyc, int waves) {
+    std::vector<unsigned long long> h(waves);
+    CHECK(hipMemcpy(h.data(), d_cyc, (size_t)waves * 8, hipMemcpyDeviceToHost));
+    double s = 0; for (auto c : h) s += (double)c;
+    return s / waves;
+}
+static int cycles_mode() {
+    const int NPTS = 4096;
+    std::vector<uint32_t> h(NPTS * 72);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = (uint32_t)(i * 2654435761u + 12345u) & 0x0fffffffu;
+    uint32_t *d_tab, *d_out, *d_io; unsigned long long* d_cyc;
+    CHECK(hipMalloc(&d_tab, h.size() * 4)); CHECK(hipMemcpy(d_tab, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&d_out, (size_t)256 * 8 * 256 * 36 * 4)); CHECK(hipMalloc(&d_io, (size_t)256 * 8 * 256 * 18 * 4));
+    CHECK(hipMalloc(&d_cyc, (size_t)256 * 8 * 4 * 8));
+    CHECK(hipMemset(d_io, 0x5a, (size_t)256 * 8 * 256 * 18 * 4));
+    printf("{\"what\": \"shader cycles per operation per SIMD (clock64 around each wave's loop; L2-resident operands, no HBM)\", \"waves_per_simd\": [1, 2, 4, 8], ");
+    double mulc[4], maddc[4];
+    const int wps[4] = {1, 2, 4, 8};
+    for (int i = 0; i < 4; ++i) {
+        const int blocks = 256 * wps[i], waves = blocks * 4;
+        k_fq_mul_cyc<<<blocks, 256>>>(d_io, d_cyc, 20); CHECK(hipDeviceSynchronize());
+        k_fq_mul_cyc<<<blocks, 256>>>(d_io, d_cyc, 200); CHECK(hipDeviceSynchronize());
+        mulc[i] = mean_cycles(d_cyc, waves) / (wps[i] * 400.0);
+        k_madd_cyc<<<blocks, 256>>>(d_tab, d_out, d_cyc, 8, NPTS); CHECK(hipDeviceSynchronize());
+        k_madd_cyc<<<blocks, 256>>>(d_tab, d_out, d_cyc, 64, NPTS); CHECK(hipDeviceSynchronize());
+        maddc[i] = mean_cycles(d_cyc, waves) / (wps[i] * 64.0);
+    }
+    printf("\"fq_mul_cycles\": [%.1f, %.1f, %.1f, %.1f], \"g1_madd_cycles\": [%.1f, %.1f, %.1f, %.1f]}\n", mulc[0], mulc[1], mulc[2], mulc[3],
+           maddc[0], maddc[1], maddc[2], maddc[3]);
+    return 0;
+}
+
 template <class K, class... A>
 static float timeit(K kern, dim3 g, dim3 b, A... args) {
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -68,6 +125,7 @@ __global__ void __launch_bounds__(256) k_madd_gather(const uint32_t* table, uint
 }
 
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "--cycles")) return cycles_mode();
     {
         uint32_t* big; uint32_t *o2;
         const uint32_t NP = 27u * 1000 * 1000;   // 1.7 GB: the h-query table at c = 20

@@ -150,6 +150,17 @@ __global__ void __launch_bounds__(256) k_rate_cycles(uint32_t* out, unsigned lon
         } else if (KIND == 9) {
             REP64(asm volatile("v_lshrrev_b32 %0, 3, %1\n v_lshrrev_b32 %1, 3, %2\n v_lshrrev_b32 %2, 3, %3\n v_lshrrev_b32 %3, 3, %0\n"
                                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+        } else if (KIND == 10) {      // ONE dependent chain of multiply-adds: a product's column sum as field29.hpp writes it
+            REP64(asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %2, %0\n v_mad_u64_u32 %0, s[10:11], %2, %3, %0\n"
+                               "v_mad_u64_u32 %0, s[10:11], %3, %4, %0\n v_mad_u64_u32 %0, s[10:11], %4, %1, %0\n"
+                               : "+v"(d0) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "s10", "s11");)
+        } else if (KIND == 11) {      // TWO interleaved chains
+            REP64(asm volatile("v_mad_u64_u32 %0, s[10:11], %2, %3, %0\n v_mad_u64_u32 %1, s[10:11], %3, %4, %1\n"
+                               "v_mad_u64_u32 %0, s[10:11], %4, %5, %0\n v_mad_u64_u32 %1, s[10:11], %5, %2, %1\n"
+                               : "+v"(d0), "+v"(d1) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "s10", "s11");)
+        } else if (KIND == 12) {      // ONE dependent chain of simple 32-bit adds
+            REP64(asm volatile("v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %2\n v_add_u32 %0, %0, %3\n v_add_u32 %0, %0, %1\n"
+                               : "+v"(a0) : "v"(a1), "v"(a2), "v"(a3));)
         }
     }
     const unsigned long long c1 = clock64();
@@ -158,8 +169,8 @@ __global__ void __launch_bounds__(256) k_rate_cycles(uint32_t* out, unsigned lon
 }
 
 template <int KIND>
-double cycles_per_instr(uint32_t* d_out, unsigned long long* d_cyc, double* wall_ms) {
-    const int blocks = 256 * 4, threads = 256, iters = 40, waves = blocks * threads / 64;
+double cycles_per_instr(uint32_t* d_out, unsigned long long* d_cyc, double* wall_ms, int waves_per_simd = 4) {
+    const int blocks = 256 * waves_per_simd, threads = 256, iters = 40, waves = blocks * threads / 64;
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     k_rate_cycles<KIND><<<blocks, threads>>>(d_out, d_cyc, 4, 1);
@@ -175,7 +186,7 @@ double cycles_per_instr(uint32_t* d_out, unsigned long long* d_cyc, double* wall
     double sum = 0;
     for (auto c : h) sum += (double)c;
     const double n_instr = (double)iters * 64.0 * 4.0;          // per wave
-    return (sum / waves) / (4.0 * n_instr);
+    return (sum / waves) / ((double)waves_per_simd * n_instr);
 }
 
 // The same multiply-add loop, long: ~60 ms of nothing but v_mad_u64_u32 on every SIMD, eight waves deep.  Its wall time gives
@@ -215,14 +226,25 @@ static void sustained_mad(uint32_t* d_out, unsigned long long* d_cyc, double* g_
 static int json_mode() {
     int ncu = 0;
     CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
-    uint32_t* d_out; CHECK(hipMalloc(&d_out, 256 * 4 * 256 * 4));
-    unsigned long long* d_cyc; CHECK(hipMalloc(&d_cyc, 256 * 4 * 4 * sizeof(unsigned long long)));
+    uint32_t* d_out; CHECK(hipMalloc(&d_out, 256 * 8 * 256 * 4));
+    unsigned long long* d_cyc; CHECK(hipMalloc(&d_cyc, 256 * 8 * 4 * sizeof(unsigned long long)));
     double w_mad = 0;
     const double mad_u = cycles_per_instr<0>(d_out, d_cyc, &w_mad), mad_i = cycles_per_instr<1>(d_out, d_cyc, nullptr);
     const double addc = cycles_per_instr<2>(d_out, d_cyc, nullptr), add3 = cycles_per_instr<3>(d_out, d_cyc, nullptr);
     const double shr64 = cycles_per_instr<4>(d_out, d_cyc, nullptr), lshladd64 = cycles_per_instr<5>(d_out, d_cyc, nullptr);
     const double mov = cycles_per_instr<6>(d_out, d_cyc, nullptr), and32 = cycles_per_instr<7>(d_out, d_cyc, nullptr);
     const double add32 = cycles_per_instr<8>(d_out, d_cyc, nullptr), shr32 = cycles_per_instr<9>(d_out, d_cyc, nullptr);
+    // how the issue rate depends on the waves a SIMD holds and on the independent chains a wave offers: a dependent instruction
+    // cannot issue before its predecessor's result is there, so a wave with ONE chain issues once per latency, and a SIMD
+    // needs latency / issue-cycles such waves (or chains) to stay busy
+    double dep[3][4];
+    const int wps[4] = {1, 2, 4, 8};
+    for (int i = 0; i < 4; ++i) {
+        dep[0][i] = cycles_per_instr<10>(d_out, d_cyc, nullptr, wps[i]);
+        dep[1][i] = cycles_per_instr<11>(d_out, d_cyc, nullptr, wps[i]);
+        dep[2][i] = cycles_per_instr<0>(d_out, d_cyc, nullptr, wps[i]);
+    }
+    const double add_chain_1 = cycles_per_instr<12>(d_out, d_cyc, nullptr, 1), add_chain_4 = cycles_per_instr<12>(d_out, d_cyc, nullptr, 4);
     double sus_g = 0, sus_clk = 0, sus_ms = 0;
     sustained_mad(d_out, d_cyc, &sus_g, &sus_clk, &sus_ms);
     (void)w_mad;
@@ -230,6 +252,10 @@ static int json_mode() {
            "\"cycles_per_wave_instr\": %.3f, \"what\": \"v_mad_u64_u32 only, eight waves per SIMD on every SIMD, one launch of that length: the rate "
            "the chip sustains on dense 32x32+64 multiply-adds and the shader clock (clock64 over wall time) it holds meanwhile\"}, ", ncu, sus_g,
            sus_clk, sus_ms, sus_clk * 1e9 * 1024.0 / (sus_g * 1e9));
+    printf("\"mad64_cycles_by_chains_and_waves_per_simd\": {\"waves_per_simd\": [1, 2, 4, 8], \"one_chain\": [%.3f, %.3f, %.3f, %.3f], "
+           "\"two_chains\": [%.3f, %.3f, %.3f, %.3f], \"four_chains\": [%.3f, %.3f, %.3f, %.3f], \"add32_one_chain_1_and_4_waves\": [%.3f, %.3f]}, ",
+           dep[0][0], dep[0][1], dep[0][2], dep[0][3], dep[1][0], dep[1][1], dep[1][2], dep[1][3], dep[2][0], dep[2][1], dep[2][2], dep[2][3],
+           add_chain_1, add_chain_4);
     printf("\"cycles_per_wave_instr\": {\"mad64\": %.3f, \"other\": %.3f, \"simple32\": %.3f}, "
            "\"per_instruction\": {\"v_mad_u64_u32\": %.3f, \"v_mad_i64_i32\": %.3f, \"v_add_co_u32+v_addc_co_u32\": %.3f, \"v_add3_u32\": %.3f, "
            "\"v_lshrrev_b64\": %.3f, \"v_lshl_add_u64\": %.3f, \"v_mov_b32\": %.3f, \"v_and_b32\": %.3f, \"v_add_u32\": %.3f, \"v_lshrrev_b32\": %.3f}, "
