@@ -565,6 +565,9 @@ static void staged_worker(cg_ctx* c) {
             build_h_bases_folded(bh, c->bh.table.p, c->bh.valid.p, D - 1, c->logD, 0, 1, D, wb > 0 ? wb : msm_default_window(D, true), st,
                                  &ms_fold, &ms_tables);
             stop();
+            // tuning builds, CG_FAULT_STAGED=1 (fault injection for tests/fault_retune_child.py): fail here as an allocation of the
+            // final tables would.  The shipped library carries no such switch.
+            if (const char* f = CG_TUNE_ENV("FAULT_STAGED")) if (f[0] == '1') throw HipError(CG_ERR_OUT_OF_MEMORY, "injected: out of device memory while building the final arrangement");
             build_l_bases_folded(bl, c->bh.table.p, c->bh.valid.p, D - 1, c->logD, c->bl.table.p, c->bl.valid.p, l, M, c->c_transposed, c->m,
                                  c->dom.vanishing_inv, 0, M,
                                  [&] { return window_for(M, 0); }, st, &ms_fold, &ms_tables);

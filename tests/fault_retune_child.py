@@ -64,6 +64,25 @@ def main():
         assert p2.prove(w, 5, 6).data == want and p2.prove(w, 5, 6).data == want and p2.info()["tuned"] == 1
     finally:
         p2.close()
+    # CG_FAULT_STAGED=1: the WORKER of a staged load fails while it builds the final arrangement (as an allocation of the final
+    # tables would beside another tenant of the GPU).  The context keeps proving in the warm-up arrangement - the right bytes,
+    # from several callers - cg_ctx_wait_ready reports the failure with its message, and the context frees cleanly.
+    os.environ["CG_FAULT_STAGED"] = "1"
+    try:
+        p3 = cc.Prover(pk, cm, proof_slots=4, staged_load=True)
+        assert p3.prove(w, 5, 6).data == want
+        try:
+            p3.wait_ready(120_000)
+            raise AssertionError("wait_ready did not report the worker's failure")
+        except cc.CrescentGpuError as e:
+            assert e.code == -4 and "warm-up arrangement" in str(e) and "injected" in str(e)
+        lt, info = p3.load_timings(), p3.info()
+        assert lt["staged"] == 1 and lt["ready"] == 0 and lt["background_status"] == -4 and info["warmup"] == 1
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            assert all(x == want for x in ex.map(lambda _: p3.prove(w, 5, 6).data, range(12)))
+        p3.close()
+    finally:
+        del os.environ["CG_FAULT_STAGED"]
     print("FAULT-RETUNE-OK")
 
 

@@ -23,4 +23,11 @@ python bench.py --gpus 2 --backend gloo --steps 24 --warmup 4 > $O/bench_2rank_g
 python bench.py --gpus 2 --backend nccl --allow-shared-gpu --steps 24 --warmup 4 --no-host-witness > $O/bench_2rank_nccl_one_gpu.json 2> $O/bench_2rank_nccl_one_gpu.err
 for s in 1 2 4 8; do python tools/probe_latency.py $s 2>/dev/null | cut -c1-330; done > $O/latency.txt
 python tools/soak.py 12000 16 > $O/soak.txt 2>&1; tail -1 $O/soak.txt
+# round 6: the clock the chip holds under each kind of load, the issue rates in shader cycles, the cold start through the C caller
+python tools/probe_clock_vs_load.py 3 > $O/clock_vs_load.txt 2>&1
+tools/ubench/valu_rates --json > $O/valu_rates.json 2>&1
+tools/ubench/f29_rates --cycles > $O/f29_cycles.json 2>&1
+python -m pytest tests/test_gpu_cold_start.py -q -s -k "files_to_client_state" 2>&1 | grep "cold start" > $O/cold_start_c_caller.txt
+# every bench line of this run goes through tools/line_value.py: a line marked `incomplete` (printed by the watchdog) is refused
+for f in $O/bench_*.json; do python tools/line_value.py $(basename $f .json) < $f; done | tee $O/lines_checked.txt
 ls -la $O $O/serial $O/pipe $O/pmc $O/sq
