@@ -1057,6 +1057,32 @@ def main():
                                 "proof, the scatter, cg_prove_partial_q_finish with the slice (the h share)"}
                     assert same_t, "the two-call scatter arrangement's proof differs from the unsharded one"
                     sc_ctx.close()
+                    # ... and with the witness map in two halves: rank 0 computes the a side, rank 1 the b side at the same time, each
+                    # scatters its own, every shard multiplies its two slices and adds the h share (ranks 0 and 1 hold witness-map memory)
+                    if world >= 2:
+                        sh_ctx = cc.Prover(pk_s, cm_s, device=local_rank, window_bits=a.window, shard_rank=rank, shard_count=world,
+                                           h_scalars_external=(rank > 1))
+                        sph = ShardedProver(sh_ctx, dev, group=grp, arrangement="scatter", two_call=True, split_map=True)
+                        for _ in range(3):
+                            sph.prove_dev(ws_s[0].data_ptr(), srng.randrange(R), srng.randrange(R))
+                        barrier_sync(world)
+                        sph.reset_breakdown()
+                        t_start = time.perf_counter()
+                        for k in range(a.sharded_steps):
+                            sph.prove_dev(ws_s[k % len(ws_s)].data_ptr(), srng.randrange(R), srng.randrange(R))
+                        torch.cuda.synchronize()
+                        barrier_sync(world)
+                        dsh_ = max_over_ranks(time.perf_counter() - t_start, world)
+                        r_, s_ = srng.randrange(R), srng.randrange(R)
+                        same_h = sph.prove_dev(ws_s[0].data_ptr(), r_, s_).data == ref_s.prove_dev(ws_s[0].data_ptr(), r_, s_).data
+                        sh["arrangements"]["scatter_two_halves"] = {
+                            "ms_per_proof": round(dsh_ / a.sharded_steps * 1e3, 3), "collectives_per_proof": 3,
+                            "ms_breakdown_rank0": sph.breakdown_ms(), "bytes_identical_to_unsharded": bool(same_h),
+                            "what": "cg_prove_partial_q_begin everywhere; rank 0 computes vinv·a on the coset, rank 1 b on the coset (one sparse "
+                                    "product + two transforms each, at the same time); two scatters; cg_prove_partial_q_finish2 multiplies the "
+                                    "slices and adds the h share"}
+                        assert same_h, "the two-halves scatter arrangement's proof differs from the unsharded one"
+                        sh_ctx.close()
                 except AssertionError:
                     raise
                 except Exception as e:

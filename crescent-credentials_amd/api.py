@@ -130,6 +130,9 @@ _SIGNATURES = {
     "cg_partial_witness_map_coset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "cg_prove_partial_q_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(CgTimings)]),
     "cg_prove_partial_q_abort": (None, [C.c_void_p]),
+    "cg_witness_map_coset_half": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "cg_partial_witness_map_coset_half": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "cg_prove_partial_q_finish2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(CgTimings)]),
     "cg_host_alloc": (C.c_void_p, [C.c_uint64]),
     "cg_host_free": (None, [C.c_void_p]),
     "cg_host_register": (C.c_int, [C.c_void_p, C.c_uint64]),
@@ -374,6 +377,31 @@ class OpenPartial:
         _check(lib().cg_partial_witness_map_coset(self._h, _ptr(q), 0))
         return q
 
+    def witness_map_coset_half(self, which: int, out_dev: Optional[int] = None, out_host: Optional[int] = None):
+        """cg_partial_witness_map_coset_half: ONE side of the coset values (which = 0: vinv·a, 1: b) for this proof's assignment"""
+        if out_dev is not None:
+            _check(lib().cg_partial_witness_map_coset_half(self._h, which, C.c_void_p(int(out_dev)), 1))
+            return None
+        if out_host is not None:
+            _check(lib().cg_partial_witness_map_coset_half(self._h, which, C.c_void_p(int(out_host)), 0))
+            return None
+        q = np.zeros(self._prover.domain_size * 32, dtype=np.uint8)
+        _check(lib().cg_partial_witness_map_coset_half(self._h, which, _ptr(q), 0))
+        return q
+
+    def finish2(self, a_slice, b_slice, on_device: bool = False, timings: bool = False):
+        """cg_prove_partial_q_finish2: the h share from this shard's slices of BOTH sides (their products are the h scalars)"""
+        out = np.zeros(384, dtype=np.uint8)
+        if on_device:
+            ap, bp = C.c_void_p(int(a_slice)), C.c_void_p(int(b_slice))
+        else:
+            a, b = _u8(a_slice), _u8(b_slice)
+            ap, bp = C.c_void_p(_ptr(a) if a.size else _ptr(out)), C.c_void_p(_ptr(b) if b.size else _ptr(out))
+        tm = CgTimings()
+        h, self._h = self._h, None
+        _check(lib().cg_prove_partial_q_finish2(h, ap, bp, 1 if on_device else 0, _ptr(out), C.byref(tm) if timings else None))
+        return (out.tobytes(), tm.as_dict()) if timings else out.tobytes()
+
     def finish(self, q_slice, q_on_device: bool = False, timings: bool = False):
         """cg_prove_partial_q_finish: the h share with this shard's slice; -> the 384-byte record.  The handle is gone afterwards,
         whether the call succeeded or not."""
@@ -588,6 +616,25 @@ class Prover:
             return None
         q = np.zeros(self.domain_size * 32, dtype=np.uint8)
         _check(lib().cg_witness_map_coset(self._h, ptr, 1 if on_device else 0, _ptr(q), 0))
+        return q
+
+    def witness_map_coset_half(self, assignment, which: int, on_device: bool = False, out_dev: Optional[int] = None,
+                               out_host: Optional[int] = None):
+        """cg_witness_map_coset_half: ONE side of the coset values - which = 0: vinv·a(g w^j), 1: b(g w^j) - as plain canonical
+        integers, laid out like witness_map_coset's output; q is their product mod r"""
+        if on_device:
+            ptr = C.c_void_p(int(assignment))
+        else:
+            w = _u8(assignment, self.num_variables * 32)
+            ptr = C.c_void_p(_ptr(w))
+        if out_dev is not None:
+            _check(lib().cg_witness_map_coset_half(self._h, ptr, 1 if on_device else 0, which, C.c_void_p(int(out_dev)), 1))
+            return None
+        if out_host is not None:
+            _check(lib().cg_witness_map_coset_half(self._h, ptr, 1 if on_device else 0, which, C.c_void_p(int(out_host)), 0))
+            return None
+        q = np.zeros(self.domain_size * 32, dtype=np.uint8)
+        _check(lib().cg_witness_map_coset_half(self._h, ptr, 1 if on_device else 0, which, _ptr(q), 0))
         return q
 
     def assemble(self, partials: bytes, n_shards: int, r: int, s: int) -> Proof:

@@ -133,6 +133,7 @@ struct ProofSlot {
     MsmEngine<Fq> eh, el, ea, eb1;
     MsmEngine<Fq2> eb2;
     DevBuf<Fr> h_canon;
+    DevBuf<Fr> q2;                     // cg_prove_partial_q_finish2: the second side's slice when it arrives in host memory (made on first use)
     const Fr* knock_h = nullptr;       // tuning builds (KNOCK & 16): the h scalars of this slot's first proof, reused
     Wm29Buffers wm;
     hipStream_t st[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // 0: witness map + h, 1: l, 2: a, 3: b1, 4: b2
@@ -1449,6 +1450,25 @@ struct cg_partial {
     }
 };
 
+// all coset values (half = 0) or one side of them (1: vinv·a, 2: b) for `w_dev`, on the slot's stream 0, shard-major for strided
+// shards, to host or device memory; waits for them.  -> CG_OK or CG_ERR_INVALID_ARGUMENT (a non-canonical assignment element)
+static int coset_values_to(cg_ctx* ctx, ProofSlot* S, const Fr* w_dev, int half, void* q_out, int q_on_device) {
+    hipStream_t s0 = S->st[0];
+    wm29_run(ctx->wdom, ctx->A, ctx->B, ctx->C, ctx->dA, ctx->dB, ctx->dC, S->wm, w_dev, ctx->M, ctx->m, ctx->l, S->h_canon.p, s0, true, nullptr, half);
+    const Fr* src = S->h_canon.p;
+    if (ctx->h_strided) {        // shard-major: shard p's scalars q_{p + k·count} become the contiguous slice p
+        Fr* tmp = reinterpret_cast<Fr*>(half == 1 ? S->wm.vb.p : S->wm.va.p);      // a vector the half just computed does not use
+        if (!half) tmp = reinterpret_cast<Fr*>(S->wm.vt.p);
+        k_shard_major<<<ceil_div(ctx->D, 256), 256, 0, s0>>>(S->h_canon.p, tmp, ctx->D, (uint32_t)ctx->shard_count);
+        CG_KERNEL_CHECK();
+        src = tmp;
+    }
+    CG_HIP(hipMemcpyAsync(q_out, src, ctx->D * 32, q_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s0));
+    CG_HIP(hipStreamSynchronize(s0));
+    if (S->wm.h_bad_input.p[0]) return fail(CG_ERR_INVALID_ARGUMENT, "full_assignment holds a value >= the scalar field modulus");
+    return CG_OK;
+}
+
 extern "C" int cg_prove_partial_q_begin(cg_ctx* ctx, const void* full_assignment, int assignment_on_device, const uint8_t r[32], cg_partial** out) {
     if (!ctx || !full_assignment || !r || !out) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
@@ -1514,37 +1534,30 @@ extern "C" int cg_prove_partial_q_begin(cg_ctx* ctx, const void* full_assignment
     }
 }
 
-extern "C" int cg_partial_witness_map_coset(cg_partial* p, void* q_out, int q_on_device) {
+static int partial_coset_values(cg_partial* p, int half, void* q_out, int q_on_device) {
     if (!p || !p->c || !p->S || !q_out) return fail(CG_ERR_INVALID_ARGUMENT, "null argument or a closed handle");
     cg_ctx* ctx = p->c;
     if (ctx->external_q) return fail(CG_ERR_INVALID_ARGUMENT, "context loaded with CG_FLAG_H_SCALARS_EXTERNAL holds no witness-map resources");
     try {
         CG_HIP(hipSetDevice(ctx->device));
-        ProofSlot* S = p->S;
-        hipStream_t s0 = S->st[0];
-        // all coset values, natural order, then shard-major for strided shards (as cg_witness_map_coset)
-        wm29_run(ctx->wdom, ctx->A, ctx->B, ctx->C, ctx->dA, ctx->dB, ctx->dC, S->wm, p->w_dev, ctx->M, ctx->m, ctx->l, S->h_canon.p, s0, true, nullptr);
-        const Fr* src = S->h_canon.p;
-        if (ctx->h_strided) {
-            Fr* tmp = reinterpret_cast<Fr*>(S->wm.vt.p);
-            k_shard_major<<<ceil_div(ctx->D, 256), 256, 0, s0>>>(S->h_canon.p, tmp, ctx->D, (uint32_t)ctx->shard_count);
-            CG_KERNEL_CHECK();
-            src = tmp;
-        }
-        CG_HIP(hipMemcpyAsync(q_out, src, ctx->D * 32, q_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s0));
-        CG_HIP(hipStreamSynchronize(s0));
-        if (S->wm.h_bad_input.p[0]) return fail(CG_ERR_INVALID_ARGUMENT, "full_assignment holds a value >= the scalar field modulus");
-        return CG_OK;
+        return coset_values_to(ctx, p->S, p->w_dev, half, q_out, q_on_device);
     } catch (...) {
         return translate_exception();
     }
 }
+extern "C" int cg_partial_witness_map_coset(cg_partial* p, void* q_out, int q_on_device) { return partial_coset_values(p, 0, q_out, q_on_device); }
+extern "C" int cg_partial_witness_map_coset_half(cg_partial* p, int which, void* out, int out_on_device) {
+    if (which != 0 && which != 1) return fail(CG_ERR_INVALID_ARGUMENT, "which must be 0 (the a side) or 1 (the b side)");
+    return partial_coset_values(p, which + 1, out, out_on_device);
+}
 
-extern "C" int cg_prove_partial_q_finish(cg_partial* p, const void* q_slice, int q_on_device, uint8_t out_partials[384], cg_timings* timings) {
+// q_slice: this shard's h scalars; or, with b_slice, the a side's slice, the h scalars being the products of the two
+static int partial_finish(cg_partial* p, const void* q_slice, const void* b_slice, bool two_sides, int q_on_device, uint8_t out_partials[384],
+                          cg_timings* timings) {
     if (!p) return fail(CG_ERR_INVALID_ARGUMENT, "null handle");
     std::unique_ptr<cg_partial> own(p);
     if (!p->c || !p->S) return fail(CG_ERR_INVALID_ARGUMENT, "closed handle");
-    if (!q_slice || !out_partials) { p->close(); return fail(CG_ERR_INVALID_ARGUMENT, "null argument"); }
+    if (!q_slice || !out_partials || (two_sides && !b_slice)) { p->close(); return fail(CG_ERR_INVALID_ARGUMENT, "null argument"); }
     cg_ctx* c = p->c;
     ProofSlot* S = p->S;
     int e = CG_OK;
@@ -1555,12 +1568,28 @@ extern "C" int cg_prove_partial_q_finish(cg_partial* p, const void* q_slice, int
         hipStream_t s0 = S->st[0];
         const uint64_t nq = c->rh.hi - c->rh.lo;
         const Fr* q_dev = (const Fr*)q_slice;
+        Fr* const own_q = c->external_q ? S->h_canon.p : S->h_canon.p + c->rh.lo;      // this shard's place in the slot's h vector
         if (!q_on_device && nq) {
-            Fr* dst = c->external_q ? S->h_canon.p : S->h_canon.p + c->rh.lo;
-            CG_HIP(hipMemcpyAsync(dst, q_slice, nq * 32, hipMemcpyHostToDevice, s0));
-            q_dev = dst;
+            CG_HIP(hipMemcpyAsync(own_q, q_slice, nq * 32, hipMemcpyHostToDevice, s0));
+            q_dev = own_q;
         }
-        const Fr* h_scalars = witness_map_or_check(c, S, p->w_dev, q_dev, s0);
+        // the input checks the witness map would have made (canonical assignment), and of what arrived instead of it
+        S->wm.h_bad_input.p[0] = 0;
+        k_flag_non_canonical<<<ceil_div(c->M, 256), 256, 0, s0>>>(p->w_dev, c->M, S->wm.h_bad_input.dev());
+        if (two_sides && nq) {
+            const Fr* b_dev = (const Fr*)b_slice;
+            if (!q_on_device) {
+                if (S->q2.n < nq) S->q2.alloc(nq);
+                CG_HIP(hipMemcpyAsync(S->q2.p, b_slice, nq * 32, hipMemcpyHostToDevice, s0));
+                b_dev = S->q2.p;
+            }
+            fr_mul_plain29(q_dev, b_dev, own_q, nq, S->wm.h_bad_input.dev(), s0);    // q_j = (vinv·a_j)·b_j; checks both operands
+            q_dev = own_q;
+        } else if (nq) {
+            k_flag_non_canonical<<<ceil_div(nq, 256), 256, 0, s0>>>(q_dev, nq, S->wm.h_bad_input.dev());
+        }
+        CG_KERNEL_CHECK();
+        const Fr* h_scalars = q_dev;
         S->eh.digits(h_scalars, nq, s0);
         S->eh.accumulate(s0);
         if (S->one_stream && !spin_wait(c)) {
@@ -1598,6 +1627,14 @@ extern "C" int cg_prove_partial_q_finish(cg_partial* p, const void* q_slice, int
     return e;
 }
 
+extern "C" int cg_prove_partial_q_finish(cg_partial* p, const void* q_slice, int q_on_device, uint8_t out_partials[384], cg_timings* timings) {
+    return partial_finish(p, q_slice, nullptr, false, q_on_device, out_partials, timings);
+}
+extern "C" int cg_prove_partial_q_finish2(cg_partial* p, const void* a_slice, const void* b_slice, int slices_on_device, uint8_t out_partials[384],
+                                          cg_timings* timings) {
+    return partial_finish(p, a_slice, b_slice, true, slices_on_device, out_partials, timings);
+}
+
 extern "C" void cg_prove_partial_q_abort(cg_partial* p) {
     if (!p) return;
     p->close();
@@ -1619,7 +1656,7 @@ extern "C" int cg_h_scalars_slice(const cg_ctx* ctx, uint32_t shard, uint64_t* o
     return CG_OK;
 }
 
-extern "C" int cg_witness_map_coset(cg_ctx* ctx, const void* full_assignment, int assignment_on_device, void* q_out, int q_on_device) {
+static int witness_map_coset_common(cg_ctx* ctx, const void* full_assignment, int assignment_on_device, int half, void* q_out, int q_on_device) {
     if (!ctx || !full_assignment || !q_out) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
     if (!ctx->folded) return fail(CG_ERR_INVALID_ARGUMENT, "context keeps the h query in the coefficient basis: its h scalars are cg_witness_map's");
     if (ctx->external_q) return fail(CG_ERR_INVALID_ARGUMENT, "context loaded with CG_FLAG_H_SCALARS_EXTERNAL holds no witness-map resources");
@@ -1636,24 +1673,18 @@ extern "C" int cg_witness_map_coset(cg_ctx* ctx, const void* full_assignment, in
             w_dev = up.u->w.p;
         }
         SlotGuard g(ctx);
-        ProofSlot* S = g.s;
-        hipStream_t s0 = S->st[0];
-        // ALL coset values (the whole-domain arrangement, whatever this context's own share is), natural order
-        wm29_run(ctx->wdom, ctx->A, ctx->B, ctx->C, ctx->dA, ctx->dB, ctx->dC, S->wm, w_dev, ctx->M, ctx->m, ctx->l, S->h_canon.p, s0, true, nullptr);
-        const Fr* src = S->h_canon.p;
-        if (ctx->h_strided) {        // shard-major: shard p's scalars q_{p + k·count} become the contiguous slice p
-            Fr* tmp = reinterpret_cast<Fr*>(S->wm.vt.p);
-            k_shard_major<<<ceil_div(ctx->D, 256), 256, 0, s0>>>(S->h_canon.p, tmp, ctx->D, (uint32_t)ctx->shard_count);
-            CG_KERNEL_CHECK();
-            src = tmp;
-        }
-        CG_HIP(hipMemcpyAsync(q_out, src, ctx->D * 32, q_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s0));
-        CG_HIP(hipStreamSynchronize(s0));
-        if (S->wm.h_bad_input.p[0]) return fail(CG_ERR_INVALID_ARGUMENT, "full_assignment holds a value >= the scalar field modulus");
-        return CG_OK;
+        // ALL coset values (the whole-domain arrangement, whatever this context's own share is)
+        return coset_values_to(ctx, g.s, w_dev, half, q_out, q_on_device);
     } catch (...) {
         return translate_exception();
     }
+}
+extern "C" int cg_witness_map_coset(cg_ctx* ctx, const void* full_assignment, int assignment_on_device, void* q_out, int q_on_device) {
+    return witness_map_coset_common(ctx, full_assignment, assignment_on_device, 0, q_out, q_on_device);
+}
+extern "C" int cg_witness_map_coset_half(cg_ctx* ctx, const void* full_assignment, int assignment_on_device, int which, void* out, int out_on_device) {
+    if (which != 0 && which != 1) return fail(CG_ERR_INVALID_ARGUMENT, "which must be 0 (the a side) or 1 (the b side)");
+    return witness_map_coset_common(ctx, full_assignment, assignment_on_device, which + 1, out, out_on_device);
 }
 
 extern "C" int cg_assemble(cg_ctx* ctx, const uint8_t* partials, uint32_t n_shards, const uint8_t r[32], const uint8_t s[32],

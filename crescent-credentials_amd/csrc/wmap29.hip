@@ -520,7 +520,7 @@ static void dit29(const Wm29Domain& d, const uint32_t* tw, const uint32_t* in_a,
 
 void wm29_run(const Wm29Domain& dom, const DevCsr& A, const DevCsr& B, const DevCsr& C, const Csr29& dA, const Csr29& dB,
               const Csr29& dC, Wm29Buffers& buf, const Fr* w_canon, uint64_t M, uint64_t m, uint64_t l, Fr* h_out,
-              hipStream_t st, bool coset_values, const Wm29Strided* strided) {
+              hipStream_t st, bool coset_values, const Wm29Strided* strided, int half) {
     const uint64_t D = dom.n;
     const int logn = dom.logn;
     // the flag is HOST memory the kernel writes only when it meets a non-canonical element: no memset, no copy back
@@ -533,6 +533,7 @@ void wm29_run(const Wm29Domain& dom, const DevCsr& A, const DevCsr& B, const Dev
     const Csr29* dicts[3] = {&dA, &dB, &dC};
     const int nvec = coset_values ? 2 : 3;       // c's share of the quotient lives in the folded l query
     for (int k = 0; k < nvec; ++k) {
+        if (half && k != half - 1) continue;       // one side of the quotient only (wmap29.hpp): the other matrix is somebody else's
         if (k) fill_zero(v[k], D * 32, st);
         const uint32_t* src = buf.w29.p;
         for (int lv = 0; lv < mats[k]->n_sell; ++lv) {
@@ -564,6 +565,16 @@ void wm29_run(const Wm29Domain& dom, const DevCsr& A, const DevCsr& B, const Dev
               buf.vc.p);
         return;
     }
+    if (coset_values && half) {
+        // ONE side of the quotient's a∘b part on the coset, as plain canonical integers in natural order: vinv·a(gω^j) (half 1)
+        // or b(gω^j) (half 2) - two transforms and one sparse product; q_j is their product mod r (fr_mul_plain29)
+        static const uint32_t one_plain[8] = {1u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        uint32_t* x = half == 1 ? buf.va.p : buf.vb.p;
+        dit29(dom, dom.tw_inv.p, x, nullptr, nullptr, false, x, buf.vt.p, dom.coset.p, true, st);
+        dit29(dom, dom.tw_fwd.p, buf.vt.p, nullptr, nullptr, false, buf.vt.p, reinterpret_cast<uint32_t*>(h_out), nullptr, false, st,
+              half == 1 ? dom.vinv_plain : one_plain);
+        return;
+    }
     if (coset_values) {
         // four transforms: q_j = vinv·a(gω^j)·b(gω^j), the scalars of the h MSM over the transformed h query
         dit29(dom, dom.tw_inv.p, buf.va.p, nullptr, nullptr, false, buf.va.p, buf.vt.p, dom.coset.p, true, st);
@@ -581,6 +592,23 @@ void wm29_run(const Wm29Domain& dom, const DevCsr& A, const DevCsr& B, const Dev
     }
     // (a∘b - c)/Z(g) on load; coset ifft; x g^-i / n and out of Montgomery form on store           :187,201-210
     dit29(dom, dom.tw_inv.p, buf.va.p, buf.vb.p, buf.vc.p, true, buf.va.p, reinterpret_cast<uint32_t*>(h_out), dom.icoset.p, false, st);
+}
+
+// out[i] = a[i]·b[i] mod r for plain canonical operands (two halves of the quotient's a∘b part -> the h MSM's scalars); a
+// non-canonical operand sets *bad_input
+__global__ void __launch_bounds__(256) k_mul_plain29(const Fr* __restrict__ a, const Fr* __restrict__ b, uint32_t* __restrict__ out, uint64_t n,
+                                                     uint32_t* __restrict__ bad_input) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fr x = a[i], y = b[i];
+    if (!fr_lt_modulus(x) || !fr_lt_modulus(y)) *bad_input = 1u;
+    const Fr29 v = mul(unpack29<Fr29P>(x.l), Fr29::from_limbs(Fr29P::R2));      // x·R', below 2N
+    store_packed29(out, i, cond_sub_n(mul(v, unpack29<Fr29P>(y.l))));            // x·y, canonical
+}
+void fr_mul_plain29(const Fr* a, const Fr* b, Fr* out, uint64_t n, uint32_t* bad_input_dev, hipStream_t st) {
+    if (!n) return;
+    k_mul_plain29<<<ceil_div(n, 256), 256, 0, st>>>(a, b, reinterpret_cast<uint32_t*>(out), n, bad_input_dev);
+    CG_KERNEL_CHECK();
 }
 
 // ---- unit-level transform (cg_ntt_*): canonical natural-order data in place -----------------------------------------

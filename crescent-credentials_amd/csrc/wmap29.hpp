@@ -84,6 +84,10 @@ struct Ntt29Unit {
 // q_j of the shard's points j = rank + k·2^logs, k < d, in the order of k.
 void wm29_run(const Wm29Domain& dom, const DevCsr& A, const DevCsr& B, const DevCsr& C, const Csr29& dA, const Csr29& dB,
               const Csr29& dC, Wm29Buffers& buf, const Fr* w_canon, uint64_t M, uint64_t m, uint64_t l, Fr* h_out,
-              hipStream_t st, bool coset_values, const Wm29Strided* strided = nullptr);
+              hipStream_t st, bool coset_values, const Wm29Strided* strided = nullptr, int half = 0);
+// half (coset_values only, no `strided`): 1 = the a side alone, vinv·a(g·ω^j); 2 = the b side alone, b(g·ω^j) - D plain
+// canonical integers each, natural order, from ONE sparse product and TWO transforms: the two sides are independent until
+// the pointwise product, so two GPUs can compute one each (cg_witness_map_coset_half).  q_j = side1_j · side2_j:
+void fr_mul_plain29(const Fr* a, const Fr* b, Fr* out, uint64_t n, uint32_t* bad_input_dev, hipStream_t st);
 
 }  // namespace cg

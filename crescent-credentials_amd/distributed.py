@@ -199,7 +199,7 @@ class HScalarScatter:
     gloo on the host.  `slots` receive buffers let several proofs' slices be held at once (ShardedProver.prove_stream); with
     `rotate` any rank may be asked to be the source (it then holds the 32 B x domain_size send buffer too)."""
 
-    def __init__(self, prover, device, group, rank: int, world: int, slots: int = 1, rotate: bool = False):
+    def __init__(self, prover, device, group, rank: int, world: int, slots: int = 1, rotate: bool = False, src_ranks=(0,)):
         self.prover, self.group, self.rank, self.world, self.rotate = prover, group, rank, world, rotate
         self.on_host = (world <= 1) or _on_host(group)
         self.slices = [prover.h_scalars_slice(p) for p in range(world)]
@@ -207,7 +207,7 @@ class HScalarScatter:
         total = max(o + c for o, c in self.slices)
         dev = torch.device("cpu") if self.on_host else device
         self._recv = [torch.zeros(max(1, self.chunk), dtype=torch.uint8, device=dev) for _ in range(max(1, slots))]
-        sends = rank == 0 or rotate
+        sends = rank in src_ranks or rotate          # ranks that may be asked to be the source hold the send buffer
         self._all = torch.zeros(total * 32, dtype=torch.uint8, device=dev) if sends else None
         # a real context (cg_witness_map_coset) can write into host memory it is handed; page-locked when a GPU is there
         self._direct_host = self.on_host and sends and hasattr(prover, "domain_size") and total == getattr(prover, "domain_size", -1)
@@ -289,7 +289,7 @@ class ShardedProver:
     of the next proofs are on the GPU."""
 
     def __init__(self, prover, device, group=None, arrangement: str = "recompute", rotate: bool = False, stream_slots: int = 8,
-                 two_call: bool = False):
+                 two_call: bool = False, split_map: bool = False):
         """arrangement ("run the witness map on GPU 0 and scatter h, or recompute it redundantly on every GPU -
         measure both"):
           "recompute" - every rank runs the witness map for its own share of the h MSM (cg_prove_partial); one collective
@@ -311,12 +311,21 @@ class ShardedProver:
         # (cg_prove_partial_q_finish).  The assignment-driven MSMs leave the critical path: witness map -> scatter -> h share.
         # `prover` needs prove_partial_q_begin (-> an object with witness_map_coset / finish / abort).
         self.two_call = bool(two_call)
+        # split_map (with two_call): the witness map in two halves on two ranks - rank 0 computes the a side, vinv·a(g w^j), rank 1
+        # the b side, b(g w^j) (one sparse product and two transforms each: half the witness map's time, at the same time) - each
+        # scatters its side, and every shard multiplies its two slices itself (cg_prove_partial_q_finish2).  Two scatters and one
+        # gather per proof.  `prover` on ranks 0 and 1 needs witness-map resources; its open proofs need witness_map_coset_half
+        # and finish2.
+        if split_map and not two_call:
+            raise ValueError("split_map belongs to the two-call form of the 'scatter' arrangement")
+        self.split_map = bool(split_map)
         self.prover = prover
         self.device = device
         self.group = group
         self.arrangement = arrangement
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.src_b = min(1, self.world - 1)      # split_map: the rank that computes the b side
         self.all_gathers = 0          # all_gathers issued so far (one per proof when world > 1)
         self.scatters = 0             # scatters issued so far ("scatter" arrangement: one per proof)
         self.proofs = 0
@@ -326,6 +335,8 @@ class ShardedProver:
         self._stream_slots = max(1, stream_slots)
         self._scatter = (HScalarScatter(prover, device, group, self.rank, self.world, slots=self._stream_slots, rotate=self.rotate)
                          if arrangement == "scatter" else None)
+        self._scatter_b = (HScalarScatter(prover, device, group, self.rank, self.world, slots=1, src_ranks=(self.src_b,))
+                           if self.split_map else None)
         # A stream of scatter-arrangement proofs issues BOTH its collectives - the scatter of job k and the gather of job
         # k - in_flight - from ONE communication thread on a fixed schedule (_prove_stream_scatter), on the one group.  (Round 5
         # issued them from two free-running threads on two groups: each group saw its own sequence in order, but nothing ordered
@@ -339,7 +350,33 @@ class ShardedProver:
         t0 = time.perf_counter()
         failure = None
         part = None
-        if self._scatter is not None and self.two_call:
+        if self._scatter is not None and self.split_map:
+            opened = self.prover.prove_partial_q_begin(assignment, r, on_device=on_device)     # a failure here precedes every collective
+            qa = qb = None
+            q_on_device = False
+            for side, sc, src in ((0, self._scatter, 0), (1, self._scatter_b, self.src_b)):    # both scatters, whatever fails
+                try:
+                    got, q_on_device = sc.exchange(assignment, on_device, self.seconds, src, 0,
+                                                   wm=lambda side=side, **kw: opened.witness_map_coset_half(side, **kw))
+                    if side == 0:
+                        qa = got
+                    else:
+                        qb = got
+                except WitnessMapFailed as e:
+                    failure = failure or e.cause
+                except BaseException:        # noqa: BLE001 - the collective failed: give the slot back, nothing can follow
+                    opened.abort()
+                    raise
+                self.scatters += 1
+            t0 = time.perf_counter()
+            if failure is None:
+                try:
+                    part = opened.finish2(qa, qb, q_on_device)
+                except BaseException as e:   # noqa: BLE001 - raised below, after the gather
+                    failure = e
+            else:
+                opened.abort()
+        elif self._scatter is not None and self.two_call:
             opened = self.prover.prove_partial_q_begin(assignment, r, on_device=on_device)     # a failure here precedes every collective
             q = None
             try:

@@ -336,7 +336,18 @@ int cg_prove_partial_q(cg_ctx* ctx, const void* full_assignment, int assignment_
  *   cg_prove_partial_q_abort  : for a caller that cannot deliver the slice: waits for what was queued, gives the slot back.
  * An open proof holds its slot: begin as many as the context has slots and no more, or begin blocks.  Calls on one handle are
  * the caller's to serialise; begin and finish may come from different threads. */
+/* The witness map in two HALVES (round 6).  Until their pointwise product the two sides of q_j = vinv·a(g w^j) · b(g w^j)
+ * (r1cs_to_qap.rs:164-187) are independent - a sparse product with A (resp. B) and two transforms each - so two ranks can
+ * compute one side each, at half the witness map's time, and every shard multiplies its two slices itself:
+ *   cg_witness_map_coset_half / cg_partial_witness_map_coset_half : which = 0: the a side, vinv·a(g w^j); which = 1: the b side,
+ *       b(g w^j); domain_size plain canonical values, laid out shard-major exactly as cg_witness_map_coset lays out q.
+ *   cg_prove_partial_q_finish2 : cg_prove_partial_q_finish with the shard's slices of BOTH sides (both in host or both in device
+ *       memory); the h scalars are their products mod r, formed on the GPU.  (The one-call form: begin, then finish2.) */
 typedef struct cg_partial cg_partial;
+int cg_witness_map_coset_half(cg_ctx* ctx, const void* full_assignment, int assignment_on_device, int which, void* out, int out_on_device);
+int cg_partial_witness_map_coset_half(cg_partial* p, int which, void* out, int out_on_device);
+int cg_prove_partial_q_finish2(cg_partial* p, const void* a_slice, const void* b_slice, int slices_on_device, uint8_t out_partials[384],
+                               cg_timings* timings);
 int cg_prove_partial_q_begin(cg_ctx* ctx, const void* full_assignment, int assignment_on_device, const uint8_t r[32], cg_partial** out);
 int cg_partial_witness_map_coset(cg_partial* p, void* q_out, int q_on_device);
 int cg_prove_partial_q_finish(cg_partial* p, const void* q_slice, int q_on_device, uint8_t out_partials[384], cg_timings* timings);

@@ -212,6 +212,24 @@ extern "C" {
         timings: *mut cg_timings,
     ) -> c_int;
     pub fn cg_prove_partial_q_abort(p: *mut cg_partial);
+    // the witness map in two halves: which = 0 the a side, 1 the b side; finish2 multiplies a shard's two slices
+    pub fn cg_witness_map_coset_half(
+        ctx: *mut cg_ctx,
+        full_assignment: *const c_void,
+        assignment_on_device: c_int,
+        which: c_int,
+        out: *mut c_void,
+        out_on_device: c_int,
+    ) -> c_int;
+    pub fn cg_partial_witness_map_coset_half(p: *mut cg_partial, which: c_int, out: *mut c_void, out_on_device: c_int) -> c_int;
+    pub fn cg_prove_partial_q_finish2(
+        p: *mut cg_partial,
+        a_slice: *const c_void,
+        b_slice: *const c_void,
+        slices_on_device: c_int,
+        out_partials: *mut u8,
+        timings: *mut cg_timings,
+    ) -> c_int;
     pub fn cg_domain_size(ctx: *const cg_ctx) -> u64;
     pub fn cg_qap_load(
         out: *mut *mut cg_qap_ctx,

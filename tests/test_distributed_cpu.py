@@ -85,6 +85,23 @@ class OracleShard:
                 shard.finished = getattr(shard, "finished", 0) + 1
                 return shard.prove_partial_q(w, q_slice, r)
 
+            # the witness map in two halves: the stand-in's "a side" is its h vector, its "b side" all ones - what matters
+            # here is that the two sides travel separately and are multiplied slice by slice
+            def witness_map_coset_half(self, which, out_dev=None, out_host=None):
+                shard.half_calls = getattr(shard, "half_calls", []) + [which]
+                if which == 0:
+                    return shard.witness_map_coset(w)
+                D = shard.o.domain_size_for(shard.m + shard.l)
+                return shard.o.fe_bytes(1) * (D - 1)
+
+            def finish2(self, a_slice, b_slice, on_device=False):
+                shard.finished = getattr(shard, "finished", 0) + 1
+                a, b = bytes(a_slice), bytes(b_slice)
+                assert len(a) == len(b)
+                prod = b"".join(shard.o.fe_bytes(int.from_bytes(a[i:i + 32], "little") * int.from_bytes(b[i:i + 32], "little") % shard.o.R)
+                                for i in range(0, len(a), 32))
+                return shard.prove_partial_q(w, prod, r)
+
             def abort(self):
                 shard.aborted = getattr(shard, "aborted", 0) + 1
         return Open()
@@ -194,6 +211,14 @@ def _worker(rank, world, port, q):
             ok = ok and spt.prove(w, int(case["r"], 16), int(case["s"], 16)).hex() == case["proof"]
         ok = ok and spt.all_gathers == spt.scatters == len(g["proofs"]) == shard_t.begun == shard_t.finished
         ok = ok and getattr(shard_t, "aborted", 0) == 0 and getattr(shard_t, "coset_calls", 0) == (len(g["proofs"]) if rank == 0 else 0)
+        # ... with the witness map in two halves: rank 0 computes one side, rank 1 the other, two scatters, the products on the shards
+        shard_h = OracleShard(o, pk, _rows(g["matrices"]), g["num_inputs"], g["num_constraints"], g["num_variables"], rank, world)
+        sph = ShardedProver(shard_h, torch.device("cpu"), arrangement="scatter", two_call=True, split_map=True)
+        for case in g["proofs"]:
+            ok = ok and sph.prove(w, int(case["r"], 16), int(case["s"], 16)).hex() == case["proof"]
+        ok = ok and sph.all_gathers == len(g["proofs"]) and sph.scatters == 2 * len(g["proofs"])
+        want_halves = ([0] if rank == 0 else []) + ([1] if rank == min(1, world - 1) else [])
+        ok = ok and getattr(shard_h, "half_calls", []) == want_halves * len(g["proofs"]) and getattr(shard_h, "aborted", 0) == 0
         # ... and a STREAM of such proofs, the rank that runs the witness map rotating from job to job (k mod world): scatters
         # from one thread, gathers from another (two groups), three proofs in flight per rank; every proof the golden one, one
         # scatter + one gather per job, and the witness maps spread over the ranks

@@ -442,6 +442,7 @@ def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
     assert arr["recompute"]["ms_per_proof"] == sh["ms_per_proof"] and arr["scatter"]["bytes_identical_to_unsharded"] is True
     assert arr["scatter"]["scatters"] == arr["scatter"]["all_gathers"] == 6 and arr["scatter"]["ms_per_proof"] > 0
     assert arr["scatter_two_call"]["bytes_identical_to_unsharded"] is True and arr["scatter_two_call"]["ms_per_proof"] > 0    # three rows
+    assert arr["scatter_two_halves"]["bytes_identical_to_unsharded"] is True and arr["scatter_two_halves"]["collectives_per_proof"] == 3    # four
     assert "error" not in sh and "backend_fallback" not in sh
     fl = sh["in_flight"]
     assert fl["proofs_in_flight"] == 8 and fl["all_gathers"] == fl["proofs"] and fl["bytes_identical_to_unsharded"] is True

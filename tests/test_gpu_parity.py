@@ -1120,6 +1120,36 @@ def test_sharded_proof_in_two_calls(cc, oracle, n, contig, slots):
                 opened[0].witness_map_coset(out_dev=qd.data_ptr())
                 parts = b"".join(op.finish(qd.data_ptr() + o * 32, q_on_device=True) for op, (o, c) in zip(opened, slices))
                 assert parts == one_call
+        # the witness map in two halves (cg_witness_map_coset_half / cg_partial_witness_map_coset_half / cg_prove_partial_q_finish2):
+        # q is the product of the two sides mod r, each side is laid out like q, and a shard that multiplies its own two slices
+        # on the GPU produces the record it produces from q's slice
+        for wit in (w, w_bad):
+            r = rng.randrange(oracle.R)
+            q_ref = first.witness_map_coset(wit)
+            a_side, b_side = first.witness_map_coset_half(wit, 0), first.witness_map_coset_half(wit, 1)
+            qi = lambda arr, j: int.from_bytes(arr[32 * j:32 * j + 32].tobytes(), "little")
+            for j in (0, 1, 5, D // 2 + 3, D - 1):
+                assert qi(a_side, j) * qi(b_side, j) % oracle.R == qi(q_ref, j) and qi(a_side, j) < oracle.R and qi(b_side, j) < oracle.R
+            one_call = b"".join(p.prove_partial_q(wit, q_ref[o * 32:(o + c) * 32], r) for p, (o, c) in zip(shards, slices))
+            opened = [p.prove_partial_q_begin(wit, r) for p in shards]
+            assert bytes(opened[0].witness_map_coset_half(0)) == bytes(a_side) and bytes(opened[0].witness_map_coset_half(1)) == bytes(b_side)
+            parts = b"".join(op.finish2(a_side[o * 32:(o + c) * 32], b_side[o * 32:(o + c) * 32]) for op, (o, c) in zip(opened, slices))
+            assert parts == one_call
+            wd = torch.from_numpy(np.ascontiguousarray(wit)).cuda()
+            ad, bd = torch.empty(D * 32, dtype=torch.uint8, device="cuda"), torch.empty(D * 32, dtype=torch.uint8, device="cuda")
+            first.witness_map_coset_half(wd.data_ptr(), 0, on_device=True, out_dev=ad.data_ptr())
+            opened = [p.prove_partial_q_begin(wd.data_ptr(), r, on_device=True) for p in shards]
+            opened[0].witness_map_coset_half(1, out_dev=bd.data_ptr())
+            assert bytes(ad.cpu().numpy()) == bytes(a_side) and bytes(bd.cpu().numpy()) == bytes(b_side)
+            parts = b"".join(op.finish2(ad.data_ptr() + o * 32, bd.data_ptr() + o * 32, on_device=True) for op, (o, c) in zip(opened, slices))
+            assert parts == one_call
+        with pytest.raises(cc.CrescentGpuError):
+            first.witness_map_coset_half(w, 2)                                        # which is 0 or 1
+        o1, c1 = slices[1]
+        a_bad = a_side[o1 * 32:(o1 + c1) * 32].copy()
+        a_bad[32:64] = np.frombuffer(oracle.R.to_bytes(32, "little"), np.uint8)
+        with pytest.raises(cc.CrescentGpuError):                                      # a non-canonical operand of the product is refused
+            others[0].prove_partial_q_begin(w_bad, r).finish2(a_bad, b_side[o1 * 32:(o1 + c1) * 32])
         # an open proof holds its slot; abort gives it back; a bad slice fails the finish and gives it back too
         r = 5
         q = first.witness_map_coset(w)

@@ -49,5 +49,29 @@ if shard > 1:
             tsrc.append(t_src); tfin.append(t_fin)
     print("shards", shard, "two-call form: begin + witness map on the source rank", round(float(np.median(tsrc)), 3), "ms; the h share after the slice",
           round(float(np.median(tfin)), 3), "ms; critical path ~", round(float(np.median(tsrc)) + float(np.median(tfin)), 3), "ms + the scatter")
+    # the witness map in two halves: rank 0 computes the a side, rank 1 the b side (at the same time), two scatters, every shard
+    # multiplies its slices and adds the h share (cg_partial_witness_map_coset_half / cg_prove_partial_q_finish2)
+    qa = torch.empty(p.domain_size * 32, dtype=torch.uint8, device="cuda")
+    qb = torch.empty(p.domain_size * 32, dtype=torch.uint8, device="cuda")
+    th0, th1, tf2, talone = [], [], [], []
+    for i in range(13):
+        t0 = time.perf_counter(); op = p.prove_partial_q_begin(wd.data_ptr(), 5, on_device=True); op.witness_map_coset_half(0, out_dev=qa.data_ptr())
+        t_h0 = (time.perf_counter() - t0) * 1e3
+        op.witness_map_coset_half(1, out_dev=qb.data_ptr())
+        o0, c0 = p.h_scalars_slice(0)
+        op.finish2(qa.data_ptr() + o0 * 32, qb.data_ptr() + o0 * 32, on_device=True)
+        t0 = time.perf_counter(); op = p.prove_partial_q_begin(wd.data_ptr(), 5, on_device=True); op.witness_map_coset_half(1, out_dev=qb.data_ptr())
+        t_h1 = (time.perf_counter() - t0) * 1e3
+        op.finish2(qa.data_ptr() + o0 * 32, qb.data_ptr() + o0 * 32, on_device=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); p.witness_map_coset_half(wd.data_ptr(), 0, on_device=True, out_dev=qa.data_ptr()); t_al = (time.perf_counter() - t0) * 1e3
+        ope = ext.prove_partial_q_begin(wd.data_ptr(), 5, on_device=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); ope.finish2(qa.data_ptr() + off * 32, qb.data_ptr() + off * 32, on_device=True); t_f2 = (time.perf_counter() - t0) * 1e3
+        if i >= 3:
+            th0.append(t_h0); th1.append(t_h1); tf2.append(t_f2); talone.append(t_al)
+    md = lambda x: round(float(np.median(x)), 3)
+    print("shards", shard, "two halves: begin + the a side on rank 0", md(th0), "ms, begin + the b side on rank 1", md(th1), "ms (one side alone on an idle GPU",
+          md(talone), "ms); product + h share after the slices", md(tf2), "ms; critical path ~", round(max(md(th0), md(th1)) + md(tf2), 3), "ms + two scatters")
     ext.close()
 print("shards", shard, "wall ms", round(float(np.median(ws)), 3), "library total_ms", round(float(np.median(ts)), 3), {k: round(v, 3) for k, v in tm.items() if k.endswith("_ms")})
