@@ -184,6 +184,14 @@ public:
         cv.wait(lk, [&] { return !writer && writers_waiting == 0; });
         ++readers;
     }
+    // For a reader that may ALREADY hold the gate through another handle (cg_prove_partial_q_begin: a host opens proof k + 1
+    // before it finishes proof k): it passes a WAITING writer - queueing behind it would wait for the writer, which waits for
+    // this caller's first handle - and waits only for an ACTIVE one.
+    void lock_shared_passing_waiting_writers() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !writer; });
+        ++readers;
+    }
     void unlock_shared() {
         std::lock_guard<std::mutex> lk(mu);
         if (--readers == 0) cv.notify_all();
@@ -1479,7 +1487,7 @@ extern "C" int cg_prove_partial_q_begin(cg_ctx* ctx, const void* full_assignment
     p->c = ctx;
     ctx->calls_inside.fetch_add(1, std::memory_order_acq_rel);
     try {
-        ctx->tune_mu.lock_shared();
+        ctx->tune_mu.lock_shared_passing_waiting_writers();
         p->gate_held = true;
         if (ctx->broken) { p->close(); return fail(CG_ERR_OUT_OF_MEMORY, "%s", BROKEN_CONTEXT); }
         CG_HIP(hipSetDevice(ctx->device));

@@ -335,7 +335,8 @@ int cg_prove_partial_q(cg_ctx* ctx, const void* full_assignment, int assignment_
  *       the 384-byte record, gives the slot back and destroys the handle - also when it fails.
  *   cg_prove_partial_q_abort  : for a caller that cannot deliver the slice: waits for what was queued, gives the slot back.
  * An open proof holds its slot: begin as many as the context has slots and no more, or begin blocks.  Calls on one handle are
- * the caller's to serialise; begin and finish may come from different threads. */
+ * the caller's to serialise; begin and finish may come from different threads.  Every open proof must be finished or aborted
+ * before cg_circuit_free (which waits for the calls inside the context, open proofs included). */
 /* The witness map in two HALVES (round 6).  Until their pointwise product the two sides of q_j = vinv·a(g w^j) · b(g w^j)
  * (r1cs_to_qap.rs:164-187) are independent - a sparse product with A (resp. B) and two transforms each - so two ranks can
  * compute one side each, at half the witness map's time, and every shard multiplies its two slices itself:
