@@ -12,5 +12,5 @@ python - <<PY
 import json
 for f in ("bench_default", "bench_driver_args"):
     d = json.load(open("$O/" + f + ".json"))
-    print(f, d["value"], d["timing"]["median_block"]["spread_pct"], d["roofline_valu"]["frac"], d["roofline_valu"]["counters"]["current"], d["host_witness"]["pinned"]["proofs_per_s"], d["vs_baseline"], d["proof_verifies"], d["key_check"]["ok"])
+    print(f, d["value"], d["timing"]["median_block"]["spread_pct"], d["roofline_valu"]["frac"], d["roofline_valu"]["counters"]["current"], d["host_witness"]["pinned"]["proofs_per_s"], d["cpu_baseline"]["gpu_over_cpu"], d["proof_verifies"], d["key_check"]["ok"])
 PY
