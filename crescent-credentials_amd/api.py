@@ -57,7 +57,7 @@ class _CgCsr(C.Structure):
 
 class _CgOptions(C.Structure):
     _fields_ = [("device", C.c_int32), ("window_bits", C.c_int32), ("shard_rank", C.c_int32),
-                ("shard_count", C.c_int32), ("proof_slots", C.c_int32), ("flags", C.c_int32), ("hw_queues", C.c_int32), ("reserved", C.c_int32 * 1)]
+                ("shard_count", C.c_int32), ("proof_slots", C.c_int32), ("flags", C.c_int32), ("hw_queues", C.c_int32), ("shard_span", C.c_int32)]
 
 
 class CgTimings(C.Structure):
@@ -434,8 +434,10 @@ class Prover:
     def __init__(self, pk: ProvingKey, matrices: ConstraintMatrices, device: int = -1, window_bits: int = 0,
                  shard_rank: int = 0, shard_count: int = 1, proof_slots: int = 1, h_coefficient_basis: bool = False,
                  mode: Optional[str] = None, spin_wait: bool = False, contiguous_h_shards: bool = False,
-                 h_scalars_external: bool = False, flags: int = 0, staged_load: bool = False):
+                 h_scalars_external: bool = False, flags: int = 0, staged_load: bool = False, shard_span: Optional[Tuple[int, int]] = None):
         """h_coefficient_basis=True keeps the h query as loaded (seven transforms per proof, CG_FLAG_H_COEFFICIENT_BASIS).
+        shard_span: (lo, hi) in 1/10000 of every query - this shard's part instead of the shard_rank-th of shard_count equal parts
+        (cg_options.shard_span: unequal shares for the ranks that also run the witness map).
         staged_load: CG_FLAG_STAGED_LOAD - the call returns as soon as the context can prove (warm-up arrangement) and a worker
         thread of the library finishes the load behind the first proofs (wait_ready(), load_timings()).
         mode: None (proof_slots decides), "latency" or "throughput" (CG_FLAG_LATENCY_MODE / CG_FLAG_THROUGHPUT_MODE);
@@ -452,7 +454,7 @@ class Prover:
         self.num_constraints = matrices.num_constraints
         self.num_variables = matrices.num_variables
         opt = _CgOptions(device=device, window_bits=window_bits, shard_rank=shard_rank, shard_count=shard_count,
-                         proof_slots=proof_slots, flags=flags)
+                         proof_slots=proof_slots, flags=flags, shard_span=(shard_span[0] | shard_span[1] << 16) if shard_span else 0)
         self.proof_slots = max(1, proof_slots)
         cpk = pk._c()
         abc, _keep = matrices._c()

@@ -225,6 +225,7 @@ struct cg_ctx {
     uint64_t l = 0, m = 0, M = 0, D = 0;
     int logD = 0;
     int shard_rank = 0, shard_count = 1;
+    int span_lo = 0, span_hi = 0;       // cg_options.shard_span (1/10000 of every query); 0, 0 = equal parts
     // h query held in the coset evaluation basis and the C matrix folded into the l query (msm.hpp): four transforms
     // per proof instead of seven, no sparse product with C; false = the reference's arrangement
     bool folded = true;
@@ -678,6 +679,9 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
     if (wb < 0 || wb == 1 || wb > 22) return fail(CG_ERR_INVALID_ARGUMENT, "window_bits must be 0 (automatic) or in [2, 22]");
     if (opt && opt->proof_slots < 0) return fail(CG_ERR_INVALID_ARGUMENT, "proof_slots must not be negative");
     if (opt && opt->hw_queues < 0) return fail(CG_ERR_INVALID_ARGUMENT, "hw_queues must not be negative");
+    const int span_lo = opt ? (opt->shard_span & 0xffff) : 0, span_hi = opt ? ((opt->shard_span >> 16) & 0xffff) : 0;
+    if (opt && opt->shard_span != 0 && (shard_count <= 1 || span_lo >= span_hi || span_hi > 10000))
+        return fail(CG_ERR_INVALID_ARGUMENT, "shard_span needs a sharded context and 0 <= lo < hi <= 10000");
     constexpr int32_t KNOWN_FLAGS = CG_FLAG_H_COEFFICIENT_BASIS | CG_FLAG_LATENCY_MODE | CG_FLAG_THROUGHPUT_MODE | CG_FLAG_SPIN_WAIT |
                                     CG_FLAG_CONTIGUOUS_H_SHARDS | CG_FLAG_H_SCALARS_EXTERNAL | CG_FLAG_STAGED_LOAD;
     if (opt && (opt->flags & ~KNOWN_FLAGS)) return fail(CG_ERR_INVALID_ARGUMENT, "unknown bits in flags");
@@ -705,6 +709,7 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         c->l = l; c->m = m; c->M = M; c->D = D; c->logD = logD;
         c->shard_count = shard_count;
         c->shard_rank = shard_rank;
+        c->span_lo = span_lo; c->span_hi = span_hi;
         c->fixed_window = wb > 0;
         c->window_opt = wb;
         int n_slots = (opt && opt->proof_slots > 0) ? opt->proof_slots : 1;
@@ -766,13 +771,17 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
             {
                 const int logs = ilog2_ceil((uint64_t)c->shard_count);
                 c->h_strided = c->folded && c->shard_count > 1 && (1 << logs) == c->shard_count && logD - logs >= 4 &&
-                               !(opt && (opt->flags & CG_FLAG_CONTIGUOUS_H_SHARDS));
+                               !(opt && (opt->flags & CG_FLAG_CONTIGUOUS_H_SHARDS)) && span_hi == 0;     // a span is a contiguous range
             }
             const bool folded_now = c->folded && !staged;     // the arrangement this call leaves in force
-            c->rh = shard_range(folded_now ? D : D - 1, c->shard_rank, c->shard_count);
+            // this shard's part of a query of n entries: the rank-th of count equal parts, or the span it was given
+            auto part_of = [&](uint64_t n) {
+                return span_hi ? Range{n * (uint64_t)span_lo / 10000u, n * (uint64_t)span_hi / 10000u} : shard_range(n, c->shard_rank, c->shard_count);
+            };
+            c->rh = part_of(folded_now ? D : D - 1);
             if (c->h_strided) c->rh = {0, D / (uint64_t)c->shard_count};     // positions in the shard's own list of points
-            c->rl = shard_range(folded_now ? M : M - l, c->shard_rank, c->shard_count);
-            c->ra = shard_range(M - 1, c->shard_rank, c->shard_count);
+            c->rl = part_of(folded_now ? M : M - l);
+            c->ra = part_of(M - 1);
             {
                 const auto t = std::chrono::steady_clock::now();
                 AllocScope booking(&c->matrix_bytes);
@@ -1653,7 +1662,11 @@ extern "C" int cg_h_scalars_slice(const cg_ctx* ctx, uint32_t shard, uint64_t* o
     if (!ctx || !offset || !count) return fail(CG_ERR_INVALID_ARGUMENT, "null argument");
     if (!ctx->folded) return fail(CG_ERR_INVALID_ARGUMENT, "context keeps the h query in the coefficient basis");
     if (shard >= (uint32_t)ctx->shard_count) return fail(CG_ERR_INVALID_ARGUMENT, "shard out of range");
-    if (ctx->h_strided) {
+    if (ctx->span_hi) {          // a context that was given its span knows its own shard only
+        if ((int)shard != ctx->shard_rank) return fail(CG_ERR_INVALID_ARGUMENT, "a context loaded with shard_span answers for its own shard only");
+        *offset = ctx->D * (uint64_t)ctx->span_lo / 10000u;
+        *count = ctx->D * (uint64_t)ctx->span_hi / 10000u - *offset;
+    } else if (ctx->h_strided) {
         *count = ctx->D / (uint64_t)ctx->shard_count;
         *offset = *count * shard;
     } else {

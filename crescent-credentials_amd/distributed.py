@@ -199,10 +199,14 @@ class HScalarScatter:
     gloo on the host.  `slots` receive buffers let several proofs' slices be held at once (ShardedProver.prove_stream); with
     `rotate` any rank may be asked to be the source (it then holds the 32 B x domain_size send buffer too)."""
 
-    def __init__(self, prover, device, group, rank: int, world: int, slots: int = 1, rotate: bool = False, src_ranks=(0,)):
+    def __init__(self, prover, device, group, rank: int, world: int, slots: int = 1, rotate: bool = False, src_ranks=(0,), spans=None):
         self.prover, self.group, self.rank, self.world, self.rotate = prover, group, rank, world, rotate
         self.on_host = (world <= 1) or _on_host(group)
-        self.slices = [prover.h_scalars_slice(p) for p in range(world)]
+        if spans is not None:        # unequal shares (cg_options.shard_span): shard p owns [D·lo/10000, D·hi/10000) of the coset values
+            D = prover.domain_size
+            self.slices = [(D * lo // 10000, D * hi // 10000 - D * lo // 10000) for lo, hi in spans]
+        else:
+            self.slices = [prover.h_scalars_slice(p) for p in range(world)]
         self.chunk = max(c for _, c in self.slices) * 32
         total = max(o + c for o, c in self.slices)
         dev = torch.device("cpu") if self.on_host else device
@@ -210,7 +214,8 @@ class HScalarScatter:
         sends = rank in src_ranks or rotate          # ranks that may be asked to be the source hold the send buffer
         self._all = torch.zeros(total * 32, dtype=torch.uint8, device=dev) if sends else None
         # a real context (cg_witness_map_coset) can write into host memory it is handed; page-locked when a GPU is there
-        self._direct_host = self.on_host and sends and hasattr(prover, "domain_size") and total == getattr(prover, "domain_size", -1)
+        self._direct_host = (self.on_host and sends and hasattr(prover, "_h") and hasattr(prover, "domain_size")
+                             and total == getattr(prover, "domain_size", -1))
         if self._direct_host and torch.cuda.is_available():
             try:
                 self._all = self._all.pin_memory()
@@ -289,7 +294,7 @@ class ShardedProver:
     of the next proofs are on the GPU."""
 
     def __init__(self, prover, device, group=None, arrangement: str = "recompute", rotate: bool = False, stream_slots: int = 8,
-                 two_call: bool = False, split_map: bool = False):
+                 two_call: bool = False, split_map: bool = False, spans=None):
         """arrangement ("run the witness map on GPU 0 and scatter h, or recompute it redundantly on every GPU -
         measure both"):
           "recompute" - every rank runs the witness map for its own share of the h MSM (cg_prove_partial); one collective
@@ -319,6 +324,11 @@ class ShardedProver:
         if split_map and not two_call:
             raise ValueError("split_map belongs to the two-call form of the 'scatter' arrangement")
         self.split_map = bool(split_map)
+        # spans ("scatter" only): the (lo, hi) every rank's context was loaded with (cg_options.shard_span, 1/10000 of every query),
+        # rank order - unequal shares, so that the ranks that also compute (half of) the witness map carry less of the MSMs
+        self.spans = list(spans) if spans is not None else None
+        if self.spans is not None and arrangement != "scatter":
+            raise ValueError("spans belong to the 'scatter' arrangement")
         self.prover = prover
         self.device = device
         self.group = group
@@ -333,9 +343,9 @@ class ShardedProver:
         self._gather = PartialGather(device, group) if self.world > 1 else None
         self.rotate = bool(rotate)
         self._stream_slots = max(1, stream_slots)
-        self._scatter = (HScalarScatter(prover, device, group, self.rank, self.world, slots=self._stream_slots, rotate=self.rotate)
-                         if arrangement == "scatter" else None)
-        self._scatter_b = (HScalarScatter(prover, device, group, self.rank, self.world, slots=1, src_ranks=(self.src_b,))
+        self._scatter = (HScalarScatter(prover, device, group, self.rank, self.world, slots=self._stream_slots, rotate=self.rotate,
+                                        spans=self.spans) if arrangement == "scatter" else None)
+        self._scatter_b = (HScalarScatter(prover, device, group, self.rank, self.world, slots=1, src_ranks=(self.src_b,), spans=self.spans)
                            if self.split_map else None)
         # A stream of scatter-arrangement proofs issues BOTH its collectives - the scatter of job k and the gather of job
         # k - in_flight - from ONE communication thread on a fixed schedule (_prove_stream_scatter), on the one group.  (Round 5

@@ -102,7 +102,13 @@ typedef struct cg_options {
                               cg_init - and a throughput context then shares four copy-only streams among its upload buffers.  A host that
                               initialises HIP first and cannot export the variable passes the real count here (4 unless it chose
                               otherwise): with fewer queues than proof_slots + 4 every upload buffer keeps a stream of its own */
-    int32_t reserved[1];
+    int32_t shard_span;    /* sharded contexts: 0 = this shard owns the shard_rank-th of shard_count EQUAL parts of every query.
+                              Otherwise lo | hi << 16, both in 1/10000 of a query's length (0 <= lo < hi <= 10000): the shard owns the
+                              entries [n·lo/10000, n·hi/10000) of each of the five queries (of the h query: that contiguous range
+                              of its coset points).  The spans of a proof's shards must tile [0, 10000] - the host's business, as
+                              the ranks are.  For hosts that give unequal shares: the ranks that also run (half of) the witness map
+                              take a smaller share of the MSMs.  cg_h_scalars_slice then answers for the
+                              context's own shard only */
 } cg_options;
 
 /* By default cg_circuit_load moves the h query into the evaluation basis of the coset and folds the C matrix into

@@ -52,7 +52,7 @@ pub struct cg_options {
     pub proof_slots: i32,
     pub flags: i32,
     pub hw_queues: i32,
-    pub reserved: [i32; 1],
+    pub shard_span: i32,
 }
 
 #[repr(C)]

@@ -31,14 +31,15 @@ def _unpack_pk(o, j):
 class OracleShard:
     """Stand-in for a GPU shard: same contract as Prover.prove_partial / Prover.assemble, computed by the oracle."""
 
-    def __init__(self, o, pk, mats, l, m, M, rank, count):
+    def __init__(self, o, pk, mats, l, m, M, rank, count, span=None):
         from crescent_credentials_amd.distributed import shard_range
         self.o, self.pk, self.mats, self.l, self.m, self.M = o, pk, mats, l, m, M
         self.count = count
         D = o.domain_size_for(m + l)
-        self.rh = shard_range(D - 1, rank, count)
-        self.rl = shard_range(M - l, rank, count)
-        self.ra = shard_range(M - 1, rank, count)
+        # (the stand-in keeps the key as loaded: its "coset values" are the D - 1 coefficients of h, and a span cuts those)
+        self.domain_size = D - 1
+        part = (lambda n: (n * span[0] // 10000, n * span[1] // 10000)) if span else (lambda n: shard_range(n, rank, count))
+        self.rh, self.rl, self.ra = part(D - 1), part(M - l), part(M - 1)
 
     def prove_partial(self, w, r, on_device=False, h_slice=None):
         o, pk, l = self.o, self.pk, self.l
@@ -219,6 +220,14 @@ def _worker(rank, world, port, q):
         ok = ok and sph.all_gathers == len(g["proofs"]) and sph.scatters == 2 * len(g["proofs"])
         want_halves = ([0] if rank == 0 else []) + ([1] if rank == min(1, world - 1) else [])
         ok = ok and getattr(shard_h, "half_calls", []) == want_halves * len(g["proofs"]) and getattr(shard_h, "aborted", 0) == 0
+        # ... and with UNEQUAL shares (cg_options.shard_span): the ranks that compute the halves carry less of the MSMs
+        cuts = [0] + [10000 * (2 * k + 1) // (2 * world) for k in range(1, world)] + [10000]     # half a share for rank 0, the rest equal steps
+        spans = [(cuts[k], cuts[k + 1]) for k in range(world)]
+        shard_w = OracleShard(o, pk, _rows(g["matrices"]), g["num_inputs"], g["num_constraints"], g["num_variables"], rank, world, span=spans[rank])
+        spw = ShardedProver(shard_w, torch.device("cpu"), arrangement="scatter", two_call=True, split_map=True, spans=spans)
+        for case in g["proofs"]:
+            ok = ok and spw.prove(w, int(case["r"], 16), int(case["s"], 16)).hex() == case["proof"]
+        ok = ok and spw.all_gathers == len(g["proofs"]) and spw.scatters == 2 * len(g["proofs"])
         # ... and a STREAM of such proofs, the rank that runs the witness map rotating from job to job (k mod world): scatters
         # from one thread, gathers from another (two groups), three proofs in flight per rank; every proof the golden one, one
         # scatter + one gather per job, and the witness maps spread over the ranks

@@ -1174,3 +1174,46 @@ def test_sharded_proof_in_two_calls(cc, oracle, n, contig, slots):
         whole.close()
         for p in shards:
             p.close()
+
+
+def test_unequal_shares_of_a_sharded_proof(cc, oracle):
+    """cg_options.shard_span: a shard owns [n·lo/10000, n·hi/10000) of every query instead of an equal part, so that the ranks
+    that also compute (half of) the witness map carry less of the MSMs.  Four shards of 8 / 17 / 30 / 45 %: the one-call partial
+    sums (every shard runs the witness map for its contiguous range of coset points) and the two-halves flow (slices cut by the
+    spans, products on the shards) both assemble to the unsharded context's bytes; cg_h_scalars_slice answers for the own shard."""
+    from crescent_credentials_amd import workloads as wl
+    l, m, M = _CPU_SHAPES["log14"]
+    cm, w = wl.synthetic_circuit(97, l, m, M, 0.6, 3, profile="gates")
+    rng = random.Random(28)
+    pk = cc.generate_parameters_with_qap(cm, *[rng.randrange(1, oracle.R) for _ in range(4)])
+    spans = [(0, 800), (800, 2500), (2500, 5500), (5500, 10000)]
+    whole = cc.Prover(pk, cm)
+    shards = [cc.Prover(pk, cm, shard_rank=k, shard_count=4, shard_span=spans[k], h_scalars_external=(k > 1)) for k in range(4)]
+    try:
+        D = whole.domain_size
+        slices = [(D * lo // 10000, D * hi // 10000 - D * lo // 10000) for lo, hi in spans]
+        assert [p.h_scalars_slice(k) for k, p in enumerate(shards)] == slices and sum(c for _, c in slices) == D
+        with pytest.raises(cc.CrescentGpuError):
+            shards[0].h_scalars_slice(1)                                 # a span context knows its own shard only
+        for r, s in ((0, 0), (rng.randrange(oracle.R), rng.randrange(oracle.R))):
+            want = whole.prove(w, r, s).data
+            # recompute on the two shards that can, the slices of q on the two that cannot
+            q = shards[0].witness_map_coset(w)                           # natural order (contiguous shards)
+            assert bytes(q) == bytes(shards[1].witness_map_coset(w))
+            parts = b"".join(p.prove_partial(w, r) if k < 2 else p.prove_partial_q(w, q[o * 32:(o + c) * 32], r)
+                             for k, (p, (o, c)) in enumerate(zip(shards, slices)))
+            assert shards[3].assemble(parts, 4, r, s).data == want
+            # the two halves, products on the shards
+            opened = [p.prove_partial_q_begin(w, r) for p in shards]
+            a_side, b_side = opened[0].witness_map_coset_half(0), opened[1].witness_map_coset_half(1)
+            parts2 = b"".join(op.finish2(a_side[o * 32:(o + c) * 32], b_side[o * 32:(o + c) * 32]) for op, (o, c) in zip(opened, slices))
+            assert parts2 == parts
+        for bad in ((5, 5), (7000, 6000), (0, 10001)):
+            with pytest.raises(cc.CrescentGpuError):
+                cc.Prover(pk, cm, shard_rank=0, shard_count=4, shard_span=bad)
+        with pytest.raises(cc.CrescentGpuError):
+            cc.Prover(pk, cm, shard_span=(0, 5000))                      # needs a sharded context
+    finally:
+        whole.close()
+        for p in shards:
+            p.close()

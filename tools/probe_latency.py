@@ -73,5 +73,29 @@ if shard > 1:
     md = lambda x: round(float(np.median(x)), 3)
     print("shards", shard, "two halves: begin + the a side on rank 0", md(th0), "ms, begin + the b side on rank 1", md(th1), "ms (one side alone on an idle GPU",
           md(talone), "ms); product + h share after the slices", md(tf2), "ms; critical path ~", round(max(md(th0), md(th1)) + md(tf2), 3), "ms + two scatters")
+    # ... with UNEQUAL shares (cg_options.shard_span): the two ranks that compute a half carry `ws` of an equal share of the MSMs,
+    # the others the rest; the pieces for ws = 0.6
+    if shard > 2:
+        ws = 0.6
+        w_src = 10000.0 / shard * ws
+        w_oth = (10000.0 - 2 * w_src) / (shard - 2)
+        src_ctx = cc.Prover(pk, cm, shard_rank=0, shard_count=shard, shard_span=(0, int(w_src)))
+        oth_ctx = cc.Prover(pk, cm, shard_rank=2, shard_count=shard, shard_span=(int(2 * w_src), int(2 * w_src + w_oth)), h_scalars_external=True)
+        so, sc_ = src_ctx.h_scalars_slice(0)
+        oo, oc = oth_ctx.h_scalars_slice(2)
+        tsw, tow = [], []
+        for i in range(13):
+            t0 = time.perf_counter(); op = src_ctx.prove_partial_q_begin(wd.data_ptr(), 5, on_device=True); op.witness_map_coset_half(0, out_dev=qa.data_ptr())
+            t_s = (time.perf_counter() - t0) * 1e3
+            t0 = time.perf_counter(); op.finish2(qa.data_ptr() + so * 32, qb.data_ptr() + so * 32, on_device=True); t_s2 = (time.perf_counter() - t0) * 1e3
+            ope = oth_ctx.prove_partial_q_begin(wd.data_ptr(), 5, on_device=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter(); ope.finish2(qa.data_ptr() + oo * 32, qb.data_ptr() + oo * 32, on_device=True); t_o = (time.perf_counter() - t0) * 1e3
+            if i >= 3:
+                tsw.append((t_s, t_s2)); tow.append(t_o)
+        s1, s2 = md([x[0] for x in tsw]), md([x[1] for x in tsw])
+        print("shards", shard, "two halves, unequal shares (sources %.2f of an equal share): begin + a half on a source" % ws, s1, "ms, its product + h share", s2,
+              "ms; another rank's product + h share", md(tow), "ms; critical path ~", round(s1 + max(s2, md(tow)), 3), "ms + two scatters")
+        src_ctx.close(); oth_ctx.close()
     ext.close()
 print("shards", shard, "wall ms", round(float(np.median(ws)), 3), "library total_ms", round(float(np.median(ts)), 3), {k: round(v, 3) for k, v in tm.items() if k.endswith("_ms")})
