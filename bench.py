@@ -1083,6 +1083,34 @@ def main():
                                     "slices and adds the h share"}
                         assert same_h, "the two-halves scatter arrangement's proof differs from the unsharded one"
                         sh_ctx.close()
+                    # ... and with UNEQUAL shares (cg_options.shard_span): the two ranks that compute a half carry 0.6 of an equal
+                    # share of the MSMs, the other ranks the rest (tools/probe_latency.py: 1.9 against 2.2 ms by the pieces at S21 / 8)
+                    if world > 2:
+                        w_src = 10000.0 / world * 0.6
+                        w_oth = (10000.0 - 2 * w_src) / (world - 2)
+                        cuts = [0, int(w_src), int(2 * w_src)] + [int(2 * w_src + w_oth * k) for k in range(1, world - 2)] + [10000]
+                        spans = [(cuts[k], cuts[k + 1]) for k in range(world)]
+                        su_ctx = cc.Prover(pk_s, cm_s, device=local_rank, window_bits=a.window, shard_rank=rank, shard_count=world,
+                                           shard_span=spans[rank], h_scalars_external=(rank > 1))
+                        spu = ShardedProver(su_ctx, dev, group=grp, arrangement="scatter", two_call=True, split_map=True, spans=spans)
+                        for _ in range(3):
+                            spu.prove_dev(ws_s[0].data_ptr(), srng.randrange(R), srng.randrange(R))
+                        barrier_sync(world)
+                        spu.reset_breakdown()
+                        t_start = time.perf_counter()
+                        for k in range(a.sharded_steps):
+                            spu.prove_dev(ws_s[k % len(ws_s)].data_ptr(), srng.randrange(R), srng.randrange(R))
+                        torch.cuda.synchronize()
+                        barrier_sync(world)
+                        dsu_ = max_over_ranks(time.perf_counter() - t_start, world)
+                        r_, s_ = srng.randrange(R), srng.randrange(R)
+                        same_u = spu.prove_dev(ws_s[0].data_ptr(), r_, s_).data == ref_s.prove_dev(ws_s[0].data_ptr(), r_, s_).data
+                        sh["arrangements"]["scatter_two_halves_unequal_shares"] = {
+                            "ms_per_proof": round(dsu_ / a.sharded_steps * 1e3, 3), "collectives_per_proof": 3, "spans_per_10000": spans,
+                            "ms_breakdown_rank0": spu.breakdown_ms(), "bytes_identical_to_unsharded": bool(same_u),
+                            "what": "the two-halves arrangement with the two source ranks carrying 0.6 of an equal share of every query"}
+                        assert same_u, "the unequal-shares arrangement's proof differs from the unsharded one"
+                        su_ctx.close()
                 except AssertionError:
                     raise
                 except Exception as e:

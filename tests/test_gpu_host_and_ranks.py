@@ -496,6 +496,10 @@ def test_bench_gpus_8_as_eight_processes_on_the_one_gpu():
     fl = sh["in_flight"]
     assert fl["proofs_in_flight"] == 2 and fl["all_gathers"] == fl["proofs"] == 16 and fl["bytes_identical_to_unsharded"] is True
     assert fl["scatter_rotating"]["bytes_identical_to_unsharded"] is True and fl["scatter_rotating"]["scatters"] == 16
+    arr = sh["arrangements"]                      # five rows at world 8: the unequal-shares one needs more than the two source ranks
+    assert arr["scatter_two_halves"]["bytes_identical_to_unsharded"] is True
+    un = arr["scatter_two_halves_unequal_shares"]
+    assert un["bytes_identical_to_unsharded"] is True and len(un["spans_per_10000"]) == 8 and un["spans_per_10000"][-1][1] == 10000
 
 
 def test_bench_gpus_2_without_a_shape_shards_config_4s_own_circuit():
