@@ -152,6 +152,15 @@ impl GpuCircuit {
         Self::load_opt(pk, m, sys::cg_options { device, proof_slots, shard_rank, shard_count, flags, ..Default::default() })
     }
 
+    /// `load_shard` with an UNEQUAL share (`cg_options.shard_span`): the shard owns `[n·lo/10000, n·hi/10000)` of every query.
+    /// The spans of a proof's shards must tile `[0, 10000]`; the ranks that also compute (half of) the witness map take the
+    /// smaller ones.
+    pub fn load_shard_span(pk: &ProvingKey<Bn254>, m: &ConstraintMatrices<Fr>, device: i32, proof_slots: i32, shard_rank: i32,
+                           shard_count: i32, span: (u16, u16), flags: i32) -> Result<Self, SynthesisError> {
+        let shard_span = span.0 as i32 | ((span.1 as i32) << 16);
+        Self::load_opt(pk, m, sys::cg_options { device, proof_slots, shard_rank, shard_count, flags, shard_span, ..Default::default() })
+    }
+
     fn load_opt(pk: &ProvingKey<Bn254>, m: &ConstraintMatrices<Fr>, opt: sys::cg_options) -> Result<Self, SynthesisError> {
         let proof_slots = opt.proof_slots;
         let rc = unsafe { sys::cg_init(0, std::ptr::null()) };
@@ -324,6 +333,64 @@ impl GpuCircuit {
                                     std::ptr::null_mut())
         };
         if rc != 0 { Err(map_err(rc)) } else { Ok(out) }
+    }
+}
+
+/// A sharded proof between `cg_prove_partial_q_begin` and `_finish` / `_finish2`: the shard's l, a, b1, b2 partial sums are
+/// queued and running; the h share follows once the slice (or the two halves' slices) has arrived.  Holds one of the circuit's
+/// proof slots; dropped unfinished, it is aborted (`cg_prove_partial_q_abort`).
+pub struct OpenProof<'a> {
+    p: *mut sys::cg_partial,
+    circuit: &'a GpuCircuit,
+}
+
+impl GpuCircuit {
+    /// `cg_prove_partial_q_begin`: open a sharded proof; returns while the assignment-driven sums run.
+    pub fn prove_partial_q_begin(&self, r: Fr, full_assignment: &[Fr]) -> Result<OpenProof<'_>, SynthesisError> {
+        if full_assignment.len() != self.num_variables {
+            return Err(SynthesisError::AssignmentMissing);
+        }
+        let (w, rb) = (canonical_bytes(full_assignment), r.into_bigint().to_bytes_le());
+        let mut p: *mut sys::cg_partial = std::ptr::null_mut();
+        // (the library has copied the assignment to the GPU before it returns: `w` may go)
+        let rc = unsafe { sys::cg_prove_partial_q_begin(self.ctx, w.as_ptr() as *const _, 0, rb.as_ptr(), &mut p) };
+        if rc != 0 { Err(map_err(rc)) } else { Ok(OpenProof { p, circuit: self }) }
+    }
+}
+
+impl<'a> OpenProof<'a> {
+    /// One side of the coset values for this proof's assignment (`cg_partial_witness_map_coset_half`): `which` = 0 the a side,
+    /// 1 the b side; `domain_size` plain canonical scalars, laid out like `witness_map_coset`'s output.
+    pub fn witness_map_coset_half(&self, which: i32) -> Result<Vec<u8>, SynthesisError> {
+        let mut q = vec![0u8; unsafe { sys::cg_domain_size(self.circuit.ctx) } as usize * 32];
+        let rc = unsafe { sys::cg_partial_witness_map_coset_half(self.p, which, q.as_mut_ptr() as *mut _, 0) };
+        if rc != 0 { Err(map_err(rc)) } else { Ok(q) }
+    }
+
+    /// `cg_prove_partial_q_finish`: the h share with this shard's slice of the coset values -> the 384-byte record.
+    pub fn finish(mut self, q_slice: &[u8]) -> Result<[u8; 384], SynthesisError> {
+        let mut out = [0u8; 384];
+        let p = std::mem::replace(&mut self.p, std::ptr::null_mut());      // the call consumes the handle, success or not
+        let rc = unsafe { sys::cg_prove_partial_q_finish(p, q_slice.as_ptr() as *const _, 0, out.as_mut_ptr(), std::ptr::null_mut()) };
+        if rc != 0 { Err(map_err(rc)) } else { Ok(out) }
+    }
+
+    /// `cg_prove_partial_q_finish2`: the same from the shard's slices of BOTH sides; their products are formed on the GPU.
+    pub fn finish2(mut self, a_slice: &[u8], b_slice: &[u8]) -> Result<[u8; 384], SynthesisError> {
+        let mut out = [0u8; 384];
+        let p = std::mem::replace(&mut self.p, std::ptr::null_mut());
+        let rc = unsafe {
+            sys::cg_prove_partial_q_finish2(p, a_slice.as_ptr() as *const _, b_slice.as_ptr() as *const _, 0, out.as_mut_ptr(), std::ptr::null_mut())
+        };
+        if rc != 0 { Err(map_err(rc)) } else { Ok(out) }
+    }
+}
+
+impl<'a> Drop for OpenProof<'a> {
+    fn drop(&mut self) {
+        if !self.p.is_null() {
+            unsafe { sys::cg_prove_partial_q_abort(self.p) }
+        }
     }
 }
 
