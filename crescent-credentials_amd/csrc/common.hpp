@@ -60,42 +60,114 @@ struct AllocScope {
     static void note(int64_t delta) { if (int64_t* c = current()) *c += delta; }
 };
 
+// One allocation that many buffers are carved from (a proof slot's ~56 device buffers and ~11 page-locked ones).  hipMalloc,
+// hipHostMalloc and hipFree each wait for the device; next to a context with sixteen proofs in flight that is ~20 ms apiece, and
+// building sixteen slots buffer by buffer took 19 s there (1.2 s per slot; 0.02 s on an idle GPU: tools/probe_load_under_load.py).
+// While a SlotArena is installed on a thread (ArenaScope), DevBuf::alloc / PinnedBuf::alloc on that thread take their memory
+// from it - 256-byte aligned, not owned: released with the arena - and fall back to an allocation of their own when it is
+// full.  An AllocMeter installed instead adds up what a build asks for, so the next identical build can size its arena.
+struct SlotArena {
+    uint8_t* dev = nullptr;
+    uint8_t* host = nullptr;
+    size_t dev_size = 0, host_size = 0, dev_off = 0, host_off = 0;
+    SlotArena() = default;
+    SlotArena(const SlotArena&) = delete;
+    SlotArena& operator=(const SlotArena&) = delete;
+    ~SlotArena() {
+        if (dev) (void)hipFree(dev);
+        if (host) (void)hipHostFree(host);
+    }
+    static SlotArena*& current() { static thread_local SlotArena* a = nullptr; return a; }
+    void* take_dev(size_t bytes) {
+        const size_t at = (dev_off + 255) & ~(size_t)255;
+        if (!dev || at + bytes > dev_size) return nullptr;
+        dev_off = at + bytes;
+        return dev + at;
+    }
+    void* take_host(size_t bytes) {
+        const size_t at = (host_off + 255) & ~(size_t)255;
+        if (!host || at + bytes > host_size) return nullptr;
+        host_off = at + bytes;
+        return host + at;
+    }
+};
+struct AllocMeter {
+    size_t dev_bytes = 0, host_bytes = 0;          // with the 256-byte alignment an arena would add
+    static AllocMeter*& current() { static thread_local AllocMeter* m = nullptr; return m; }
+    static void note_dev(size_t bytes) { if (AllocMeter* m = current()) m->dev_bytes = ((m->dev_bytes + 255) & ~(size_t)255) + bytes; }
+    static void note_host(size_t bytes) { if (AllocMeter* m = current()) m->host_bytes = ((m->host_bytes + 255) & ~(size_t)255) + bytes; }
+};
+struct ArenaScope {      // installs an arena (or a meter) on this thread for one scope
+    SlotArena* prev_a;
+    AllocMeter* prev_m;
+    ArenaScope(SlotArena* a, AllocMeter* m) : prev_a(SlotArena::current()), prev_m(AllocMeter::current()) {
+        SlotArena::current() = a;
+        AllocMeter::current() = m;
+    }
+    ~ArenaScope() { SlotArena::current() = prev_a; AllocMeter::current() = prev_m; }
+    ArenaScope(const ArenaScope&) = delete;
+    ArenaScope& operator=(const ArenaScope&) = delete;
+};
+
 // RAII device buffer
 template <class T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    bool owned = true;          // false: carved from a SlotArena, which releases it
+    size_t cap_bytes = 0;       // of an arena piece: what was carved (a later, smaller alloc() reuses the piece in place)
     DevBuf() = default;
     explicit DevBuf(size_t count) { alloc(count); }
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n), owned(o.owned), cap_bytes(o.cap_bytes) { o.p = nullptr; o.n = 0; o.owned = true; o.cap_bytes = 0; }
     DevBuf& operator=(DevBuf&& o) noexcept {
-        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        if (this != &o) {
+            release();
+            p = o.p; n = o.n; owned = o.owned; cap_bytes = o.cap_bytes;
+            o.p = nullptr; o.n = 0; o.owned = true; o.cap_bytes = 0;
+        }
         return *this;
     }
     ~DevBuf() { release(); }
     void alloc(size_t count) {
+        if (p && !owned && count && count * sizeof(T) <= cap_bytes) {      // an arena piece re-cut (a re-tune shrinks bucket arrays)
+            AllocScope::note((int64_t)(count * sizeof(T)) - (int64_t)(n * sizeof(T)));
+            n = count;
+            return;
+        }
         release();
         if (count) {
-            const hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
-            if (e != hipSuccess) {
-                p = nullptr;
-                (void)hipGetLastError();        // the failure is reported here, not left behind as the thread's sticky error
-                size_t free_b = 0, total_b = 0;
-                (void)hipMemGetInfo(&free_b, &total_b);
-                char b[256];
-                snprintf(b, sizeof(b), "device allocation of %zu bytes failed: %s (%zu of %zu bytes free on the device)",
-                         count * sizeof(T), hipGetErrorString(e), free_b, total_b);
-                throw ::cg::HipError(e == hipErrorOutOfMemory ? CG_ERR_OUT_OF_MEMORY : CG_ERR_HIP, b);
+            AllocMeter::note_dev(count * sizeof(T));
+            void* q = SlotArena::current() ? SlotArena::current()->take_dev(count * sizeof(T)) : nullptr;
+            if (q) {
+                p = (T*)q;
+                owned = false;
+                cap_bytes = count * sizeof(T);
+            } else {
+                const hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+                if (e != hipSuccess) {
+                    p = nullptr;
+                    (void)hipGetLastError();        // the failure is reported here, not left behind as the thread's sticky error
+                    size_t free_b = 0, total_b = 0;
+                    (void)hipMemGetInfo(&free_b, &total_b);
+                    char b[256];
+                    snprintf(b, sizeof(b), "device allocation of %zu bytes failed: %s (%zu of %zu bytes free on the device)",
+                             count * sizeof(T), hipGetErrorString(e), free_b, total_b);
+                    throw ::cg::HipError(e == hipErrorOutOfMemory ? CG_ERR_OUT_OF_MEMORY : CG_ERR_HIP, b);
+                }
+                owned = true;
             }
         }
         n = count;
         AllocScope::note((int64_t)(count * sizeof(T)));
     }
     void release() {
-        if (p) { (void)hipFree(p); AllocScope::note(-(int64_t)(n * sizeof(T))); }
-        p = nullptr; n = 0;
+        if (p) {
+            if (owned) (void)hipFree(p);
+            AllocScope::note(-(int64_t)(n * sizeof(T)));
+        }
+        p = nullptr; n = 0; owned = true; cap_bytes = 0;
     }
     size_t bytes() const { return n * sizeof(T); }
 };
@@ -104,18 +176,30 @@ template <class T>
 struct PinnedBuf {
     T* p = nullptr;
     size_t n = 0;
+    bool owned = true;
     PinnedBuf() = default;
     explicit PinnedBuf(size_t count) { alloc(count); }
     PinnedBuf(const PinnedBuf&) = delete;
     PinnedBuf& operator=(const PinnedBuf&) = delete;
     ~PinnedBuf() { free_now(); }
     void free_now() {
-        if (p) (void)hipHostFree(p);
+        if (p && owned) (void)hipHostFree(p);
         p = nullptr;
+        owned = true;
     }
     void alloc(size_t count) {
         free_now();
-        if (count) CG_HIP(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault));
+        if (count) {
+            AllocMeter::note_host(count * sizeof(T));
+            void* q = SlotArena::current() ? SlotArena::current()->take_host(count * sizeof(T)) : nullptr;
+            if (q) {
+                p = (T*)q;
+                owned = false;
+            } else {
+                CG_HIP(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault));
+                owned = true;
+            }
+        }
         n = count;
     }
     // the address kernels use to write this host memory directly (results of a few KB: no copy kernel, no extra

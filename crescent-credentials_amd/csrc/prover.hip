@@ -126,6 +126,9 @@ using namespace cg;
 // several proofs can overlap on one GPU (the latency-bound tails of one proof hide under the bulk kernels
 // of another); the key tables, matrices and NTT tables are shared and read-only.
 struct ProofSlot {
+    // the slot's device and page-locked buffers are carved from ONE allocation each (common.hpp SlotArena) when the size is
+    // known - every slot after a set's first; declared first: released after everything that points into it
+    std::unique_ptr<SlotArena> arena;
     std::mutex busy;
     // one-stream slots: the five MSMs of a proof run one after another, so their entry lists and segment pieces live in
     // ONE scratch sized for the largest (declared before the engines that point into it: destroyed after them)
@@ -460,10 +463,25 @@ static void load_query(MsmBases<F>& bases, const uint8_t* bytes, uint32_t form, 
 // zs: the stream the engines' initial zero-fills go out on; the caller waits for it ONCE after its last slot (a wait per
 // engine is a wait for a fill kernel to be scheduled, and behind a busy context that is tens of ms each: eighty of them made
 // a sixteen-slot set take 2 s on a loaded GPU).
+// rec: what a slot of this set asks for, measured on the set's first slot (built buffer by buffer) and used to size the ONE
+// device and ONE page-locked allocation every later slot is carved from.
+struct SlotRecipe { size_t dev_bytes = 0, host_bytes = 0; };
 static std::unique_ptr<ProofSlot> make_slot(cg_ctx* c, const MsmBases<Fq>* bh, const MsmBases<Fq>* bl, const MsmBases<Fq>* ba,
-                                            const MsmBases<Fq>* bb1, const MsmBases<Fq2>* bb2, hipStream_t zs) {
+                                            const MsmBases<Fq>* bb1, const MsmBases<Fq2>* bb2, hipStream_t zs, SlotRecipe& rec) {
     CG_HIP(hipSetDevice(c->device));
     std::unique_ptr<ProofSlot> sl(new ProofSlot());
+    AllocMeter meter;
+    if (rec.dev_bytes) {
+        sl->arena.reset(new SlotArena());
+        DevBuf<uint8_t> whole(rec.dev_bytes);                 // (DevBuf for its out-of-memory report; the arena takes the memory over)
+        sl->arena->dev = whole.p; sl->arena->dev_size = rec.dev_bytes;
+        whole.p = nullptr; whole.n = 0;
+        if (rec.host_bytes) {
+            CG_HIP(hipHostMalloc((void**)&sl->arena->host, rec.host_bytes, hipHostMallocDefault));
+            sl->arena->host_size = rec.host_bytes;
+        }
+    }
+    ArenaScope carve(sl->arena.get(), rec.dev_bytes ? nullptr : &meter);
     // A throughput context runs every proof on ONE stream: with a dozen proofs in flight the overlap comes from the
     // other proofs, and twelve streams fit the hardware queues one each, where 60 share them (and anything above
     // ~24 user queues per process is time-sliced by the hardware scheduler in 15 ms quanta): 192 proofs/s on 16
@@ -507,6 +525,7 @@ static std::unique_ptr<ProofSlot> make_slot(cg_ctx* c, const MsmBases<Fq>* bh, c
         sl->h_canon.alloc(c->D);
         sl->wm.alloc(c->M, c->D, std::max(c->A.sell_scratch, std::max(c->B.sell_scratch, c->C.sell_scratch)));
     }
+    if (!rec.dev_bytes) { rec.dev_bytes = meter.dev_bytes + 4096; rec.host_bytes = meter.host_bytes + 4096; }
     return sl;
 }
 
@@ -598,8 +617,9 @@ static void staged_worker(cg_ctx* c) {
         {
             const auto tt = std::chrono::steady_clock::now();
             ScopedStream zs;
+            SlotRecipe rec;
             for (int k = 0; k < c->n_slots_final; ++k) {
-                slots.push_back(make_slot(c, &bh, &bl, &ba, &bb1, &bb2, zs));
+                slots.push_back(make_slot(c, &bh, &bl, &ba, &bb1, &bb2, zs, rec));
                 stop();
             }
             CG_HIP(hipStreamSynchronize(zs));
@@ -866,7 +886,8 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         // final ones.
         const int n_now = staged ? std::min(n_slots, 4) : n_slots;
         if (staged) c->folded = false;                    // the arrangement in force until the swap
-        for (int k = 0; k < n_now; ++k) c->slots.push_back(make_slot(c.get(), &c->bh, &c->bl, &c->ba, &c->bb1, &c->bb2, s0));
+        SlotRecipe slot_recipe;
+        for (int k = 0; k < n_now; ++k) c->slots.push_back(make_slot(c.get(), &c->bh, &c->bl, &c->ba, &c->bb1, &c->bb2, s0, slot_recipe));
         CG_HIP(hipStreamSynchronize(s0));
         // Four shared copy-only streams when the runtime's hardware queues hold them beside the proof streams one each
         // (GPU_MAX_HW_QUEUES is the HIP runtime's own variable; cg_init asks for 20); with fewer queues four shared streams
