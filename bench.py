@@ -766,6 +766,12 @@ def main():
         "config": {"workload": "%s shape: D=2^%d, m=%d, M=%d, l=%d, nnz=%d (%s mix); bit_fraction=%.2f; pk from seeded trapdoor (GPU setup)" %
                    (a.shape, prover.domain_size.bit_length() - 1, m, M, l, nnz, a.profile, a.bits),
                    "wires": wires, "mode": "throughput (one full key replica per GPU)",
+                   "baseline_configs": "value = configs[2] (rs256-sd, the circuit BASELINE's metric is quoted on) on one GPU; configs[1] "
+                                       "(rs256) and configs[4] (rs256-db, one replica per GPU: --gpus N) are this S21 shape with l = 20 / 28 "
+                                       "instead of 26 - a few of 1.5 M wires move between the l query and gamma_abc, which no kernel's "
+                                       "time can tell apart, so their rate IS `value` (all three proved at full size by tests/"
+                                       "test_gpu_fullsize.py); configs[3] (mdl1 / S22 sharded over the ranks) is `sharded`, its one-GPU "
+                                       "rate `shapes.mdl1`; configs[0] is the CPU path: `cpu_baseline`",
                    "h_query_basis": "coefficient" if a.h_coefficient_basis else "coset evaluation (transformed at load)",
                    "proofs_per_rank": n_timed, "proofs_in_flight_per_gpu": inflight,
                    "inputs": {"host": "witness in HOST memory (pageable) -> proof through cg_prove, the metric as SURVEY 8d writes it: every "
@@ -945,8 +951,8 @@ def main():
             srng = random.Random(99)                     # the same (r, s) on every rank
             # The sharded proofs are made on config 4's own circuit - mdl1, S22 (BASELINE.json configs[3]: "mdl1 ... MSM sharded
             # across 8 x MI355X") - unless the run was given a shape; `value` above stays the replica rate of the headline shape.
-            # (Config 5's shape, rs256-db, is the headline's with l = 28 instead of 26: two more of 1.5 M wires move from the l
-            # query to gamma_abc, which no kernel's time can tell apart - its replica rate IS `value`.)
+            # (configs[4]'s shape, rs256-db, is the headline's with l = 28 instead of 26: two more of 1.5 M wires move from the l
+            # query to gamma_abc, which no kernel's time can tell apart - its replica rate IS `value`; `config.baseline_configs`.)
             if a.sharded_shape != a.shape:
                 ls_, ms_, Ms_ = wl.SHAPES[a.sharded_shape]
                 t_w = time.time()
