@@ -783,6 +783,7 @@ def main():
                    "witness_origin": a.witness, "caller_threads": callers,
                    "context": {"resident_GB": round(info["total_bytes"] / 1e9, 2), "tables_GB": round(info["table_bytes"] / 1e9, 2),
                                "per_slot_GB": round(info["slot_bytes"] / 1e9, 3),
+                               "lone_slot_GB": round(info["lone_slot_bytes"] / 1e9, 3),     # the extra slot a proof arriving alone runs on
                                "per_slot_GB_by_kind": {k[5:-6]: round(info[k] / 1e9, 3) for k in
                                                        ("slot_entry_bytes", "slot_piece_bytes", "slot_bucket_bytes", "slot_transform_bytes",
                                                         "slot_upload_bytes")},
@@ -915,8 +916,8 @@ def main():
                 curve.append({"in_flight": k, "proofs": n_, "proofs_per_s": round(rate_, 2),
                               "latency_ms": percentiles_ms([d for t_, d in lat if t_ > done_[k - 1]])})
             knee = next((c_["in_flight"] for c_ in curve if c_["proofs_per_s"] >= 0.95 * max(x["proofs_per_s"] for x in curve)), None)
-            out["inflight_curve"] = {"points": curve, "callers": "k host threads on the headline context (%d slots, throughput arrangement), witness "
-                                     "from %s memory" % (inflight, a.witness),
+            out["inflight_curve"] = {"points": curve, "callers": "k host threads on the headline context (%d slots, throughput arrangement, + the lone slot a "
+                                     "proof that finds nothing in flight runs on: the k = 1 point), witness from %s memory" % (inflight, a.witness),
                                      "in_flight_for_95_pct_of_the_best_rate": knee}
         except Exception as e:
             out["inflight_curve"] = {"error": repr(e)}

@@ -26,6 +26,7 @@ CG_FORM_CANONICAL, CG_FORM_MONTGOMERY = 0, 1
 CG_FLAG_H_COEFFICIENT_BASIS = 1
 CG_FLAG_LATENCY_MODE, CG_FLAG_THROUGHPUT_MODE, CG_FLAG_SPIN_WAIT, CG_FLAG_CONTIGUOUS_H_SHARDS, CG_FLAG_H_SCALARS_EXTERNAL = 2, 4, 8, 16, 32
 CG_FLAG_STAGED_LOAD = 64
+CG_FLAG_NO_LONE_SLOT = 128
 
 
 class CrescentGpuError(RuntimeError):
@@ -78,8 +79,9 @@ class CgCtxInfo(C.Structure):
                 ("device_free_bytes", C.c_uint64), ("device_total_bytes", C.c_uint64), ("proof_slots", C.c_int32),
                 ("window_bits", C.c_int32 * 5), ("tuned", C.c_int32), ("retune_skipped_for_memory", C.c_int32),
                 ("retune_attempts", C.c_int32), ("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("latency_mode", C.c_int32),
-                ("warmup", C.c_int32), ("reserved", C.c_int32 * 3), ("slot_entry_bytes", C.c_uint64), ("slot_piece_bytes", C.c_uint64),
-                ("slot_bucket_bytes", C.c_uint64), ("slot_transform_bytes", C.c_uint64), ("slot_upload_bytes", C.c_uint64)]
+                ("warmup", C.c_int32), ("lone_slots", C.c_int32), ("reserved", C.c_int32 * 2), ("slot_entry_bytes", C.c_uint64),
+                ("slot_piece_bytes", C.c_uint64), ("slot_bucket_bytes", C.c_uint64), ("slot_transform_bytes", C.c_uint64),
+                ("slot_upload_bytes", C.c_uint64), ("lone_slot_bytes", C.c_uint64)]
 
 
 class CgLoadTimings(C.Structure):
@@ -434,8 +436,10 @@ class Prover:
     def __init__(self, pk: ProvingKey, matrices: ConstraintMatrices, device: int = -1, window_bits: int = 0,
                  shard_rank: int = 0, shard_count: int = 1, proof_slots: int = 1, h_coefficient_basis: bool = False,
                  mode: Optional[str] = None, spin_wait: bool = False, contiguous_h_shards: bool = False,
-                 h_scalars_external: bool = False, flags: int = 0, staged_load: bool = False, shard_span: Optional[Tuple[int, int]] = None):
-        """h_coefficient_basis=True keeps the h query as loaded (seven transforms per proof, CG_FLAG_H_COEFFICIENT_BASIS).
+                 h_scalars_external: bool = False, flags: int = 0, staged_load: bool = False, shard_span: Optional[Tuple[int, int]] = None,
+                 lone_slot: bool = True):
+        """lone_slot=False: CG_FLAG_NO_LONE_SLOT (a throughput context then holds no extra slot for proofs that arrive alone).
+        h_coefficient_basis=True keeps the h query as loaded (seven transforms per proof, CG_FLAG_H_COEFFICIENT_BASIS).
         shard_span: (lo, hi) in 1/10000 of every query - this shard's part instead of the shard_rank-th of shard_count equal parts
         (cg_options.shard_span: unequal shares for the ranks that also run the witness map).
         staged_load: CG_FLAG_STAGED_LOAD - the call returns as soon as the context can prove (warm-up arrangement) and a worker
@@ -448,7 +452,7 @@ class Prover:
         flags |= (CG_FLAG_H_COEFFICIENT_BASIS if h_coefficient_basis else 0) | (CG_FLAG_LATENCY_MODE if mode == "latency" else 0) | \
                  (CG_FLAG_THROUGHPUT_MODE if mode == "throughput" else 0) | (CG_FLAG_SPIN_WAIT if spin_wait else 0) | \
                  (CG_FLAG_CONTIGUOUS_H_SHARDS if contiguous_h_shards else 0) | (CG_FLAG_H_SCALARS_EXTERNAL if h_scalars_external else 0) | \
-                 (CG_FLAG_STAGED_LOAD if staged_load else 0)
+                 (CG_FLAG_STAGED_LOAD if staged_load else 0) | (0 if lone_slot else CG_FLAG_NO_LONE_SLOT)
         L = lib()
         self.num_inputs = matrices.num_instance_variables
         self.num_constraints = matrices.num_constraints

@@ -140,14 +140,18 @@ struct ProofSlot {
     const Fr* knock_h = nullptr;       // tuning builds (KNOCK & 16): the h scalars of this slot's first proof, reused
     Wm29Buffers wm;
     hipStream_t st[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // 0: witness map + h, 1: l, 2: a, 3: b1, 4: b2
+    bool st_borrowed[5] = {false, false, false, false, false};          // a lone slot runs on streams of the one-stream slots
     hipEvent_t ev_w = nullptr;
     hipEvent_t ev_b1 = nullptr;        // b1's entries are grouped (the G2 MSM adopts them)
     hipEvent_t ev_done = nullptr;      // one-stream slots: recorded behind the proof's last kernel and polled (wait_sleeping)
     bool one_stream = false;
+    // the extra slot of a throughput context, taken by a proof that arrives when no other is in flight (cg_ctx::acquire): five
+    // streams and the latency arrangement of the engines, as a latency context's only slot has them
+    bool lone = false;
     hipEvent_t ev_t[2] = {nullptr, nullptr};
     ~ProofSlot() {
         for (int i = 0; i < 5; ++i)
-            if (st[i] && (i == 0 || st[i] != st[0])) (void)hipStreamDestroy(st[i]);
+            if (st[i] && !st_borrowed[i] && (i == 0 || st[i] != st[0])) (void)hipStreamDestroy(st[i]);
         if (ev_w) (void)hipEventDestroy(ev_w);
         if (ev_b1) (void)hipEventDestroy(ev_b1);
         if (ev_done) (void)hipEventDestroy(ev_done);
@@ -314,33 +318,49 @@ struct cg_ctx {
     uint64_t slot_part[5] = {0, 0, 0, 0, 0};
     std::mutex pick_mu;
     std::condition_variable pick_cv;
-    // blocks until a slot is free; returns it locked
-    ProofSlot* acquire() {
+    int in_flight = 0;           // slots taken (pick_mu)
+    // Blocks until a slot is free; returns it locked.  A throughput context keeps its proofs on one stream each because the
+    // overlap comes from the OTHER proofs in flight; a proof that finds none (a server between requests: one task per credential,
+    // sample/client_helper/src/main.rs:177-216) would run its seventy launches back to back on an otherwise empty chip - 10.9 ms
+    // where a latency context takes 6.  Such a proof (`may_run_alone`, and fewer than n_lone proofs in flight) gets one of the
+    // context's LONE slots.
+    ProofSlot* acquire(bool may_run_alone = false) {
         std::unique_lock<std::mutex> lk(pick_mu);
         for (;;) {
+            if (may_run_alone && in_flight < n_lone)
+                for (auto& sp : slots)
+                    if (sp->lone && sp->busy.try_lock()) { ++in_flight; return sp.get(); }
             for (auto& sp : slots)
-                if (sp->busy.try_lock()) return sp.get();
+                if (!sp->lone && sp->busy.try_lock()) { ++in_flight; return sp.get(); }
             pick_cv.wait(lk);
         }
     }
     void release(ProofSlot* sl) {
         sl->busy.unlock();
         std::lock_guard<std::mutex> lk(pick_mu);
+        --in_flight;
         pick_cv.notify_one();
     }
+    int64_t lone_slot_bytes = 0;
+    int n_lone = 0;              // lone slots wanted: a throughput context with more than one slot, unless CG_FLAG_NO_LONE_SLOT
 };
 // what ONE proof slot holds on the device, by kind, read off the first slot's buffers (the slots are identical); called
 // when the slots are made and after a re-tune has re-sized them
+static uint64_t slot_device_bytes(const ProofSlot& S, uint64_t part[4]) {
+    uint64_t ent = S.scratch.entry_bytes(), pcs = S.scratch.piece_bytes(), oth = 0;
+    S.eh.device_bytes(ent, pcs, oth); S.el.device_bytes(ent, pcs, oth); S.ea.device_bytes(ent, pcs, oth);
+    S.eb1.device_bytes(ent, pcs, oth); S.eb2.device_bytes(ent, pcs, oth);
+    part[0] = ent; part[1] = pcs; part[2] = oth;
+    part[3] = S.wm.device_bytes() + S.h_canon.bytes();
+    return ent + pcs + oth + part[3];
+}
 static void account_slot(cg_ctx* c) {
-    uint64_t ent = 0, pcs = 0, oth = 0;
-    if (!c->slots.empty()) {
-        const ProofSlot& S = *c->slots[0];
-        ent = S.scratch.entry_bytes(); pcs = S.scratch.piece_bytes();
-        S.eh.device_bytes(ent, pcs, oth); S.el.device_bytes(ent, pcs, oth); S.ea.device_bytes(ent, pcs, oth);
-        S.eb1.device_bytes(ent, pcs, oth); S.eb2.device_bytes(ent, pcs, oth);
-        c->slot_part[3] = S.wm.device_bytes() + S.h_canon.bytes();
-    }
-    c->slot_part[0] = ent; c->slot_part[1] = pcs; c->slot_part[2] = oth;
+    uint64_t part[4] = {0, 0, 0, 0};
+    c->lone_slot_bytes = 0;
+    for (auto& sp : c->slots)
+        if (sp->lone) { uint64_t lp[4]; c->lone_slot_bytes += (int64_t)slot_device_bytes(*sp, lp); }
+    if (!c->slots.empty() && !c->slots[0]->lone) (void)slot_device_bytes(*c->slots[0], part);
+    for (int k = 0; k < 4; ++k) c->slot_part[k] = part[k];
     c->slot_part[4] = c->uploads.empty() ? 0 : c->uploads[0]->w.bytes();      // about one upload buffer per proof in flight
     c->slot_bytes = 0;
     for (uint64_t v : c->slot_part) c->slot_bytes += (int64_t)v;
@@ -370,7 +390,7 @@ struct SlotGuard {
     cg_ctx* c;
     ProofSlot* s;
     int exceptions;
-    explicit SlotGuard(cg_ctx* ctx) : c(ctx), s(ctx->acquire()), exceptions(std::uncaught_exceptions()) {}
+    explicit SlotGuard(cg_ctx* ctx, bool may_run_alone = false) : c(ctx), s(ctx->acquire(may_run_alone)), exceptions(std::uncaught_exceptions()) {}
     ~SlotGuard() {
         // a failure part-way through a proof may leave kernels queued on the slot's streams: drain them before the
         // working set is handed to the next proof
@@ -467,9 +487,11 @@ static void load_query(MsmBases<F>& bases, const uint8_t* bytes, uint32_t form, 
 // device and ONE page-locked allocation every later slot is carved from.
 struct SlotRecipe { size_t dev_bytes = 0, host_bytes = 0; };
 static std::unique_ptr<ProofSlot> make_slot(cg_ctx* c, const MsmBases<Fq>* bh, const MsmBases<Fq>* bl, const MsmBases<Fq>* ba,
-                                            const MsmBases<Fq>* bb1, const MsmBases<Fq2>* bb2, hipStream_t zs, SlotRecipe& rec) {
+                                            const MsmBases<Fq>* bb1, const MsmBases<Fq2>* bb2, hipStream_t zs, SlotRecipe& rec, bool lone = false,
+                                            const std::vector<hipStream_t>& borrow = {}) {
     CG_HIP(hipSetDevice(c->device));
     std::unique_ptr<ProofSlot> sl(new ProofSlot());
+    sl->lone = lone;
     AllocMeter meter;
     if (rec.dev_bytes) {
         sl->arena.reset(new SlotArena());
@@ -490,8 +512,8 @@ static std::unique_ptr<ProofSlot> make_slot(cg_ctx* c, const MsmBases<Fq>* bh, c
     // (CG_FLAG_THROUGHPUT_MODE with one slot is the profiling arrangement: a kernel trace of one proof at a time on one
     // stream shows stand-alone durations of the kernels the pipelined run launches.  Tuning builds: CG_SERIAL_STREAMS=1 / 0
     // decouples the stream count from the mode.)
-    bool serial = !c->latency;
-    if (const char* e = CG_TUNE_ENV("SERIAL_STREAMS")) serial = e[0] == '1';
+    bool serial = !c->latency && !lone;
+    if (const char* e = CG_TUNE_ENV("SERIAL_STREAMS")) serial = e[0] == '1' && !lone;
     // tuning builds, CG_CHAIN_PRIORITY=1 (experiment): the witness-map -> h-MSM chain, which sets a lone proof's latency,
     // on a high-priority stream
     const bool chain_prio = CG_TUNE_ENV("CHAIN_PRIORITY") && CG_TUNE_ENV("CHAIN_PRIORITY")[0] == '1';
@@ -499,6 +521,7 @@ static std::unique_ptr<ProofSlot> make_slot(cg_ctx* c, const MsmBases<Fq>* bh, c
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     for (int i = 0; i < 5; ++i) {
         if (serial && i) sl->st[i] = sl->st[0];
+        else if ((size_t)i < borrow.size()) { sl->st[i] = borrow[i]; sl->st_borrowed[i] = true; }
         else if (chain_prio && i == 0) CG_HIP(hipStreamCreateWithPriority(&sl->st[i], hipStreamNonBlocking, prio_hi));
         else CG_HIP(hipStreamCreateWithFlags(&sl->st[i], hipStreamNonBlocking));
     }
@@ -507,7 +530,7 @@ static std::unique_ptr<ProofSlot> make_slot(cg_ctx* c, const MsmBases<Fq>* bh, c
     CG_HIP(hipEventCreateWithFlags(&sl->ev_done, hipEventDisableTiming));
     sl->one_stream = serial;
     for (auto& e : sl->ev_t) CG_HIP(hipEventCreate(&e));
-    const bool latency = c->latency;
+    const bool latency = c->latency || lone;
     sl->eh.latency_mode = sl->el.latency_mode = sl->ea.latency_mode = sl->eb1.latency_mode = sl->eb2.latency_mode = latency;
 #ifdef CG_WITH_BATCH_AFFINE
     if (CG_TUNE_ENV("BA_H_ONLY")) sl->el.ba_allowed = sl->ea.ba_allowed = sl->eb1.ba_allowed = false;   // experiment switch
@@ -527,6 +550,28 @@ static std::unique_ptr<ProofSlot> make_slot(cg_ctx* c, const MsmBases<Fq>* bh, c
     }
     if (!rec.dev_bytes) { rec.dev_bytes = meter.dev_bytes + 4096; rec.host_bytes = meter.host_bytes + 4096; }
     return sl;
+}
+
+// The lone slots of a throughput context (cg_ctx::acquire).  A device with no room left for them does without: the context
+// then proves every proof on a one-stream slot.
+static void add_lone_slot(cg_ctx* c, std::vector<std::unique_ptr<ProofSlot>>& slots, const MsmBases<Fq>* bh, const MsmBases<Fq>* bl,
+                          const MsmBases<Fq>* ba, const MsmBases<Fq>* bb1, const MsmBases<Fq2>* bb2, hipStream_t zs) {
+    if (c->n_lone <= 0) return;
+    try {
+        SlotRecipe own;                       // its buffers are a latency slot's: measured, not the one-stream slots' recipe
+        // A lone slot is in use when (next to) nothing else is: it runs on streams the one-stream slots own - the LAST slots',
+        // which a proof takes only when all the others are busy - so the context has no more streams than it had, one per
+        // hardware queue (cg_init).
+        size_t next = slots.size();
+        for (int k = 0; k < c->n_lone; ++k) {
+            std::vector<hipStream_t> borrow;
+            while (borrow.size() < 5 && next > 2 && !slots[next - 1]->lone) borrow.push_back(slots[--next]->st[0]);   // (never the first two slots')
+            slots.push_back(make_slot(c, bh, bl, ba, bb1, bb2, zs, own, true, borrow));
+        }
+    } catch (const HipError& e) {
+        if (e.code != CG_ERR_OUT_OF_MEMORY) throw;
+        (void)hipGetLastError();
+    }
 }
 
 // threads of a loader that are joined on every way out of its scope
@@ -622,6 +667,7 @@ static void staged_worker(cg_ctx* c) {
                 slots.push_back(make_slot(c, &bh, &bl, &ba, &bb1, &bb2, zs, rec));
                 stop();
             }
+            add_lone_slot(c, slots, &bh, &bl, &ba, &bb1, &bb2, zs);
             CG_HIP(hipStreamSynchronize(zs));
             ms_slots = ms_since(tt);
         }
@@ -703,7 +749,7 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
     if (opt && opt->shard_span != 0 && (shard_count <= 1 || span_lo >= span_hi || span_hi > 10000))
         return fail(CG_ERR_INVALID_ARGUMENT, "shard_span needs a sharded context and 0 <= lo < hi <= 10000");
     constexpr int32_t KNOWN_FLAGS = CG_FLAG_H_COEFFICIENT_BASIS | CG_FLAG_LATENCY_MODE | CG_FLAG_THROUGHPUT_MODE | CG_FLAG_SPIN_WAIT |
-                                    CG_FLAG_CONTIGUOUS_H_SHARDS | CG_FLAG_H_SCALARS_EXTERNAL | CG_FLAG_STAGED_LOAD;
+                                    CG_FLAG_CONTIGUOUS_H_SHARDS | CG_FLAG_H_SCALARS_EXTERNAL | CG_FLAG_STAGED_LOAD | CG_FLAG_NO_LONE_SLOT;
     if (opt && (opt->flags & ~KNOWN_FLAGS)) return fail(CG_ERR_INVALID_ARGUMENT, "unknown bits in flags");
     if (opt && (opt->flags & CG_FLAG_H_SCALARS_EXTERNAL) && ((opt->flags & CG_FLAG_H_COEFFICIENT_BASIS) || shard_count <= 1))
         return fail(CG_ERR_INVALID_ARGUMENT, "flags: CG_FLAG_H_SCALARS_EXTERNAL needs a sharded context over the folded key");
@@ -910,6 +956,13 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
             for (auto& e : u->ev) CG_HIP(hipEventCreate(&e));
             CG_HIP(hipEventCreateWithFlags(&u->ev_done, hipEventDisableTiming));
             c->uploads.push_back(std::move(u));
+        }
+        // two of them: with two proofs in flight both still gain (145 against 123-131 proofs/s at 2^21); a third buys nothing
+        c->n_lone = (!c->latency && n_slots > 1 && !(opt && (opt->flags & CG_FLAG_NO_LONE_SLOT))) ? std::min(2, n_slots - 1) : 0;
+        if (const char* e = CG_TUNE_ENV("LONE_SLOTS")) if (c->n_lone) c->n_lone = atoi(e);      // tuning builds (A/B aid)
+        if (!staged) {                                    // (a staged load's warm-up slots are few and short-lived: the worker adds it)
+            add_lone_slot(c.get(), c->slots, &c->bh, &c->bl, &c->ba, &c->bb1, &c->bb2, s0);
+            CG_HIP(hipStreamSynchronize(s0));
         }
         c->lt.slots_ms = ms_since(t_slots);
         account_slot(c.get());
@@ -1371,7 +1424,8 @@ static int prove_common(cg_ctx* ctx, const void* assignment, bool on_device, con
                 upload_ms = upload_assignment(ctx, up.u, assignment, tm != nullptr);
                 w_dev = up.u->w.p;
             }
-            SlotGuard g(ctx);
+            // (a TIMED proof stays on a one-stream slot: its phases are then stand-alone durations that add up)
+            SlotGuard g(ctx, tm == nullptr);
             e = prove_partial_impl(ctx, g.s, w_dev, scalar_is_zero(r), P, tm, &overlap);
             if (!e) snapshot_tune_stats(ctx, g.s, scalar_is_zero(r), ts);
             if (!e && tm) { tm->upload_ms = upload_ms; tm->total_ms += upload_ms; }
@@ -1814,8 +1868,12 @@ extern "C" int cg_ctx_get_info(cg_ctx* ctx, cg_ctx_info* out) {
         out->table_bytes = (uint64_t)ctx->table_bytes;
         out->matrix_bytes = (uint64_t)ctx->matrix_bytes;
         out->slot_bytes = (uint64_t)ctx->slot_bytes;
-        out->proof_slots = (int32_t)ctx->slots.size();
-        out->total_bytes = out->table_bytes + out->matrix_bytes + out->slot_bytes * (uint64_t)out->proof_slots;
+        int n_regular = 0;
+        for (auto& sp : ctx->slots) n_regular += sp->lone ? 0 : 1;
+        out->proof_slots = n_regular;
+        out->lone_slots = (int32_t)ctx->slots.size() - n_regular;
+        out->lone_slot_bytes = (uint64_t)ctx->lone_slot_bytes;
+        out->total_bytes = out->table_bytes + out->matrix_bytes + out->slot_bytes * (uint64_t)out->proof_slots + out->lone_slot_bytes;
         CG_HIP(hipSetDevice(ctx->device));
         size_t free_b = 0, total_b = 0;
         CG_HIP(hipMemGetInfo(&free_b, &total_b));

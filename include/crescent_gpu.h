@@ -149,7 +149,16 @@ enum {
      * same in both arrangements (they are the same group elements).  cg_ctx_wait_ready blocks until the swap; a host that
      * never calls it loses nothing but the first seconds' throughput.  Honoured for unsharded contexts over the folded key;
      * sharded contexts and CG_FLAG_H_COEFFICIENT_BASIS load synchronously as before. */
-    CG_FLAG_STAGED_LOAD = 64
+    CG_FLAG_STAGED_LOAD = 64,
+    /* A THROUGHPUT context with more than one slot holds up to two slots more than proof_slots: the LONE slots, arranged as a
+     * latency context's (five streams, short segments).  A proof that arrives when fewer than two proofs of the context are in
+     * flight - a server between requests: the sample client proves one credential per task,
+     * sample/client_helper/src/main.rs:177-216 - runs on one of them (at 2^21 from pageable memory: 7.7 ms instead of 10.9 alone,
+     * 13.8 instead of 15.3-16.4 in a pair); proofs that find more in flight take the one-stream slots as before, so the steady
+     * rate is untouched.  Costs a latency slot's memory each (cg_ctx_info.lone_slot_bytes is their sum; a device without room
+     * for them does without) and no stream: they run on streams of the last one-stream slots.  A call that asks for cg_timings
+     * always runs on a one-stream slot: its phases are then stand-alone durations that add up.  This flag leaves them out. */
+    CG_FLAG_NO_LONE_SLOT = 128
 };
 
 /* Per-phase wall/GPU times of one cg_prove call, mirroring the reference's `print-trace` phases
@@ -244,7 +253,7 @@ typedef struct cg_ctx_info {
     uint64_t table_bytes;        /* per-window base tables of the five queries + validity flags (shared by all slots) */
     uint64_t matrix_bytes;       /* resident constraint matrices + NTT / coset tables */
     uint64_t slot_bytes;         /* ONE proof slot's working set; the context holds proof_slots of them */
-    uint64_t total_bytes;        /* table_bytes + matrix_bytes + proof_slots x slot_bytes */
+    uint64_t total_bytes;        /* table_bytes + matrix_bytes + proof_slots x slot_bytes + lone_slot_bytes */
     uint64_t device_free_bytes;  /* hipMemGetInfo at the time of the call */
     uint64_t device_total_bytes;
     int32_t proof_slots;
@@ -256,7 +265,8 @@ typedef struct cg_ctx_info {
     int32_t shard_count;
     int32_t latency_mode;        /* 1: short accumulation segments + tree reductions (one proof at a time); 0: throughput */
     int32_t warmup;              /* 1: a staged load (CG_FLAG_STAGED_LOAD) whose final arrangement is not in force yet */
-    int32_t reserved[3];
+    int32_t lone_slots;          /* extra slots for proofs that arrive (nearly) alone: 0-2 (CG_FLAG_NO_LONE_SLOT) */
+    int32_t reserved[2];
     /* slot_bytes by kind (they add up to it).  In a throughput context the five MSMs of a proof run one after another and
      * share one set of entry lists and segment pieces, sized for the largest of them; a latency context (proof_slots = 1)
      * runs them concurrently and holds a set per MSM. */
@@ -265,6 +275,7 @@ typedef struct cg_ctx_info {
     uint64_t slot_bucket_bytes;    /* bucket arrays, row / column sums of the reduction, partition histograms and cursors */
     uint64_t slot_transform_bytes; /* the witness map's vectors (assignment + four domain-sized vectors) and the h MSM's scalars */
     uint64_t slot_upload_bytes;    /* one device copy of an assignment arriving from the host (the context holds proof_slots + 2) */
+    uint64_t lone_slot_bytes;      /* the lone slots' working sets together (each a set of entry lists and pieces per MSM) */
 } cg_ctx_info;
 int cg_ctx_get_info(cg_ctx* ctx, cg_ctx_info* out);
 

@@ -11,6 +11,7 @@ pub const CG_FLAG_SPIN_WAIT: i32 = 8;
 pub const CG_FLAG_CONTIGUOUS_H_SHARDS: i32 = 16;
 pub const CG_FLAG_H_SCALARS_EXTERNAL: i32 = 32;
 pub const CG_FLAG_STAGED_LOAD: i32 = 64;
+pub const CG_FLAG_NO_LONE_SLOT: i32 = 128;
 pub const CG_ERR_POLY_DEGREE_TOO_LARGE: c_int = -5;
 pub const CG_ERR_MALFORMED_KEY: c_int = -6;
 
@@ -97,12 +98,14 @@ pub struct cg_ctx_info {
     pub shard_count: i32,
     pub latency_mode: i32,
     pub warmup: i32,
-    pub reserved: [i32; 3],
+    pub lone_slots: i32,
+    pub reserved: [i32; 2],
     pub slot_entry_bytes: u64,
     pub slot_piece_bytes: u64,
     pub slot_bucket_bytes: u64,
     pub slot_transform_bytes: u64,
     pub slot_upload_bytes: u64,
+    pub lone_slot_bytes: u64,
 }
 
 #[repr(C)]

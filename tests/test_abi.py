@@ -172,7 +172,7 @@ def test_circuit_load_validates_before_touching_the_gpu(cc):
     pk.h_len = 7
     for kw, msg in ((dict(window_bits=1), b"window_bits"), (dict(window_bits=23), b"window_bits"), (dict(window_bits=-3), b"window_bits"),
                     (dict(shard_count=4, shard_rank=4), b"shard_rank"), (dict(shard_count=2, shard_rank=-1), b"shard_rank"),
-                    (dict(proof_slots=-1), b"proof_slots"), (dict(flags=128), b"flags"), (dict(flags=1 << 20), b"flags"),
+                    (dict(proof_slots=-1), b"proof_slots"), (dict(flags=256), b"flags"), (dict(flags=1 << 20), b"flags"),
                     (dict(flags=2 | 4), b"exclusive")):
         opt = api._CgOptions(device=-1, **kw)
         rc = L.cg_circuit_load(ctypes.byref(h), ctypes.byref(pk), abc, 3, 4, 7, ctypes.byref(opt))

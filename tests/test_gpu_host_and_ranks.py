@@ -89,7 +89,7 @@ def test_ctx_info_reports_memory_windows_and_the_retune(cc, oracle, medium):
         i0 = prover.info()
         assert i0["proof_slots"] == 2 and i0["tuned"] == 0 and i0["retune_attempts"] == 0 and i0["latency_mode"] == 0
         assert i0["table_bytes"] > 0 and i0["slot_bytes"] > 0 and i0["matrix_bytes"] > 0
-        assert i0["total_bytes"] == i0["table_bytes"] + i0["matrix_bytes"] + 2 * i0["slot_bytes"]
+        assert i0["total_bytes"] == i0["table_bytes"] + i0["matrix_bytes"] + 2 * i0["slot_bytes"] + i0["lone_slot_bytes"]
         kinds = ("slot_entry_bytes", "slot_piece_bytes", "slot_bucket_bytes", "slot_transform_bytes", "slot_upload_bytes")
         assert all(i0[k] > 0 for k in kinds) and sum(i0[k] for k in kinds) == i0["slot_bytes"]
         # a throughput slot holds ONE set of entry lists for its five MSMs (sized for the largest: h, 2 x 8 B x D x windows)
@@ -112,7 +112,7 @@ def test_ctx_info_reports_memory_windows_and_the_retune(cc, oracle, medium):
         i2 = prover.info()
         assert i2["tuned"] == 1 and i2["retune_skipped_for_memory"] == 0 and i2["window_bits"]["h"] == wb["h"]
         assert i2["window_bits"]["a"] <= wb["a"]
-        assert i2["total_bytes"] == i2["table_bytes"] + i2["matrix_bytes"] + 2 * i2["slot_bytes"]
+        assert i2["total_bytes"] == i2["table_bytes"] + i2["matrix_bytes"] + 2 * i2["slot_bytes"] + i2["lone_slot_bytes"]
         assert sum(i2[k] for k in kinds) == i2["slot_bytes"]
         prover.prove(w, 1, 2)
         assert prover.info()["retune_attempts"] == i2["retune_attempts"]

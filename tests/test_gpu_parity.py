@@ -3,6 +3,7 @@
 Bit-exact comparisons throughout: this path is integer arithmetic."""
 import hashlib
 import random
+import time
 
 import numpy as np
 import pytest
@@ -986,6 +987,57 @@ def test_proofs_in_flight_are_independent(cc, oracle):
         assert got == expect
     finally:
         serial.close(); par.close()
+
+
+def test_a_proof_that_arrives_alone_takes_the_lone_slot(cc, oracle):
+    """A throughput context holds two slots more than proof_slots, arranged as a latency context's (five streams): a proof that
+    finds fewer than two others in flight runs on one (sample/client_helper/src/main.rs:177-216: one task per credential, so a server's
+    context is often between requests), proofs that find others in flight take the one-stream slots, a timed proof always
+    does.  The bytes are the oracle's on every route, before and after the one-time re-tune (which re-sizes the lone slot's
+    engines with the others); CG_FLAG_NO_LONE_SLOT leaves it out."""
+    import cpu_ref
+    from concurrent.futures import ThreadPoolExecutor
+    from crescent_credentials_amd import workloads as wl
+    l, m, M = 12, 40_000, 41_000
+    cm, w = wl.synthetic_circuit(4141, l, m, M, 0.9, 3, profile="gates")
+    rng = random.Random(41)
+    pk = cc.generate_parameters_with_qap(cm, *(rng.randrange(1, oracle.R) for _ in range(4)))
+    rs = [(rng.randrange(oracle.R), rng.randrange(oracle.R)) for _ in range(10)] + [(0, 5), (0, 0)]
+    want = [cpu_ref.prove(pk, (cm.a, cm.b, cm.c), l, m, M, w, r, s, nthreads=8) for r, s in rs]
+    with_lone = cc.Prover(pk, cm, proof_slots=3)
+    without = cc.Prover(pk, cm, proof_slots=3, lone_slot=False)
+    try:
+        i = with_lone.info()
+        assert i["lone_slots"] == 2 and i["proof_slots"] == 3 and i["latency_mode"] == 0
+        # a latency slot holds a set of entry lists per MSM where a one-stream slot holds one for all five
+        assert i["lone_slot_bytes"] > 2 * (i["slot_bytes"] - i["slot_upload_bytes"])
+        j = without.info()
+        assert j["lone_slots"] == 0 and j["lone_slot_bytes"] == 0 and j["proof_slots"] == 3
+        assert i["total_bytes"] == j["total_bytes"] + i["lone_slot_bytes"]
+        # one at a time: the first of these is the context's first proof (size-based windows), the second triggers the re-tune
+        assert [with_lone.prove(w, r, s).data for r, s in rs] == want
+        assert with_lone.info()["tuned"] == 1
+        assert [with_lone.prove(w, r, s, timings=True)[0].data for r, s in rs[:4]] == want[:4]      # timed: a one-stream slot
+        assert [without.prove(w, r, s).data for r, s in rs] == want
+        # callers arriving together: the first two find the context (nearly) empty, the others do not
+        for _ in range(3):
+            with ThreadPoolExecutor(max_workers=4) as ex:
+                assert list(ex.map(lambda x: with_lone.prove(w, x[0], x[1]).data, rs)) == want
+            assert with_lone.prove(w, *rs[0]).data == want[0]                                       # alone again
+        # the point of it: a proof alone is not slower on the lone slot than on a one-stream slot (at 2^21 it is 1.5x faster)
+        def median_ms(p):
+            ts = []
+            for k in range(12):
+                t0 = time.perf_counter()
+                p.prove(w, *rs[k % len(rs)])
+                ts.append(time.perf_counter() - t0)
+            return sorted(ts)[len(ts) // 2] * 1e3
+        median_ms(with_lone); median_ms(without)
+        a, b = median_ms(with_lone), median_ms(without)
+        print("a proof alone at D = 2^16: %.2f ms on the lone slot, %.2f ms on a one-stream slot" % (a, b))
+        assert a < 1.15 * b
+    finally:
+        with_lone.close(); without.close()
 
 
 @pytest.mark.parametrize("bit_fraction", [0.0, 0.9])
