@@ -1478,7 +1478,7 @@ static int prove_partial_common(cg_ctx* ctx, const void* full_assignment, int as
                 upload_ms = upload_assignment(ctx, up.u, full_assignment, timings != nullptr);
                 w_dev = up.u->w.p;
             }
-            SlotGuard g(ctx);
+            SlotGuard g(ctx, timings == nullptr);        // (as prove_common: a shard of a proof that arrives alone, untimed)
             const Fr* q_dev = nullptr;
             if (with_q) {
                 q_dev = (const Fr*)q_slice;
@@ -1582,7 +1582,7 @@ extern "C" int cg_prove_partial_q_begin(cg_ctx* ctx, const void* full_assignment
             (void)upload_assignment(ctx, p->up, full_assignment, false);
             p->w_dev = p->up->w.p;
         }
-        p->S = ctx->acquire();
+        p->S = ctx->acquire(true);
         p->skip_b1 = scalar_is_zero(r);
         ProofSlot* S = p->S;
         cg_ctx* c = ctx;
