@@ -911,10 +911,13 @@ def main():
                     break
                 n_ = 200
                 lat = []
-                done_ = steady_stream(pk_, n_ + k, k, lat)                  # the first k completions are the ramp
-                rate_ = n_ / (done_[-1] - done_[k - 1])
+                # n_ completions between two instants at which the pipeline is FULL: the first k completions are the ramp and
+                # the last k the drain (a window that ends with the last completion counts work done before it began: +k/2n_,
+                # 4 % at sixteen in flight)
+                done_ = steady_stream(pk_, n_ + 2 * k, k, lat)
+                rate_ = n_ / (done_[n_ + k - 1] - done_[k - 1])
                 curve.append({"in_flight": k, "proofs": n_, "proofs_per_s": round(rate_, 2),
-                              "latency_ms": percentiles_ms([d for t_, d in lat if t_ > done_[k - 1]])})
+                              "latency_ms": percentiles_ms([d for t_, d in lat if done_[k - 1] < t_ <= done_[n_ + k - 1]])})
             knee = next((c_["in_flight"] for c_ in curve if c_["proofs_per_s"] >= 0.95 * max(x["proofs_per_s"] for x in curve)), None)
             out["inflight_curve"] = {"points": curve, "callers": "k host threads on the headline context (%d slots, throughput arrangement, + the lone slot a "
                                      "proof that finds nothing in flight runs on: the k = 1 point), witness from %s memory" % (inflight, a.witness),
