@@ -953,6 +953,23 @@ def main():
                 sh["backend_fallback"] = used
                 log("sharded leg: %s -> falling back to %s" % (sh["error"], used))
             srng = random.Random(99)                     # the same (r, s) on every rank
+
+            def whose_record_differs(sp_, w_ptr, r_):
+                """after a sharded proof that differs from the unsharded context's: every rank recomputes ITS OWN 384-byte record on
+                a plain shard context (cg_prove_partial) and says which of the five points in the gathered record differ"""
+                try:
+                    chk = cc.Prover(pk_s, cm_s, device=local_rank, window_bits=a.window, shard_rank=rank, shard_count=world)
+                    want_ = chk.prove_partial(w_ptr, r_, on_device=True)
+                    chk.close()
+                    got_ = bytes(sp_.last_parts)[384 * rank:384 * (rank + 1)] if sp_.last_parts is not None else b""
+                    names_, o_, bad_ = ("h", "l", "a", "b1", "b2"), 0, []
+                    for nm_, sz_ in zip(names_, (64, 64, 64, 64, 128)):
+                        if got_[o_:o_ + sz_] != want_[o_:o_ + sz_]:
+                            bad_.append(nm_)
+                        o_ += sz_
+                    return "rank %d: %s" % (rank, ("points " + ", ".join(bad_) + " of its record differ") if bad_ else "its own record is right")
+                except Exception as e_:      # noqa: BLE001 - a diagnosis, never the failure itself
+                    return "rank %d: no diagnosis (%r)" % (rank, e_)
             # The sharded proofs are made on config 4's own circuit - mdl1, S22 (BASELINE.json configs[3]: "mdl1 ... MSM sharded
             # across 8 x MI355X") - unless the run was given a shape; `value` above stays the replica rate of the headline shape.
             # (configs[4]'s shape, rs256-db, is the headline's with l = 28 instead of 26: two more of 1.5 M wires move from the l
@@ -1044,7 +1061,7 @@ def main():
                                     "ms_breakdown_rank0": sps.breakdown_ms(), "bytes_identical_to_unsharded": bool(same_s),
                                     "what": "rank 0 runs the witness map once (four full-size transforms), scatters the coset values, "
                                             "every rank proves with its slice"}}
-                    assert same_s, "the scatter arrangement's proof differs from the unsharded one"
+                    assert same_s, "the scatter arrangement's proof differs from the unsharded one; " + whose_record_differs(sps, ws_s[0].data_ptr(), r_)
                     # the same arrangement in two calls: every rank opens the proof (its l, a, b1, b2 sums run), THEN the witness map
                     # and the scatter, then the h share - the assignment-driven MSMs leave the critical path
                     spt = ShardedProver(sc_ctx, dev, group=grp, arrangement="scatter", two_call=True)
@@ -1065,7 +1082,7 @@ def main():
                         "ms_breakdown_rank0": spt.breakdown_ms(), "bytes_identical_to_unsharded": bool(same_t),
                         "what": "cg_prove_partial_q_begin on every rank (l, a, b1, b2 partial sums queued), rank 0's witness map on its open "
                                 "proof, the scatter, cg_prove_partial_q_finish with the slice (the h share)"}
-                    assert same_t, "the two-call scatter arrangement's proof differs from the unsharded one"
+                    assert same_t, "the two-call scatter arrangement's proof differs from the unsharded one; " + whose_record_differs(spt, ws_s[0].data_ptr(), r_)
                     sc_ctx.close()
                     # ... and with the witness map in two halves: rank 0 computes the a side, rank 1 the b side at the same time, each
                     # scatters its own, every shard multiplies its two slices and adds the h share (ranks 0 and 1 hold witness-map memory)
@@ -1091,7 +1108,7 @@ def main():
                             "what": "cg_prove_partial_q_begin everywhere; rank 0 computes vinv·a on the coset, rank 1 b on the coset (one sparse "
                                     "product + two transforms each, at the same time); two scatters; cg_prove_partial_q_finish2 multiplies the "
                                     "slices and adds the h share"}
-                        assert same_h, "the two-halves scatter arrangement's proof differs from the unsharded one"
+                        assert same_h, "the two-halves scatter arrangement's proof differs from the unsharded one; " + whose_record_differs(sph, ws_s[0].data_ptr(), r_)
                         sh_ctx.close()
                     # ... and with UNEQUAL shares (cg_options.shard_span): the two ranks that compute a half carry 0.6 of an equal
                     # share of the MSMs, the other ranks the rest (tools/probe_latency.py: 1.9 against 2.2 ms by the pieces at S21 / 8)

@@ -224,32 +224,44 @@ class HScalarScatter:
         equal = all(c * 32 == self.chunk for _, c in self.slices)
         # equal slices: the scatter list is views of the one vector; otherwise padded copies
         self._pad = None if equal or not sends else [torch.zeros(max(1, self.chunk), dtype=torch.uint8, device=dev) for _ in range(world)]
+        self._failure = None
 
     def _global(self, r: int) -> int:
         return dist.get_global_rank(self.group, r) if (self.world > 1 and self.group is not None) else r
 
-    def exchange(self, assignment, on_device: bool, seconds: dict, src: int = 0, slot: int = 0, wm=None):
+    def compute(self, assignment, on_device: bool, seconds: dict, wm=None):
+        """the source's part of an exchange on its own: run the witness map into the send buffer.  A failure is kept and
+        raised by the exchange(computed=True) that follows, after its scatter."""
+        t0 = time.perf_counter()
+        self._failure = None
+        try:
+            run = wm if wm is not None else (lambda **kw: self.prover.witness_map_coset(assignment, on_device=on_device, **kw))
+            if self.on_host:
+                if self._direct_host:       # the library writes straight into the (page-locked) tensor the scatter sends from
+                    run(out_host=self._all.data_ptr())
+                else:
+                    got = np.frombuffer(bytes(run()), dtype=np.uint8)
+                    self._all.numpy()[:] = got[:self._all.numel()]    # (a stand-in may return more than its shards' slices cover)
+            else:
+                run(out_dev=self._all.data_ptr())
+        except BaseException as e:   # noqa: BLE001
+            self._failure = e
+        seconds["witness_map"] += time.perf_counter() - t0
+
+    def exchange(self, assignment, on_device: bool, seconds: dict, src: int = 0, slot: int = 0, wm=None, computed: bool = False):
         """Rank `src` (of the group) runs the witness map on `assignment` and scatters; every rank's slice lands in receive
         buffer `slot`.  -> (this rank's slice: a device address or numpy bytes, whether it is on the device).  A witness
         map that fails on the source is raised there AFTER the scatter the other ranks are already waiting in.
         wm (optional): the witness map of an OPEN two-call proof (OpenPartial.witness_map_coset) to use instead of the
-        context's own - it runs on the working set the open proof holds."""
+        context's own - it runs on the working set the open proof holds.
+        computed: the source has run compute() already (two sources working at the same time before their scatters)."""
         t0 = time.perf_counter()
         off, cnt = self.slices[self.rank]
         failure = None
         if self.rank == src:
-            try:
-                run = wm if wm is not None else (lambda **kw: self.prover.witness_map_coset(assignment, on_device=on_device, **kw))
-                if self.on_host:
-                    if self._direct_host:       # the library writes straight into the (page-locked) tensor the scatter sends from
-                        run(out_host=self._all.data_ptr())
-                    else:
-                        got = np.frombuffer(bytes(run()), dtype=np.uint8)
-                        self._all.numpy()[:] = got[:self._all.numel()]    # (a stand-in may return more than its shards' slices cover)
-                else:
-                    run(out_dev=self._all.data_ptr())
-            except BaseException as e:   # noqa: BLE001
-                failure = e
+            if not computed:
+                self.compute(assignment, on_device, {"witness_map": 0.0}, wm)
+            failure, self._failure = self._failure, None
         t1 = time.perf_counter()
         recv = self._recv[slot]
         if self.world > 1:
@@ -336,6 +348,7 @@ class ShardedProver:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.src_b = min(1, self.world - 1)      # split_map: the rank that computes the b side
+        self.last_parts = None
         self.all_gathers = 0          # all_gathers issued so far (one per proof when world > 1)
         self.scatters = 0             # scatters issued so far ("scatter" arrangement: one per proof)
         self.proofs = 0
@@ -364,10 +377,14 @@ class ShardedProver:
             opened = self.prover.prove_partial_q_begin(assignment, r, on_device=on_device)     # a failure here precedes every collective
             qa = qb = None
             q_on_device = False
+            # the two sources compute their sides FIRST - at the same time, each on its own GPU - and only then the scatters: a
+            # source that went into the other's scatter before computing would start when that one had finished
+            for side, sc, src in ((0, self._scatter, 0), (1, self._scatter_b, self.src_b)):
+                if self.rank == src:
+                    sc.compute(assignment, on_device, self.seconds, wm=lambda side=side, **kw: opened.witness_map_coset_half(side, **kw))
             for side, sc, src in ((0, self._scatter, 0), (1, self._scatter_b, self.src_b)):    # both scatters, whatever fails
                 try:
-                    got, q_on_device = sc.exchange(assignment, on_device, self.seconds, src, 0,
-                                                   wm=lambda side=side, **kw: opened.witness_map_coset_half(side, **kw))
+                    got, q_on_device = sc.exchange(assignment, on_device, self.seconds, src, 0, computed=True)
                     if side == 0:
                         qa = got
                     else:
@@ -446,6 +463,7 @@ class ShardedProver:
         self.seconds["gather"] += t2 - t1
         self.seconds["assemble"] += t3 - t2
         self.proofs += 1
+        self.last_parts = parts          # the records the latest proof was assembled from, rank order (what a checker looks at first)
         return proof
 
     def prove(self, full_assignment, r: int, s: int):
