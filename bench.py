@@ -955,19 +955,25 @@ def main():
             srng = random.Random(99)                     # the same (r, s) on every rank
 
             def whose_record_differs(sp_, w_ptr, r_):
-                """after a sharded proof that differs from the unsharded context's: every rank recomputes ITS OWN 384-byte record on
-                a plain shard context (cg_prove_partial) and says which of the five points in the gathered record differ"""
+                """after a sharded proof that differs from the unsharded context's (on every rank: they assembled the same records):
+                every rank recomputes ITS OWN 384-byte record on a plain shard context (cg_prove_partial) and says which of the
+                five points in the gathered record differ; then the same sharded proof is made AGAIN - a second wrong answer with
+                the same points means the context's tables are wrong (load time), a right one that this proof's run was"""
                 try:
                     chk = cc.Prover(pk_s, cm_s, device=local_rank, window_bits=a.window, shard_rank=rank, shard_count=world)
                     want_ = chk.prove_partial(w_ptr, r_, on_device=True)
                     chk.close()
                     got_ = bytes(sp_.last_parts)[384 * rank:384 * (rank + 1)] if sp_.last_parts is not None else b""
+                    sp_.prove_dev(w_ptr, r_, 12345)                       # collective: every rank is here
+                    again_ = bytes(sp_.last_parts)[384 * rank:384 * (rank + 1)]
                     names_, o_, bad_ = ("h", "l", "a", "b1", "b2"), 0, []
                     for nm_, sz_ in zip(names_, (64, 64, 64, 64, 128)):
                         if got_[o_:o_ + sz_] != want_[o_:o_ + sz_]:
                             bad_.append(nm_)
                         o_ += sz_
-                    return "rank %d: %s" % (rank, ("points " + ", ".join(bad_) + " of its record differ") if bad_ else "its own record is right")
+                    return "rank %d: %s; made again: %s" % (rank, ("points " + ", ".join(bad_) + " of its record differ") if bad_ else
+                                                             "its own record is right", "the same record" if again_ == got_ else
+                                                             "the right record" if again_ == want_ else "a third record")
                 except Exception as e_:      # noqa: BLE001 - a diagnosis, never the failure itself
                     return "rank %d: no diagnosis (%r)" % (rank, e_)
             # The sharded proofs are made on config 4's own circuit - mdl1, S22 (BASELINE.json configs[3]: "mdl1 ... MSM sharded
@@ -1136,7 +1142,7 @@ def main():
                             "ms_per_proof": round(dsu_ / a.sharded_steps * 1e3, 3), "collectives_per_proof": 3, "spans_per_10000": spans,
                             "ms_breakdown_rank0": spu.breakdown_ms(), "bytes_identical_to_unsharded": bool(same_u),
                             "what": "the two-halves arrangement with the two source ranks carrying 0.6 of an equal share of every query"}
-                        assert same_u, "the unequal-shares arrangement's proof differs from the unsharded one"
+                        assert same_u, "the unequal-shares arrangement's proof differs from the unsharded one (rank %d)" % rank
                         su_ctx.close()
                 except AssertionError:
                     raise

@@ -233,6 +233,12 @@ inline void h2d_sync(void* dst, const void* src, size_t bytes, hipStream_t st) {
 // zero `bytes` (a multiple of 16) of device memory with full-width stores on the whole chip
 // (hipMemsetAsync's fill kernel reaches ~0.2 TB/s on these sizes)
 void fill_zero(void* dst, size_t bytes, hipStream_t st);
+// Device -> device copy as a KERNEL on `st`.  hipMemcpyAsync(DeviceToDevice) is not used where a kernel on the same stream reads
+// the copy next: with the process's hardware queues time-sliced against other processes' (more user queues on the GPU than
+// it maps at once) such a copy was seen to land AFTER the kernels queued behind it - a window table expanded from a row 0 that
+// had not arrived yet, wrong from then on (tools/loop_gpus8.sh with tools/hold_queues.py beside it: 4 of 20 eight-process runs).
+// A kernel is ordered behind and before its neighbours on the stream like every other kernel of this library.
+void copy_on_device(void* dst, const void* src, size_t bytes, hipStream_t st);
 
 inline uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 inline int ilog2_ceil(uint64_t n) { int l = 0; while ((1ull << l) < n) ++l; return l; }

@@ -177,8 +177,8 @@ template <class F>
 void MsmBases<F>::build_from_row0(const uint32_t* row0_dev, const uint8_t* valid_dev, uint64_t n_, int c_, hipStream_t st) {
     alloc_rows(n_, c_, true);
     if (!n) return;
-    CG_HIP(hipMemcpyAsync(table.p, row0_dev, n * AFF * 4, hipMemcpyDeviceToDevice, st));
-    CG_HIP(hipMemcpyAsync(valid.p, valid_dev, n, hipMemcpyDeviceToDevice, st));
+    copy_on_device(table.p, row0_dev, n * AFF * 4, st);       // (kernels, not hipMemcpyAsync: common.hpp)
+    copy_on_device(valid.p, valid_dev, n, st);
     expand_rows(st);
 }
 
@@ -194,7 +194,7 @@ int MsmBases<F>::rebuild(int c_new, hipStream_t st) {
         if (need + (2ull << 30) > free_b) return -1;
     }
     DevBuf<uint32_t> t2((uint64_t)W_new * n * AFF);
-    CG_HIP(hipMemcpyAsync(t2.p, table.p, n * AFF * 4, hipMemcpyDeviceToDevice, st));   // row 0 = the bases themselves
+    copy_on_device(t2.p, table.p, n * AFF * 4, st);   // row 0 = the bases themselves
     for (int j = 1; j < W_new; ++j) {
         k_table_next<F29T><<<ceil_div(n, 256), 256, 0, st>>>(t2.p, valid.p, n, j, c_new);
         CG_KERNEL_CHECK();

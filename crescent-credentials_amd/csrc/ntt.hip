@@ -78,6 +78,23 @@ void fill_zero(void* dst, size_t bytes, hipStream_t st) {
     CG_KERNEL_CHECK();
 }
 
+__global__ void __launch_bounds__(256) k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t n16) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+__global__ void __launch_bounds__(256) k_copy1(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+void copy_on_device(void* dst, const void* src, size_t bytes, hipStream_t st) {
+    if (!bytes) return;
+    const bool wide = bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) % 16 == 0;
+    const uint64_t units = wide ? bytes / 16 : bytes;
+    uint32_t blocks = ceil_div(units, 256 * 8);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (wide) k_copy16<<<blocks ? blocks : 1, 256, 0, st>>>(reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), units);
+    else k_copy1<<<blocks ? blocks : 1, 256, 0, st>>>(reinterpret_cast<const uint8_t*>(src), reinterpret_cast<uint8_t*>(dst), units);
+    CG_KERNEL_CHECK();
+}
+
 void fr_pow_table(Fr* out, const Fr& base, const Fr& scale, uint64_t n, bool bitrev, int logn, hipStream_t st) {
     if (!n) return;
     k_pow_table<<<grid_for(n), 256, 0, st>>>(out, base, scale, n, bitrev ? 1 : 0, logn);

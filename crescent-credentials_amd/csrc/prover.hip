@@ -1568,7 +1568,8 @@ static int coset_values_to(cg_ctx* ctx, ProofSlot* S, const Fr* w_dev, int half,
         CG_KERNEL_CHECK();
         src = tmp;
     }
-    CG_HIP(hipMemcpyAsync(q_out, src, ctx->D * 32, q_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s0));
+    if (q_on_device) copy_on_device(q_out, src, ctx->D * 32, s0);
+    else CG_HIP(hipMemcpyAsync(q_out, src, ctx->D * 32, hipMemcpyDeviceToHost, s0));
     CG_HIP(hipStreamSynchronize(s0));
     if (S->wm.h_bad_input.p[0]) return fail(CG_ERR_INVALID_ARGUMENT, "full_assignment holds a value >= the scalar field modulus");
     return CG_OK;
