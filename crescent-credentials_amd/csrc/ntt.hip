@@ -158,6 +158,10 @@ void DevCsr::upload(const cg_csr& m, uint64_t rows_, uint64_t num_variables, hip
     static const bool plain = CG_TUNE_ENV("SELL_PLAIN") != nullptr;       // A/B aid (tuning builds): round 2's layout (terms as given, pieces by length)
     HostCsr h;
     csr_prepare_host(m, rows_, num_variables, sliced, !plain, h);
+    upload_prepared(m, h, rows_, st);
+}
+
+void DevCsr::upload_prepared(const cg_csr& m, const HostCsr& h, uint64_t rows_, hipStream_t st) {
     rows = rows_;
     nnz = m.nnz;
     row_ptr.alloc(rows + 1);
@@ -186,7 +190,7 @@ void DevCsr::upload(const cg_csr& m, uint64_t rows_, uint64_t num_variables, hip
         h2d(L.cidx.p, H.cidx.p, H.n_slots * 4);
         h2d(L.dst.p, H.dst.p, H.dst.size() * 4);
     }
-    CG_HIP(hipStreamSynchronize(st));
+    CG_HIP(stream_sync(st));
 }
 
 static constexpr uint32_t SPMV_LONG_ROW = 4096;
