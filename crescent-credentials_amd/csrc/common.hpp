@@ -1,8 +1,6 @@
 // Shared host-side plumbing for libcrescent_gpu: error reporting, HIP checks, device buffers.
 #pragma once
 #include <hip/hip_runtime.h>
-#include <chrono>
-#include <thread>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -213,34 +211,11 @@ struct PinnedBuf {
     }
 };
 
-// Waiting for a stream / an event by POLLING its state (hipStreamQuery / hipEventQuery) instead of the runtime's blocking waits.
-// With more user queues on the GPU than it maps at once (other processes beside this one: eight ranks sharing a GPU inside the
-// test suite) hipStreamSynchronize was seen to return before the stream's last kernel had finished - the same checksum kernel
-// over the same data, summed into page-locked memory and read after the synchronise, gave a different sum once in ~500 calls
-// (tools/stress_load.sh, CG_CHECK_FOLD) - and a loader that then released or read a temporary made a context with a wrong h or
-// l table (one in ~250 loads).  A query reads the completion signal itself.  Spins first (a load step is short), then naps.
-inline hipError_t stream_sync(hipStream_t st) {
-    for (unsigned spins = 0;; ++spins) {
-        const hipError_t e = hipStreamQuery(st);
-        if (e != hipErrorNotReady) return e;
-        if (spins < 2000) std::this_thread::yield();
-        else std::this_thread::sleep_for(std::chrono::microseconds(spins < 20000 ? 20 : 200));
-    }
-}
-inline hipError_t event_sync(hipEvent_t ev) {
-    for (unsigned spins = 0;; ++spins) {
-        const hipError_t e = hipEventQuery(ev);
-        if (e != hipErrorNotReady) return e;
-        if (spins < 20000) std::this_thread::yield();
-        else std::this_thread::sleep_for(std::chrono::microseconds(20));
-    }
-}
-
 // A stream that lives for one scope (loaders): destroyed on every way out, an exception included.
 struct ScopedStream {
     hipStream_t st = nullptr;
     ScopedStream() { CG_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); }
-    ~ScopedStream() { if (st) { (void)stream_sync(st); (void)hipStreamDestroy(st); } }
+    ~ScopedStream() { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } }
     ScopedStream(const ScopedStream&) = delete;
     ScopedStream& operator=(const ScopedStream&) = delete;
     operator hipStream_t() const { return st; }
@@ -252,18 +227,12 @@ struct ScopedStream {
 inline void h2d_sync(void* dst, const void* src, size_t bytes, hipStream_t st) {
     if (!bytes) return;
     CG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
-    CG_HIP(stream_sync(st));
+    CG_HIP(hipStreamSynchronize(st));
 }
 
 // zero `bytes` (a multiple of 16) of device memory with full-width stores on the whole chip
 // (hipMemsetAsync's fill kernel reaches ~0.2 TB/s on these sizes)
 void fill_zero(void* dst, size_t bytes, hipStream_t st);
-// Device -> device copy as a KERNEL on `st`.  hipMemcpyAsync(DeviceToDevice) is not used where a kernel on the same stream reads
-// the copy next: with the process's hardware queues time-sliced against other processes' (more user queues on the GPU than
-// it maps at once) such a copy was seen to land AFTER the kernels queued behind it - a window table expanded from a row 0 that
-// had not arrived yet, wrong from then on (tools/loop_gpus8.sh with tools/hold_queues.py beside it: 4 of 20 eight-process runs).
-// A kernel is ordered behind and before its neighbours on the stream like every other kernel of this library.
-void copy_on_device(void* dst, const void* src, size_t bytes, hipStream_t st);
 
 inline uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 inline int ilog2_ceil(uint64_t n) { int l = 0; while ((1ull << l) < n) ++l; return l; }

@@ -126,7 +126,7 @@ void ec_inverse_dft(const uint32_t* row0_in, const uint8_t* valid_in, uint64_t n
     }
     k_ec_store<<<ceil_div(n, 256), 256, 0, st>>>(slots.p, n, row0_out, valid_out);
     CG_KERNEL_CHECK();
-    CG_HIP(stream_sync(st));     // the temporaries are released on return
+    CG_HIP(hipStreamSynchronize(st));     // the temporaries are released on return
 }
 
 void ec_transform_h_bases(const uint32_t* row0_in, const uint8_t* valid_in, uint64_t n_in, int logn, uint32_t* row0_out,
@@ -225,11 +225,11 @@ void ec_fold_ct_into_l(const uint32_t* h_row0, const uint8_t* h_valid, uint64_t 
         k_ec_terms<<<ceil_div(nnz, 256), 256, 0, st>>>(ct.col.p, ct.coef_idx.p, ct.dict.p, nnz, g_row0.p, g_valid.p, pts.p);
         CG_KERNEL_CHECK();
         sum_xyzz_by_key(keys.p, pts.p, nnz, p_sums.p, st);
-        CG_HIP(stream_sync(st));    // keys_h, ct and the device temporaries above outlive the kernels
+        CG_HIP(hipStreamSynchronize(st));    // keys_h, ct and the device temporaries above outlive the kernels
     }
     k_ec_fold_l<<<ceil_div(M, 256), 256, 0, st>>>(p_sums.p, l_row0, l_valid, num_inputs, M, row0_out, valid_out);
     CG_KERNEL_CHECK();
-    CG_HIP(stream_sync(st));
+    CG_HIP(hipStreamSynchronize(st));
 }
 
 }  // namespace cg

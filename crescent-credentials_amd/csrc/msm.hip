@@ -93,7 +93,7 @@ void import_bases(const uint8_t* host_bytes, uint32_t coord_form, uint64_t n, Af
     CG_HIP(hipMemcpyAsync(raw.p, host_bytes, n * NC * 32, hipMemcpyHostToDevice, st));
     k_import<F><<<ceil_div(n, 256), 256, 0, st>>>(raw.p, out_dev, n, coord_form == CG_FORM_CANONICAL ? 1 : 0);
     CG_KERNEL_CHECK();
-    CG_HIP(stream_sync(st));  // raw is freed on return
+    CG_HIP(hipStreamSynchronize(st));  // raw is freed on return
 }
 template void import_bases<Fq>(const uint8_t*, uint32_t, uint64_t, Affine<Fq>*, hipStream_t);
 template void import_bases<Fq2>(const uint8_t*, uint32_t, uint64_t, Affine<Fq2>*, hipStream_t);
@@ -177,8 +177,8 @@ template <class F>
 void MsmBases<F>::build_from_row0(const uint32_t* row0_dev, const uint8_t* valid_dev, uint64_t n_, int c_, hipStream_t st) {
     alloc_rows(n_, c_, true);
     if (!n) return;
-    copy_on_device(table.p, row0_dev, n * AFF * 4, st);       // (kernels, not hipMemcpyAsync: common.hpp)
-    copy_on_device(valid.p, valid_dev, n, st);
+    CG_HIP(hipMemcpyAsync(table.p, row0_dev, n * AFF * 4, hipMemcpyDeviceToDevice, st));
+    CG_HIP(hipMemcpyAsync(valid.p, valid_dev, n, hipMemcpyDeviceToDevice, st));
     expand_rows(st);
 }
 
@@ -194,12 +194,12 @@ int MsmBases<F>::rebuild(int c_new, hipStream_t st) {
         if (need + (2ull << 30) > free_b) return -1;
     }
     DevBuf<uint32_t> t2((uint64_t)W_new * n * AFF);
-    copy_on_device(t2.p, table.p, n * AFF * 4, st);   // row 0 = the bases themselves
+    CG_HIP(hipMemcpyAsync(t2.p, table.p, n * AFF * 4, hipMemcpyDeviceToDevice, st));   // row 0 = the bases themselves
     for (int j = 1; j < W_new; ++j) {
         k_table_next<F29T><<<ceil_div(n, 256), 256, 0, st>>>(t2.p, valid.p, n, j, c_new);
         CG_KERNEL_CHECK();
     }
-    CG_HIP(stream_sync(st));
+    CG_HIP(hipStreamSynchronize(st));
     table = std::move(t2);
     c = c_new;
     W = W_new;
@@ -1578,7 +1578,7 @@ void MsmEngine<F>::init(const MsmBases<F>* b, hipStream_t zero_stream) {
         CG_HIP(hipStreamCreateWithFlags(&zs, hipStreamNonBlocking));
         hipError_t e1 = hipMemsetAsync(counters.p, 0, counters.bytes(), zs);
         hipError_t e2 = hipMemsetAsync(bucket_sums.p, 0, bucket_sums.bytes(), zs);
-        hipError_t e3 = stream_sync(zs);
+        hipError_t e3 = hipStreamSynchronize(zs);
         (void)hipStreamDestroy(zs);
         CG_HIP(e1); CG_HIP(e2); CG_HIP(e3);
     }
@@ -1912,7 +1912,7 @@ void sum_xyzz_by_key(const uint32_t* keys, const uint32_t* pts, uint64_t count, 
         ip = op;
         to_a = !to_a;
     }
-    CG_HIP(stream_sync(st));
+    CG_HIP(hipStreamSynchronize(st));
 }
 
 // packed table points and validity flags first, first + stride, first + 2·stride, ... -> contiguous
@@ -1953,9 +1953,9 @@ void build_h_bases_folded(MsmBases<Fq>& out_h, const uint32_t* h_row0, const uin
         if (h_count) k_gather_points<<<ceil_div(h_count, 256), 256, 0, st>>>(row0t.p, validt.p, h_first, h_stride, h_count, row0s.p, valids.p);
         CG_KERNEL_CHECK();
         out_h.build_from_row0(row0s.p, valids.p, h_count, c_h, st);
-        CG_HIP(stream_sync(st));   // the gathered copies are released at the end of this scope
+        CG_HIP(hipStreamSynchronize(st));   // the gathered copies are released at the end of this scope
     }
-    CG_HIP(stream_sync(st));
+    CG_HIP(hipStreamSynchronize(st));
     if (ms_tables) *ms_tables += ms_since(t0);
 }
 
@@ -1974,27 +1974,9 @@ void build_l_bases_folded(MsmBases<Fq>& out_l, const uint32_t* h_row0, const uin
     if (ms_fold) *ms_fold += ms_since(t0);
     t0 = std::chrono::steady_clock::now();
     out_l.build_from_row0(row0f.p + l_first * AFF, validf.p + l_first, l_count, pick_c_l(), st);
-    CG_HIP(stream_sync(st));
+    CG_HIP(hipStreamSynchronize(st));
     if (ms_tables) *ms_tables += ms_since(t0);
 }
-
-#ifdef CG_TUNING
-// tuning builds, CG_CHECK_FOLD=1: order-independent 64-bit sums of the fold's inputs, intermediates and outputs, one line per load
-// on stderr - the same for every load of the same key and shard, so a load that went wrong says WHERE (tools/stress_load.sh)
-__global__ void __launch_bounds__(256) k_checksum(const uint32_t* __restrict__ p, uint64_t nwords, unsigned long long* __restrict__ out) {
-    unsigned long long acc = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (uint64_t)gridDim.x * blockDim.x)
-        acc += (unsigned long long)p[i] * (unsigned long long)((i * 2654435761ull) | 1ull);
-    atomicAdd(out, acc);
-}
-static unsigned long long checksum_dev(const void* p, uint64_t bytes, hipStream_t st) {
-    PinnedBuf<unsigned long long> r(1);
-    r.p[0] = 0;
-    if (bytes >= 4) k_checksum<<<1024, 256, 0, st>>>(reinterpret_cast<const uint32_t*>(p), bytes / 4, r.dev());
-    CG_HIP(stream_sync(st));
-    return r.p[0];
-}
-#endif
 
 // both, from the key's affine points (the synchronous load)
 void build_hl_bases_folded(MsmBases<Fq>& out_h, MsmBases<Fq>& out_l, const Affine<Fq>* h_bases_dev, uint64_t n_h, int logn,
@@ -2011,36 +1993,9 @@ void build_hl_bases_folded(MsmBases<Fq>& out_h, MsmBases<Fq>& out_l, const Affin
     HostCsc t;
     if (c_matrix.nnz && num_constraints) csr_transpose(c_matrix, num_constraints, M, t);
     else { t.ptr.assign(M + 1, 0); t.view = cg_csr{t.ptr.data(), nullptr, nullptr, 0}; }
-#ifdef CG_TUNING
-    const bool check = CG_TUNE_ENV("CHECK_FOLD") != nullptr;
-    unsigned long long cs[10] = {0};
-    if (check) {
-        cs[0] = checksum_dev(h_bases_dev, n_h * sizeof(Affine<Fq>), st);
-        cs[1] = checksum_dev(l_bases_dev, n_l * sizeof(Affine<Fq>), st);
-        cs[2] = checksum_dev(h_row0.p, n_h * AFF * 4, st);
-        cs[3] = checksum_dev(l_row0.p, n_l * AFF * 4, st);
-    }
-#endif
     build_h_bases_folded(out_h, h_row0.p, h_valid.p, n_h, logn, h_first, h_stride, h_count, c_h, st, ms_fold, ms_tables);
-#ifdef CG_TUNING
-    if (check) {
-        cs[4] = checksum_dev(h_row0.p, n_h * AFF * 4, st);
-        cs[5] = checksum_dev(out_h.table.p, out_h.n * AFF * 4, st);                     // row 0 of the h table: DFT + gather
-        cs[6] = checksum_dev(out_h.table.p, out_h.table.bytes(), st);                   // every row
-    }
-#endif
     build_l_bases_folded(out_l, h_row0.p, h_valid.p, n_h, logn, l_row0.p, l_valid.p, num_inputs, M, t, num_constraints, vanishing_inv,
                          l_first, l_count, [c_l] { return c_l; }, st, ms_fold, ms_tables);
-#ifdef CG_TUNING
-    if (check) {
-        cs[7] = checksum_dev(h_row0.p, n_h * AFF * 4, st);
-        cs[8] = checksum_dev(out_l.table.p, out_l.n * AFF * 4, st);
-        cs[9] = checksum_dev(out_l.table.p, out_l.table.bytes(), st);
-        fprintf(stderr, "CGFOLD th %016llx tl %016llx h_row0 %016llx l_row0 %016llx h_row0_after_h %016llx h_tab0 %016llx h_tab %016llx "
-                        "h_row0_after_l %016llx l_tab0 %016llx l_tab %016llx h_tab_again %016llx\n", cs[0], cs[1], cs[2], cs[3], cs[4], cs[5], cs[6],
-                cs[7], cs[8], cs[9], checksum_dev(out_h.table.p, out_h.table.bytes(), st));
-    }
-#endif
 }
 
 template struct MsmBases<Fq>;

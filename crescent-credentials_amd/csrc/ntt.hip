@@ -78,23 +78,6 @@ void fill_zero(void* dst, size_t bytes, hipStream_t st) {
     CG_KERNEL_CHECK();
 }
 
-__global__ void __launch_bounds__(256) k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t n16) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[i];
-}
-__global__ void __launch_bounds__(256) k_copy1(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint64_t n) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[i];
-}
-void copy_on_device(void* dst, const void* src, size_t bytes, hipStream_t st) {
-    if (!bytes) return;
-    const bool wide = bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) % 16 == 0;
-    const uint64_t units = wide ? bytes / 16 : bytes;
-    uint32_t blocks = ceil_div(units, 256 * 8);
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    if (wide) k_copy16<<<blocks ? blocks : 1, 256, 0, st>>>(reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), units);
-    else k_copy1<<<blocks ? blocks : 1, 256, 0, st>>>(reinterpret_cast<const uint8_t*>(src), reinterpret_cast<uint8_t*>(dst), units);
-    CG_KERNEL_CHECK();
-}
-
 void fr_pow_table(Fr* out, const Fr& base, const Fr& scale, uint64_t n, bool bitrev, int logn, hipStream_t st) {
     if (!n) return;
     k_pow_table<<<grid_for(n), 256, 0, st>>>(out, base, scale, n, bitrev ? 1 : 0, logn);
@@ -158,10 +141,6 @@ void DevCsr::upload(const cg_csr& m, uint64_t rows_, uint64_t num_variables, hip
     static const bool plain = CG_TUNE_ENV("SELL_PLAIN") != nullptr;       // A/B aid (tuning builds): round 2's layout (terms as given, pieces by length)
     HostCsr h;
     csr_prepare_host(m, rows_, num_variables, sliced, !plain, h);
-    upload_prepared(m, h, rows_, st);
-}
-
-void DevCsr::upload_prepared(const cg_csr& m, const HostCsr& h, uint64_t rows_, hipStream_t st) {
     rows = rows_;
     nnz = m.nnz;
     row_ptr.alloc(rows + 1);
@@ -190,7 +169,7 @@ void DevCsr::upload_prepared(const cg_csr& m, const HostCsr& h, uint64_t rows_, 
         h2d(L.cidx.p, H.cidx.p, H.n_slots * 4);
         h2d(L.dst.p, H.dst.p, H.dst.size() * 4);
     }
-    CG_HIP(stream_sync(st));
+    CG_HIP(hipStreamSynchronize(st));
 }
 
 static constexpr uint32_t SPMV_LONG_ROW = 4096;

@@ -51,9 +51,6 @@ struct DevCsr {
     // sliced = false: skip the sliced layout (the generator's transposed matrices only run the saturated product)
     // st: the loader's stream (the host arrays are copied on it and waited for)
     void upload(const cg_csr& m, uint64_t rows, uint64_t num_variables, hipStream_t st, bool sliced = true);
-    // the device half of upload() for a matrix whose host half (csr_prepare_host) was run elsewhere - a loader's host thread
-    // prepares, the ONE thread that talks to the GPU during a load copies
-    void upload_prepared(const cg_csr& m, const HostCsr& h, uint64_t rows, hipStream_t st);
 };
 // host-side transpose of a CSR view (rows x cols): CSR of the transpose, terms of one column kept in row order
 struct HostCsc {

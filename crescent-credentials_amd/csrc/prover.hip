@@ -384,7 +384,7 @@ struct UploadGuard {
     void take(cg_ctx* ctx) { c = ctx; u = ctx->acquire_upload(); }
     ~UploadGuard() {
         if (!u) return;
-        (void)stream_sync(u->st);      // a failed call may leave its copy in flight
+        (void)hipStreamSynchronize(u->st);      // a failed call may leave its copy in flight
         c->release_upload(u);
     }
 };
@@ -397,7 +397,7 @@ struct SlotGuard {
         // a failure part-way through a proof may leave kernels queued on the slot's streams: drain them before the
         // working set is handed to the next proof
         if (std::uncaught_exceptions() > exceptions)
-            for (auto st : s->st) if (st) (void)stream_sync(st);
+            for (auto st : s->st) if (st) (void)hipStreamSynchronize(st);
         c->release(s);
     }
 };
@@ -476,7 +476,7 @@ static void load_query(MsmBases<F>& bases, const uint8_t* bytes, uint32_t form, 
     t0 = std::chrono::steady_clock::now();
     int c = window_bits > 0 ? window_bits : msm_default_window(count ? count : 1, precompute);
     bases.build(tmp.p, count, c, precompute, st);
-    CG_HIP(stream_sync(st));
+    CG_HIP(hipStreamSynchronize(st));
     if (ms_tables) *ms_tables += ms_since(t0);
 }
 
@@ -651,13 +651,13 @@ static void staged_worker(cg_ctx* c) {
             stop();
             const auto tt = std::chrono::steady_clock::now();
             ba.build_from_row0(c->ba.table.p, c->ba.valid.p, c->ba.n, window_for(c->ba.n, 1), st);
-            CG_HIP(stream_sync(st));
+            CG_HIP(hipStreamSynchronize(st));
             stop();
             bb1.build_from_row0(c->bb1.table.p, c->bb1.valid.p, c->bb1.n, window_for(c->bb1.n, 2), st);
-            CG_HIP(stream_sync(st));
+            CG_HIP(hipStreamSynchronize(st));
             stop();
             bb2.build_from_row0(c->bb2.table.p, c->bb2.valid.p, c->bb2.n, window_for(c->bb2.n, 3), st);
-            CG_HIP(stream_sync(st));
+            CG_HIP(hipStreamSynchronize(st));
             ms_tables += ms_since(tt);
             from_proof = wb == 0 && ts.valid && all_from_proof;
         }
@@ -671,7 +671,7 @@ static void staged_worker(cg_ctx* c) {
                 stop();
             }
             add_lone_slot(c, slots, &bh, &bl, &ba, &bb1, &bb2, zs);
-            CG_HIP(stream_sync(zs));
+            CG_HIP(hipStreamSynchronize(zs));
             ms_slots = ms_since(tt);
         }
         {
@@ -801,22 +801,17 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         struct MatJob { std::exception_ptr err; int64_t bytes = 0; float ms = 0.f; } mj[4];
         DevCsr* mats[3] = {&c->A, &c->B, &c->C};
         cg_ctx* cp = c.get();
-        // ONE thread talks to the GPU during a load - this one.  The matrix thread does host work only and its results are copied
-        // from here after the key (until round 6 it copied them itself, on a stream of its own, next to this thread's copies of the
-        // key: with the process's hardware queues time-sliced against other processes' - eight ranks on one GPU inside the full
-        // test suite - a context whose matrix thread was quick, CG_FLAG_H_SCALARS_EXTERNAL, came out with a wrong h or l table
-        // once in ~250 loads, tools/stress_load.sh; two threads' pageable copies in flight at once is the one thing such a load
-        // did that no other did).
-        HostCsr host_mats[3];
         {
             JoinAll jobs;
             jobs.th.emplace_back([&] {
                 try {
                     const auto t = std::chrono::steady_clock::now();
-                    static const bool plain = CG_TUNE_ENV("SELL_PLAIN") != nullptr;       // A/B aid (tuning builds), as DevCsr::upload
+                    CG_HIP(hipSetDevice(dev));
+                    AllocScope booking(&mj[0].bytes);
+                    ScopedStream st;
                     // validates the CSR views (monotone row_ptr, column range, canonical coefficients); a context that
                     // never runs the witness map skips the sliced layout
-                    for (int k = 0; k < 3; ++k) csr_prepare_host(abc[k], m, M, !cp->external_q, !plain, host_mats[k]);
+                    for (int k = 0; k < 3; ++k) mats[k]->upload(abc[k], m, M, st, !cp->external_q);
                     mj[0].ms = ms_since(t);
                 } catch (...) {
                     mj[0].err = std::current_exception();
@@ -860,7 +855,7 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
                 const auto t = std::chrono::steady_clock::now();
                 AllocScope booking(&c->matrix_bytes);
                 c->dom.build(logD, true, s0);
-                CG_HIP(stream_sync(s0));
+                CG_HIP(hipStreamSynchronize(s0));
                 c->lt.domain_ms = ms_since(t);
             }
             AllocScope booking(&c->table_bytes);
@@ -900,21 +895,16 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
                     std::vector<uint8_t> v1(nb), v2(nb);
                     CG_HIP(hipMemcpyAsync(v1.data(), c->bb1.valid.p, nb, hipMemcpyDeviceToHost, s0));
                     CG_HIP(hipMemcpyAsync(v2.data(), c->bb2.valid.p, nb, hipMemcpyDeviceToHost, s0));
-                    CG_HIP(stream_sync(s0));
+                    CG_HIP(hipStreamSynchronize(s0));
                     c->b_same_identities = v1 == v2;
                 }
             }
         }   // the matrix threads are joined here
         for (const MatJob& j : mj)
             if (j.err) std::rethrow_exception(j.err);
-        {
-            const auto t = std::chrono::steady_clock::now();
-            AllocScope booking(&c->matrix_bytes);
-            for (int k = 0; k < 3; ++k) {
-                mats[k]->upload_prepared(abc[k], host_mats[k], m, s0);
-                host_mats[k] = HostCsr();
-            }
-            c->lt.matrices_ms = mj[0].ms + ms_since(t);
+        for (int k = 0; k < 3; ++k) {
+            c->matrix_bytes += mj[k].bytes;
+            c->lt.matrices_ms = std::max(c->lt.matrices_ms, mj[k].ms);
         }
         {
             AllocScope booking(&c->matrix_bytes);
@@ -923,7 +913,7 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
                 if (c->h_strided) c->wstr.build(c->dom, ilog2_ceil((uint64_t)c->shard_count), c->shard_rank, s0);
                 c->dA.build(c->A, s0); c->dB.build(c->B, s0); c->dC.build(c->C, s0);
             }
-            CG_HIP(stream_sync(s0));
+            CG_HIP(hipStreamSynchronize(s0));
             if (c->external_q) {      // the matrices were uploaded for their validation and for the load-time fold only
                 c->A = DevCsr(); c->B = DevCsr(); c->C = DevCsr();
             }
@@ -947,7 +937,7 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         if (staged) c->folded = false;                    // the arrangement in force until the swap
         SlotRecipe slot_recipe;
         for (int k = 0; k < n_now; ++k) c->slots.push_back(make_slot(c.get(), &c->bh, &c->bl, &c->ba, &c->bb1, &c->bb2, s0, slot_recipe));
-        CG_HIP(stream_sync(s0));
+        CG_HIP(hipStreamSynchronize(s0));
         // Four shared copy-only streams when the runtime's hardware queues hold them beside the proof streams one each
         // (GPU_MAX_HW_QUEUES is the HIP runtime's own variable; cg_init asks for 20); with fewer queues four shared streams
         // would only concentrate the blocking (measured -5 % on 16 queues), so every buffer keeps a stream of its own there.
@@ -975,7 +965,7 @@ extern "C" int cg_circuit_load(cg_ctx** out, const cg_proving_key* pk, const cg_
         if (const char* e = CG_TUNE_ENV("LONE_SLOTS")) if (c->n_lone) c->n_lone = atoi(e);      // tuning builds (A/B aid)
         if (!staged) {                                    // (a staged load's warm-up slots are few and short-lived: the worker adds it)
             add_lone_slot(c.get(), c->slots, &c->bh, &c->bl, &c->ba, &c->bb1, &c->bb2, s0);
-            CG_HIP(stream_sync(s0));
+            CG_HIP(hipStreamSynchronize(s0));
         }
         c->lt.slots_ms = ms_since(t_slots);
         account_slot(c.get());
@@ -1122,7 +1112,7 @@ static void wait_for_slot(ProofSlot* S) {
     for (int i = 0; i < 5; ++i)
         if (i == 0 || S->st[i] != S->st[0]) CG_HIP(hipEventRecord(S->ev_fin[i], S->st[i]));
     for (int i = 0; i < 5; ++i)
-        if (i == 0 || S->st[i] != S->st[0]) CG_HIP(event_sync(S->ev_fin[i]));
+        if (i == 0 || S->st[i] != S->st[0]) CG_HIP(hipEventSynchronize(S->ev_fin[i]));
 }
 
 // Host -> device copy of one assignment into `u`, on u's copy-only stream; THIS THREAD waits for it.  Every kernel of
@@ -1137,7 +1127,7 @@ static float upload_assignment(cg_ctx* c, Upload* u, const void* host_assignment
     CG_HIP(hipMemcpyAsync(u->w.p, host_assignment, c->M * 32, hipMemcpyHostToDevice, u->st));
     if (timed) CG_HIP(hipEventRecord(u->ev[1], u->st));
     if (spin_wait(c) || c->latency) {
-        CG_HIP(stream_sync(u->st));
+        CG_HIP(hipStreamSynchronize(u->st));
     } else {
         CG_HIP(hipEventRecord(u->ev_done, u->st));
         wait_sleeping(u->ev_done, 50);             // a 48 MB copy takes ~1 ms
@@ -1551,12 +1541,12 @@ struct cg_partial {
     // everything the open proof holds is given back exactly once, whichever call ends it
     void close() {
         if (S) {
-            for (auto st : S->st) if (st) (void)stream_sync(st);
+            for (auto st : S->st) if (st) (void)hipStreamSynchronize(st);
             c->release(S);
             S = nullptr;
         }
         if (up) {
-            (void)stream_sync(up->st);
+            (void)hipStreamSynchronize(up->st);
             c->release_upload(up);
             up = nullptr;
         }
@@ -1578,9 +1568,8 @@ static int coset_values_to(cg_ctx* ctx, ProofSlot* S, const Fr* w_dev, int half,
         CG_KERNEL_CHECK();
         src = tmp;
     }
-    if (q_on_device) copy_on_device(q_out, src, ctx->D * 32, s0);
-    else CG_HIP(hipMemcpyAsync(q_out, src, ctx->D * 32, hipMemcpyDeviceToHost, s0));
-    CG_HIP(stream_sync(s0));
+    CG_HIP(hipMemcpyAsync(q_out, src, ctx->D * 32, q_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s0));
+    CG_HIP(hipStreamSynchronize(s0));
     if (S->wm.h_bad_input.p[0]) return fail(CG_ERR_INVALID_ARGUMENT, "full_assignment holds a value >= the scalar field modulus");
     return CG_OK;
 }
@@ -1847,7 +1836,7 @@ extern "C" int cg_witness_map(cg_ctx* ctx, const uint8_t* full_assignment, uint8
         hipStream_t s0 = S->st[0];
         run_witness_map(ctx, S, up.u->w.p, s0, false);   // the reference's result: coefficients
         CG_HIP(hipMemcpyAsync(h_out, S->h_canon.p, ctx->D * 32, hipMemcpyDeviceToHost, s0));
-        CG_HIP(stream_sync(s0));
+        CG_HIP(hipStreamSynchronize(s0));
         if (S->wm.h_bad_input.p[0]) return fail(CG_ERR_INVALID_ARGUMENT, "full_assignment holds a value >= the scalar field modulus");
         return CG_OK;
     } catch (...) {

@@ -126,7 +126,7 @@ static void fixed_base_to_host(const Affine<F>* table, const Fr* scalars_dev, ui
     k_fixed_base<F><<<ceil_div(n, 256), 256, 0, st>>>(table, scalars_dev, n, out.p);
     CG_KERNEL_CHECK();
     CG_HIP(hipMemcpyAsync(host_out, out.p, n * sizeof(Affine<F>), hipMemcpyDeviceToHost, st));
-    CG_HIP(stream_sync(st));
+    CG_HIP(hipStreamSynchronize(st));
 }
 
 static Fr fr_import_canonical(const uint8_t* b, const char* what) {
@@ -172,7 +172,7 @@ extern "C" int cg_setup(const cg_csr abc[3], uint64_t num_inputs, uint64_t num_c
                 DevCsr d;
                 d.upload(t.view, M, m, st, false);
                 spmv(d, u.p, q[k], st);
-                CG_HIP(stream_sync(st));
+                CG_HIP(hipStreamSynchronize(st));
             }
         }
         k_add_inputs<<<ceil_div(l, 256), 256, 0, st>>>(qa.p, u.p, m, l);

@@ -31,7 +31,7 @@ struct cg_msm_ctx {
     PinnedBuf<uint32_t> h_bad;
     hipStream_t st = nullptr;
     std::mutex mu;
-    ~cg_msm_ctx() { if (st) { (void)stream_sync(st); (void)hipStreamDestroy(st); } }   // a failed load may leave work queued
+    ~cg_msm_ctx() { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } }   // a failed load may leave work queued
 };
 
 __global__ void __launch_bounds__(256) k_check_canonical(const Fr* __restrict__ s, uint64_t n, uint32_t* __restrict__ bad) {
@@ -69,14 +69,14 @@ static int msm_load(cg_msm_ctx** out, int group, const uint8_t* bases, uint32_t 
                 DevBuf<G1Affine> tmp(n);
                 import_bases<Fq>(bases, form, n, tmp.p, c->st);
                 c->b1.build(tmp.p, n, cbits, true, c->st);
-                CG_HIP(stream_sync(c->st));
+                CG_HIP(hipStreamSynchronize(c->st));
                 c->e1.latency_mode = true;      // one MSM at a time (calls on a handle serialise): short segments, tree reduction
                 c->e1.init(&c->b1);
             } else {
                 DevBuf<G2Affine> tmp(n);
                 import_bases<Fq2>(bases, form, n, tmp.p, c->st);
                 c->b2.build(tmp.p, n, cbits, true, c->st);
-                CG_HIP(stream_sync(c->st));
+                CG_HIP(hipStreamSynchronize(c->st));
                 c->e2.latency_mode = true;
                 c->e2.init(&c->b2);
             }
@@ -141,14 +141,14 @@ extern "C" int cg_msm_run(cg_msm_ctx* ctx, const void* scalars, int scalars_on_d
         if (ctx->group == 1) {
             ctx->e1.digits(sc, n, st);
             ctx->e1.accumulate(st);
-            CG_HIP(stream_sync(st));
+            CG_HIP(hipStreamSynchronize(st));
             if (ctx->h_bad.p[0]) return fail(CG_ERR_INVALID_ARGUMENT, "a scalar is not canonical (>= the scalar field modulus)");
             g1_export_canonical(to_affine(ctx->e1.value()), out);
             if (timings) fill_msm_timings(ctx->e1, false, timings);
         } else {
             ctx->e2.digits(sc, n, st);
             ctx->e2.accumulate(st);
-            CG_HIP(stream_sync(st));
+            CG_HIP(hipStreamSynchronize(st));
             if (ctx->h_bad.p[0]) return fail(CG_ERR_INVALID_ARGUMENT, "a scalar is not canonical (>= the scalar field modulus)");
             g2_export_canonical(to_affine(ctx->e2.value()), out);
             if (timings) fill_msm_timings(ctx->e2, true, timings);
@@ -186,7 +186,7 @@ static int msm_unit(const uint8_t* bases, uint32_t form, uint64_t n_bases, const
         eng.init(&mb);
         eng.digits(sc.p, n, st);
         eng.accumulate(st);
-        CG_HIP(stream_sync(st));
+        CG_HIP(hipStreamSynchronize(st));
         out = to_affine(eng.value());
     }
     return CG_OK;
@@ -235,7 +235,7 @@ struct cg_qap_ctx {
     DevBuf<Fr> w_canon, h_canon;
     hipStream_t st = nullptr;
     std::mutex mu;
-    ~cg_qap_ctx() { if (st) { (void)stream_sync(st); (void)hipStreamDestroy(st); } }
+    ~cg_qap_ctx() { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } }
 };
 
 namespace cg {
@@ -271,10 +271,10 @@ extern "C" int cg_qap_load(cg_qap_ctx** out, const cg_csr abc[3], uint64_t num_i
         c->B.upload(abc[1], c->m, c->M, c->st);
         c->C.upload(abc[2], c->m, c->M, c->st);
         c->dom.build(logD, true, c->st);
-        CG_HIP(stream_sync(c->st));
+        CG_HIP(hipStreamSynchronize(c->st));
         c->wdom.build(c->dom, c->st);
         c->dA.build(c->A, c->st); c->dB.build(c->B, c->st); c->dC.build(c->C, c->st);
-        CG_HIP(stream_sync(c->st));
+        CG_HIP(hipStreamSynchronize(c->st));
         c->dom.tw_fwd.release(); c->dom.tw_inv.release(); c->dom.coset_br.release(); c->dom.icoset_br.release();
         c->A.dict.release(); c->B.dict.release(); c->C.dict.release();
         c->wm.alloc(c->M, c->D, std::max(c->A.sell_scratch, std::max(c->B.sell_scratch, c->C.sell_scratch)));
@@ -304,7 +304,7 @@ extern "C" int cg_qap_witness_map(cg_qap_ctx* ctx, const void* full_assignment, 
         wm29_run(ctx->wdom, ctx->A, ctx->B, ctx->C, ctx->dA, ctx->dB, ctx->dC, ctx->wm, w, ctx->M, ctx->m, ctx->l, h, ctx->st,
                  false);
         if (!h_on_device) CG_HIP(hipMemcpyAsync(h_out, ctx->h_canon.p, ctx->D * 32, hipMemcpyDeviceToHost, ctx->st));
-        CG_HIP(stream_sync(ctx->st));
+        CG_HIP(hipStreamSynchronize(ctx->st));
         if (ctx->wm.h_bad_input.p[0]) return fail(CG_ERR_INVALID_ARGUMENT, "full_assignment holds a value >= the scalar field modulus");
         return CG_OK;
     } catch (...) {
@@ -375,7 +375,7 @@ extern "C" int cg_ntt_run(cg_ntt_ctx* ctx, void* data, int data_on_device, int i
                 std::lock_guard<std::mutex> lk(ctx->mu);
                 CG_HIP(hipSetDevice(ctx->device));
                 CG_HIP(hipMemcpyAsync(x, data, 32, hipMemcpyDeviceToHost, ctx->st));
-                CG_HIP(stream_sync(ctx->st));
+                CG_HIP(hipStreamSynchronize(ctx->st));
             } catch (...) { return translate_current_exception(); }
         } else {
             memcpy(x, data, 32);
@@ -397,11 +397,11 @@ extern "C" int cg_ntt_run(cg_ntt_ctx* ctx, void* data, int data_on_device, int i
         const bool ok = ctx->unit.run(d, inverse != 0, coset != 0, st);
         CG_HIP(hipEventRecord(ctx->ev[1], st));
         if (!ok) {
-            CG_HIP(stream_sync(st));
+            CG_HIP(hipStreamSynchronize(st));
             return fail(CG_ERR_INVALID_ARGUMENT, "an element is not canonical (>= the scalar field modulus)");
         }
         if (!data_on_device) CG_HIP(hipMemcpyAsync(data, d, n * 32, hipMemcpyDeviceToHost, st));
-        CG_HIP(stream_sync(st));
+        CG_HIP(hipStreamSynchronize(st));
         if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, ctx->ev[0], ctx->ev[1]);
         return CG_OK;
     } catch (...) {

@@ -146,7 +146,7 @@ void Wm29Strided::build(const NttDomain& big, int logs_, int rank, hipStream_t s
     fold.alloc(big.n * 8);
     k_to_packed29<<<ceil_div(big.n, 256), 256, 0, st>>>(t.p, fold.p, big.n, 0, 0);
     CG_KERNEL_CHECK();
-    CG_HIP(stream_sync(st));   // `small` and `t` are released on return
+    CG_HIP(hipStreamSynchronize(st));   // `small` and `t` are released on return
 }
 
 // out[rev_d(i)] = Σ_t a[i + t·d]·T[i + t·d], i < d, t < 2^logs (Wm29Strided): a the unscaled output of the inverse
@@ -643,7 +643,7 @@ void Ntt29Unit::build(int logn_, hipStream_t st) {
     one_plain[0] = 1;
     Fr ninv = from_mont(inv(fr_from_u64(n)));
     memcpy(ninv_plain, ninv.l, 32);
-    CG_HIP(stream_sync(st));   // d and g are released on return
+    CG_HIP(hipStreamSynchronize(st));   // d and g are released on return
 }
 
 bool Ntt29Unit::run(Fr* data_dev, bool inverse, bool coset, hipStream_t st) {
@@ -654,7 +654,7 @@ bool Ntt29Unit::run(Fr* data_dev, bool inverse, bool coset, hipStream_t st) {
     if (!inverse) dit29(dom, dom.tw_fwd.p, work.p, nullptr, nullptr, false, work.p, out, nullptr, false, st, one_plain);
     else if (!coset) dit29(dom, dom.tw_inv.p, work.p, nullptr, nullptr, false, work.p, out, nullptr, false, st, ninv_plain);
     else dit29(dom, dom.tw_inv.p, work.p, nullptr, nullptr, false, work.p, out, dom.icoset.p, false, st);
-    CG_HIP(stream_sync(st));
+    CG_HIP(hipStreamSynchronize(st));
     return h_bad_input.p[0] == 0;
 }
 
