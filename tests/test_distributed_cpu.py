@@ -228,6 +228,38 @@ def _worker(rank, world, port, q):
         for case in g["proofs"]:
             ok = ok and spw.prove(w, int(case["r"], 16), int(case["s"], 16)).hex() == case["proof"]
         ok = ok and spw.all_gathers == len(g["proofs"]) and spw.scatters == 2 * len(g["proofs"])
+        # a half that FAILS on its source (the b side, computed before either scatter: HScalarScatter.compute keeps the failure):
+        # both scatters and the gather still happen everywhere, every rank gives its slot back, the failing rank raises its own
+        # exception and the others name it; the next proof is the golden one
+        class FlakyHalf:
+            def __init__(self, inner, fail_side):
+                self.inner, self.fail_side = inner, fail_side
+            def prove_partial_q_begin(self, w_, r_, on_device=False):
+                opened, fail_side = self.inner.prove_partial_q_begin(w_, r_, on_device=on_device), self.fail_side
+                real = opened.witness_map_coset_half
+                def half(which, **kw):
+                    if which == fail_side:
+                        raise ValueError("half %d fault injected on rank %d" % (which, rank))
+                    return real(which, **kw)
+                opened.witness_map_coset_half = half
+                return opened
+            def __getattr__(self, name):
+                return getattr(self.inner, name)
+        shard_f = OracleShard(o, pk, _rows(g["matrices"]), g["num_inputs"], g["num_constraints"], g["num_variables"], rank, world)
+        flaky = FlakyHalf(shard_f, 1)
+        spf2 = ShardedProver(flaky, torch.device("cpu"), arrangement="scatter", two_call=True, split_map=True)
+        src_b = min(1, world - 1)
+        try:
+            spf2.prove(w, 3003, 7)
+            ok = False
+        except ValueError as e:
+            ok = ok and rank == src_b and "half 1 fault injected" in str(e)
+        except RuntimeError as e:
+            ok = ok and rank != src_b and ("rank %d failed" % src_b) in str(e)
+        ok = ok and spf2.scatters == 2 and spf2.all_gathers == 1
+        ok = ok and getattr(shard_f, "aborted", 0) == (1 if rank == src_b else 0) and getattr(shard_f, "finished", 0) == (0 if rank == src_b else 1)
+        flaky.fail_side = -1
+        ok = ok and spf2.prove(w, int(c0_["r"], 16), int(c0_["s"], 16)).hex() == c0_["proof"]
         # ... and a STREAM of such proofs, the rank that runs the witness map rotating from job to job (k mod world): scatters
         # from one thread, gathers from another (two groups), three proofs in flight per rank; every proof the golden one, one
         # scatter + one gather per job, and the witness maps spread over the ranks
