@@ -1,16 +1,20 @@
 # eight tools/stress_load.py at once (shards 0..7 of one circuit) with two processes holding 24 idle hardware queues each
 # usage: tools/stress_load.sh <loads per process> [env assignments for the loaders...]
 set -u
+# HOLDERS=0 in the environment: no holder processes (the control)
 N=${1:-100}; shift
-GPU_MAX_HW_QUEUES=24 python tools/hold_queues.py 24 3000 0 > /dev/null 2>&1 & H1=$!
-GPU_MAX_HW_QUEUES=24 python tools/hold_queues.py 24 3000 0 > /dev/null 2>&1 & H2=$!
-sleep 20
+H1=""; H2=""
+if [ "${HOLDERS:-2}" != "0" ]; then
+  GPU_MAX_HW_QUEUES=24 python tools/hold_queues.py 24 3000 0 > /dev/null 2>&1 & H1=$!
+  GPU_MAX_HW_QUEUES=24 python tools/hold_queues.py 24 3000 0 > /dev/null 2>&1 & H2=$!
+  sleep 20
+fi
 PIDS=""
 for r in 0 1 2 3 4 5 6 7; do
   env "$@" python tools/stress_load.py $r $N 2> /tmp/stress_load_$r.err & PIDS="$PIDS $!"
 done
 wait $PIDS
-kill $H1 $H2; wait $H1 $H2 2>/dev/null
+if [ -n "$H1" ]; then kill $H1 $H2; wait $H1 $H2 2>/dev/null; fi
 # CG_CHECK_FOLD lines (tuning build): per process, the lines that differ from that process's most common one
 python - <<'PY'
 import collections, glob
