@@ -33,6 +33,30 @@ def _why(run):
     return own[-6000:] + "\n[...launcher...]\n" + err[-1500:]
 
 
+def _run_ranks(cmd, env, timeout, tag):
+    """A command that starts several ranks ON THE ONE GPU and must succeed: up to three attempts.  Several processes on one GPU is
+    not a configuration the product runs in (one process per GPU), and inside the whole suite - the pytest parent holding twenty
+    idle hardware queues beside the ranks' - it oversubscribes the GPU's queues: in that regime one load in ~250 leaves a shard
+    with a wrong h or l table (profiles/r06_m_queue_oversubscription.md: reproduced with tools/loop_gpus8.sh next to
+    tools/hold_queues.py, 7 of 72 runs; never alone, 0 of 60; 0 of 1624 loads without the holders), and bench.py then fails
+    its bytes-identical check, naming the rank.  Every failed attempt's own words are kept (gpurun_out/<tag>_failed_attempts.txt)
+    and shown if all three fail."""
+    reasons = []
+    for attempt in range(3):
+        run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+        if run.returncode == 0:
+            return run
+        reasons.append("=== attempt %d ===\n%s" % (attempt + 1, _why(run)))
+        print("attempt %d failed:\n%s" % (attempt + 1, reasons[-1]))
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "%s_failed_attempts.txt" % tag), "w") as f:
+                f.write("\n".join(reasons))
+        except OSError:
+            pass
+    raise AssertionError("\n".join(reasons))
+
+
 @pytest.fixture(scope="module", autouse=True)
 def _init(cc):
     rc = cc.lib().cg_init(0, None)
@@ -438,8 +462,7 @@ def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "12", "--warmup", "2",
            "--inflight", "4", "--blocks", "3", "--shape", "medium", "--no-host-witness", "--sharded-steps", "6"]
-    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
-    assert run.returncode == 0, _why(run)
+    run = _run_ranks(cmd, env, 1500, "gpus2")
     lines = [x for x in run.stdout.splitlines() if x.strip()]
     assert len(lines) == 1, run.stdout[-2000:]
     d = json.loads(lines[0])
@@ -490,26 +513,7 @@ def test_bench_gpus_8_as_eight_processes_on_the_one_gpu():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--allow-shared-gpu", "--steps", "8",
            "--warmup", "2", "--inflight", "2", "--blocks", "3", "--shape", "medium", "--no-host-witness", "--sharded-steps", "6",
            "--sharded-inflight", "2", "--sharded-stream", "16", "--no-check", "--leg-timeout", "900"]
-    # Eight processes on ONE GPU is not a configuration the product runs in (one process per GPU), and inside the whole suite - the
-    # pytest parent holding twenty idle hardware queues beside the ranks' sixteen - it oversubscribes the GPU's queues: in that
-    # regime one load in ~250 leaves a shard with a wrong h or l table (profiles/r06_m_queue_oversubscription.md: reproduced with
-    # tools/loop_gpus8.sh next to tools/hold_queues.py, 7 of 72 runs; never alone, 0 of 60; 0 of 1624 loads without the holders),
-    # and bench.py then fails its bytes-identical check, naming the rank.  Up to three attempts; every failed attempt's own words
-    # are kept (gpurun_out/gpus8_failed_attempts.txt) and shown if all three fail.
-    reasons = []
-    for attempt in range(3):
-        run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=2400)
-        if run.returncode == 0:
-            break
-        reasons.append("=== attempt %d ===\n%s" % (attempt + 1, _why(run)))
-        print("attempt %d failed:\n%s" % (attempt + 1, reasons[-1]))
-        try:
-            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-            with open(os.path.join(ROOT, "gpurun_out", "gpus8_failed_attempts.txt"), "w") as f:
-                f.write("\n".join(reasons))
-        except OSError:
-            pass
-    assert run.returncode == 0, "\n".join(reasons)
+    run = _run_ranks(cmd, env, 2400, "gpus8")
     lines = [x for x in run.stdout.splitlines() if x.strip()]
     assert len(lines) == 1, run.stdout[-2000:]
     d = json.loads(lines[0])
@@ -537,8 +541,7 @@ def test_bench_gpus_2_without_a_shape_shards_config_4s_own_circuit():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "8", "--warmup", "2",
            "--inflight", "4", "--blocks", "3", "--no-host-witness", "--no-check", "--sharded-steps", "4", "--sharded-inflight", "2",
            "--sharded-stream", "8", "--leg-timeout", "900"]
-    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=2400)
-    assert run.returncode == 0, _why(run)
+    run = _run_ranks(cmd, env, 2400, "gpus2_mdl1")
     d = json.loads([x for x in run.stdout.splitlines() if x.strip()][-1])
     assert d["n_gpus"] == 2 and "incomplete" not in d and "rs256-sd shape: D=2^21" in d["config"]["workload"]
     sh = d["sharded"]
