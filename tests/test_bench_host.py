@@ -165,3 +165,22 @@ def test_content_digest_memo_holds_its_arrays_and_is_not_kept_for_views_of_writa
     assert cm2._content_key is None
     buf[1] = 7
     assert api._matrices_key(cm2) != k2
+
+
+def test_every_tool_parses():
+    """tools/ holds the scripts the evidence under profiles/ was made with (profilers, A/B loops, stress reproducers): each of
+    them at least parses - Python by compile(), shell by `bash -n` - and the experiments patch names the tree it applies to"""
+    import glob
+    tools = os.path.join(ROOT, "tools")
+    pys = sorted(glob.glob(os.path.join(tools, "*.py")))
+    shs = sorted(glob.glob(os.path.join(tools, "*.sh")))
+    assert len(pys) >= 10 and len(shs) >= 5
+    for f in pys:
+        with open(f) as fh:
+            compile(fh.read(), f, "exec")
+    for f in shs:
+        r = subprocess.run(["bash", "-n", f], capture_output=True, text=True)
+        assert r.returncode == 0, (f, r.stderr)
+    with open(os.path.join(tools, "patches", "r06_load_stress_experiments.patch")) as fh:
+        head = fh.read(2000)
+    assert "NOT applied" in head and "fingerprint" in head
